@@ -1,0 +1,360 @@
+#!/usr/bin/env python3
+"""tools/make_goldens.py -- generate tests/golden/*.npz by running the REFERENCE.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).
+The reference's source files are imported from where they lie and executed; only
+their inputs and outputs are written out (small fixtures).  Harness tricks
+(SURVEY.md 8c):
+  * `cv2`, `colour` are not installed -> empty placeholder modules in sys.modules;
+    cv2.GaussianBlur / cv2.Sobel are injected where a fixture needs the blur
+    (identity, or this repo's OpenCV-semantics restatement: PARITY UNPINNED);
+  * `animals/__init__.py` cannot be imported (animals/cat.py holds merge-conflict
+    markers) -> a synthetic `animals` package with the real __path__;
+  * classic_rgb_to_hsi's analytic branch is guarded by torch.cuda.is_available()
+    -> the module's `torch` global is swapped for a proxy that reports CUDA and
+    maps device="cuda" to CPU tensors, so the reference's own lines 47-82 run.
+
+Usage: python tools/make_goldens.py [--only NAME] (writes tests/golden/).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import cpu_ref as O  # noqa: E402  (only for the injected OpenCV-semantics blur)
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_synth = _load("_avx_synth", os.path.join(ROOT, "animal-vision_amd", "synthetic.py"))
+noise_frame, structured_frame = _synth.noise_frame, _synth.structured_frame
+
+# ---- placeholder third-party modules ---------------------------------------
+cv2 = types.ModuleType("cv2")
+cv2.BORDER_REFLECT101 = 4
+cv2.BORDER_REFLECT_101 = 4
+cv2.BORDER_DEFAULT = 4
+cv2.CV_32F = 5
+BLUR_MODE = {"mode": "oracle"}
+
+
+def _GaussianBlur(src, ksize, sigmaX, sigmaY=0.0, borderType=4, dst=None):
+    if BLUR_MODE["mode"] == "identity":
+        return src.copy()
+    return O.cv_gaussian_blur(src, tuple(ksize), float(sigmaX), float(sigmaY))
+
+
+cv2.GaussianBlur = _GaussianBlur
+sys.modules["cv2"] = cv2
+sys.modules["colour"] = types.ModuleType("colour")
+
+sys.path.insert(0, REF)
+animals_pkg = types.ModuleType("animals")
+animals_pkg.__path__ = [os.path.join(REF, "animals")]
+sys.modules["animals"] = animals_pkg
+
+import importlib  # noqa: E402
+
+ref_au = importlib.import_module("animals.animal_utils")
+ref_uvh = importlib.import_module("uv_helpers")
+ref_uvm = importlib.import_module("uv_mappers")
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# =============================================================================
+def g_srgb_tables():
+    """a3+a4 decode LUT; a11 encode thresholds (f32 dichromat, f64 cat tail, f32 UV)."""
+    codes = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
+    lut = ref_au.srgb_to_linear(ref_au.get_normalized_image(codes))[..., 0].reshape(256)
+    assert lut.dtype == np.float32
+    # to_float01 + uv_helpers.srgb_to_linear (mantis/reindeer route) on u8 codes
+    lut_uv = ref_uvh.srgb_to_linear(ref_uvh.to_float01(codes))[..., 0].reshape(256)
+
+    def enc_dog(x):  # animals/dog.py:54-57
+        s = np.clip(ref_au.linear_to_srgb(np.clip(x, 0.0, 1.0)), 0.0, 1.0)
+        return (s * 255.0 + 0.5).astype(np.uint8)
+
+    def enc_bee(x):  # animals/honeybee.py:166-171
+        s = ref_uvh.linear_to_srgb(np.clip(x, 0.0, 1.0))
+        return (s * 255.0 + 0.5).astype(np.uint8)
+
+    def enc_ff01(x):  # animals/mantis_shrimp.py:278 (from_float01)
+        return ref_uvh.from_float01(ref_uvh.linear_to_srgb(np.clip(x, 0.0, 1.0)), np.uint8)
+
+    thr32 = O.encode_thresholds(np.float32, lambda x: enc_dog(np.asarray(x, np.float32)))
+    thr64 = O.encode_thresholds(np.float64, lambda x: enc_dog(np.asarray(x, np.float64)))
+    thr_bee = O.encode_thresholds(np.float32, lambda x: enc_bee(np.asarray(x, np.float32)))
+    thr_ff = O.encode_thresholds(np.float32, lambda x: enc_ff01(np.asarray(x, np.float32)))
+    rng = np.random.default_rng(7)
+    ramp = np.concatenate([rng.random(1 << 16, dtype=np.float32), np.linspace(0, 1, 4097, dtype=np.float32),
+                           np.array([-0.5, 0.0, 1.0, 1.5, 0.0031308, 0.0031309], np.float32)])
+    near = np.concatenate([np.nextafter(thr32, np.float32(0)), thr32, np.nextafter(thr32, np.float32(2))]).astype(np.float32)
+    ramp = np.concatenate([ramp, near])
+    ramp64 = np.concatenate([ramp.astype(np.float64), rng.random(1 << 14), np.nextafter(thr64, 0.0), thr64])
+    save("srgb_tables", decode_lut=lut, decode_lut_uv=lut_uv, enc_thr_f32=thr32, enc_thr_f64=thr64,
+         enc_thr_bee_f32=thr_bee, enc_thr_ff01_f32=thr_ff,
+         ramp_f32=ramp, ramp_f32_u8=enc_dog(ramp), ramp_f32_bee_u8=enc_bee(ramp), ramp_f32_ff01_u8=enc_ff01(ramp),
+         ramp_f64=ramp64, ramp_f64_u8=enc_dog(ramp64))
+    print("   thresholds equal (dog f32 == bee f32):", np.array_equal(thr32, thr_bee), " (== from_float01):", np.array_equal(thr32, thr_ff))
+
+
+def g_matrices():
+    """a5/a6: collapse_LMS_matrix for every (alpha, s) of SURVEY Appendix A."""
+    pairs = sorted({(s.alpha, s.s_scale) for s in O.DICHROMATS.values()} | {(0.45, 0.80)})
+    mats = np.stack([ref_au.collapse_LMS_matrix(a, s) for a, s in pairs])
+    E = np.eye(3, dtype=np.float32)
+    save("collapse_matrices", pairs=np.array(pairs, np.float64), T=mats,
+         lms_of_eye=ref_au.sRGB_to_LMS(E), rgb_of_eye=ref_au.LMS_to_RGB(E))
+
+
+def _species(name):
+    mod = importlib.import_module(f"animals.{name}")
+    cls = [v for k, v in vars(mod).items() if isinstance(v, type) and k.lower() == name.replace("_", "")][0]
+    return cls()
+
+
+def g_dichromat():
+    """a1-a11: <Species>.visualize of the reference on seeded frames, with the blur
+    (cv2.GaussianBlur) injected as identity and as this repo's OpenCV restatement."""
+    frames = {"n48": noise_frame(0, 48, 64), "s48": structured_frame(0, 48, 64), "n120": noise_frame(1, 120, 160),
+              "dark": (noise_frame(2, 24, 32) // 255).astype(np.uint8)}  # all <= 1: the a3 "no /255" branch
+    out = {f"in_{k}": v for k, v in frames.items()}
+    for name in sorted(O.DICHROMATS):
+        if name == "cat":
+            continue  # animals/cat.py does not parse (F2); its colour core is re-enacted below
+        sp = _species(name)
+        for mode in ("identity", "oracle"):
+            BLUR_MODE["mode"] = mode
+            for k, f in frames.items():
+                if k == "n120" and name not in ("dog", "wolf", "sheep"):
+                    continue  # keep the fixture small: the big frame only for three species
+                base, res = sp.visualize(f.copy())
+                assert base.dtype == f.dtype and res.dtype == f.dtype
+                out[f"{name}_{mode}_{k}"] = res
+    # Cat colour core, cat.py:95-103,109 (Tina-animals side, Q8) re-enacted with the
+    # reference's own helpers; ENABLE_FOV_WARP path excluded.
+    for mode in ("identity", "oracle"):
+        BLUR_MODE["mode"] = mode
+        for k, f in frames.items():
+            H, W = f.shape[:2]
+            cat01 = ref_au.get_normalized_image(f)
+            lin = ref_au.srgb_to_linear(cat01)
+            vec = lin.reshape(-1, 3)
+            lms = ref_au.sRGB_to_LMS(vec)
+            alpha = 0.5
+            LM = alpha * lms[:, 0] + (1.0 - alpha) * lms[:, 1]
+            merged = np.stack([LM, LM, lms[:, 2]], axis=1)
+            lin_rgb = ref_au.LMS_to_RGB(merged).reshape(H, W, 3)
+            assert lin_rgb.dtype == np.float64
+            lin_rgb = ref_au.apply_acuity_blur(lin_rgb, sigma=1.0)
+            cat_srgb = np.clip(ref_au.linear_to_srgb(np.clip(lin_rgb, 0.0, 1.0)), 0.0, 1.0)
+            out[f"cat_{mode}_{k}"] = (cat_srgb * 255.0 + 0.5).astype(np.uint8)
+    # float-input contract (dtype == input dtype): dog on a float32 [0,1] frame
+    BLUR_MODE["mode"] = "oracle"
+    f32 = (frames["n48"].astype(np.float32) / 255.0)
+    out["in_f32"] = f32
+    out["dog_oracle_f32"] = _species("dog").visualize(f32.copy())[1]
+    # intermediate: linear colour stage of dog on n48 (pins the FMA-chain matmul)
+    lin = ref_au.srgb_to_linear(ref_au.get_normalized_image(frames["n48"]))
+    out["dog_colorstage_n48"] = (lin.reshape(-1, 3) @ ref_au.collapse_LMS_matrix(0.58, 0.65).T).reshape(lin.shape)
+    # a10 helpers on a seeded linear image
+    x = np.random.default_rng(3).random((20, 24, 3), dtype=np.float32)
+    out["helper_in"] = x
+    out["chroma_0p4"] = ref_au.apply_chroma_compression(x.copy(), 0.4)
+    out["scone_rat"] = ref_au.apply_s_cone_vertical_gain(x.copy(), s_top=1.3, s_bottom=0.5, power=1.4, extra_boost=0.25)
+    out["scone_band"] = ref_au.apply_s_cone_vertical_gain(x.copy(), 1.0, 0.6, band=(0.4, 0.2, 0.5), clamp=False)
+    save("dichromat", **out)
+
+
+def g_uv():
+    """a12, a15-a18, a20, a21 + hsv/snow-glare on seeded planes (pure NumPy reference code)."""
+    rng = np.random.default_rng(11)
+    out = {}
+    lam31 = np.linspace(400.0, 700.0, 31, dtype=np.float32)
+    lam81 = np.linspace(300.0, 700.0, 81, dtype=np.float32)
+    out["lam31"], out["lam81"] = lam31, lam81
+    out["d65_31"], out["d65_81"] = ref_uvh.D65_like(lam31), ref_uvh.D65_like(lam81)
+    bands = [(320.0, 360.0), (360.0, 400.0), (400.0, 430.0), (610.0, 680.0), (300.0, 400.0), (100.0, 200.0), (405.0, 406.0), (400.0, 400.0)]
+    out["bp_bands"] = np.array(bands)
+    out["bp_31"] = np.stack([ref_uvh.bandpass_weights(lam31, lo, hi) for lo, hi in bands])
+    out["bp_81"] = np.stack([ref_uvh.bandpass_weights(lam81, lo, hi) for lo, hi in bands])
+    cube = rng.random((18, 22, 31), dtype=np.float32)
+    out["cube31"] = cube
+    out["ib_31"] = np.stack([ref_uvh.integrate_band(cube, lam31, lo, hi) for lo, hi in bands[:5]])
+    out["iuv_31"] = ref_uvh.integrate_uv(cube, lam31, 400.0, 460.0)
+    U, B, G = (rng.random((36, 44), dtype=np.float32) ** 2 for _ in range(3))
+    U = U * 0.3
+    out["U"], out["B"], out["G"] = U, B, G
+    out["safe_norm_U"] = ref_uvh.safe_norm(U)
+    out["safe_norm_const"] = ref_uvh.safe_norm(np.full((4, 5), 0.25, np.float32))
+    for nm, fn in (("wp", ref_uvh.von_kries_white_patch), ("gw", ref_uvh.von_kries_gray_world)):
+        r = fn(U, B, G)
+        out[f"vk_{nm}"] = np.stack(r)
+    out["map_falsecolor"] = ref_uvm.map_falsecolor(U, B, G)
+    out["map_opponent"] = ref_uvm.map_opponent(U, B, G)
+    out["map_upy"] = ref_uvm.map_uv_purple_yellow(U)
+    out["map_upy_soft"] = ref_uvm.map_uv_purple_yellow_soft(U)
+    out["map_mixed_035"] = ref_uvm.map_falsecolor_uv_mixed(U, B, G)
+    out["map_mixed_045"] = ref_uvm.map_falsecolor_uv_mixed(U, B, G, alpha=0.45)
+    M = rng.random((3, 3)).astype(np.float32)
+    out["M"], out["map_matrix"] = M, ref_uvm.map_linear_matrix(U, B, G, M)
+    hsv = rng.random((16, 16, 3), dtype=np.float32)
+    hsv[0, 0] = (1.0, 0.5, 0.5)  # floor(6h) == 6 -> i_mod == 0
+    out["hsv"], out["hsv_rgb"] = hsv, ref_uvm.hsv_to_rgb(hsv)
+    x = rng.random((10, 12, 3), dtype=np.float32) * 1.2
+    out["glare_in"], out["glare_out"] = x, ref_uvh.snow_glare_tone_compress(x, strength=0.7)
+    f = noise_frame(5, 8, 9)
+    out["tf01_u8_in"], out["tf01_u8"] = f, ref_uvh.to_float01(f)
+    f255 = f.astype(np.float32)
+    out["tf01_f255"] = ref_uvh.to_float01(f255)
+    out["ff01_u8"] = ref_uvh.from_float01(ref_uvh.to_float01(f) * 0.9, np.uint8)
+    save("uv_helpers", **out)
+
+
+class _TorchCudaAsCpu:
+    """Proxy for the `torch` global of classic_rgb_to_hsi.py: CUDA 'available', tensors on CPU."""
+
+    def __init__(self, real):
+        self._r = real
+        self.cuda = types.SimpleNamespace(is_available=lambda: True)
+
+    def __getattr__(self, n):
+        return getattr(self._r, n)
+
+    def as_tensor(self, data, dtype=None, device=None):
+        return self._r.as_tensor(data, dtype=dtype)
+
+
+def _ref_classic():
+    import torch
+
+    mod = importlib.import_module("ml.classic_rgb_to_hsi.classic_rgb_to_hsi")
+    mod.torch = _TorchCudaAsCpu(torch)
+    return mod.classic_rgb_to_hsi
+
+
+def g_lobes():
+    """a13: the reference's analytic branch (classic_rgb_to_hsi.py:47-82) on float frames."""
+    conv = _ref_classic()
+    rng = np.random.default_rng(21)
+    img = rng.random((12, 14, 3), dtype=np.float32)
+    img[0, 0] = (0.0, 0.04045, 1.0)
+    out = {"img": img}
+    for nm, lam in (("31", np.linspace(400.0, 700.0, 31, dtype=np.float32)),
+                    ("81", np.linspace(300.0, 700.0, 81, dtype=np.float32)),
+                    ("129", np.linspace(320.0, 700.0, 129))):
+        out[f"lam{nm}"] = lam
+        out[f"hsi{nm}"] = conv(img, wavelengths=lam)
+    save("lobes", **out)
+
+
+def g_honeybee():
+    """a12-a21 end to end: the reference HoneyBee class, every mapping mode."""
+    _ref_classic()
+    hb = importlib.import_module("animals.honeybee")
+    hb.classic_rgb_to_hsi = sys.modules["ml.classic_rgb_to_hsi.classic_rgb_to_hsi"].classic_rgb_to_hsi
+    ref_uvh.cv2 = cv2  # uv_helpers.gaussian_blur takes its cv2 branch (injected blur)
+    frames = {"s40": structured_frame(0, 40, 56), "n40": noise_frame(3, 40, 56)}
+    out = {f"in_{k}": v for k, v in frames.items()}
+    BLUR_MODE["mode"] = "oracle"
+    M = np.array([[0.9, 0.1, 0.0], [0.1, 0.2, 0.7], [0.3, 0.6, 0.1]], np.float32)
+    out["custom_matrix"] = M
+    for mode in ("opponent", "falsecolor", "uv_purple_yellow", "falsecolor_uv_mixed", "custom_matrix"):
+        for adapt in ("white_patch", "gray_world"):
+            bee = hb.HoneyBee(mapping_mode=mode, adaptation=adapt, custom_matrix=M if mode == "custom_matrix" else None)
+            for k, f in frames.items():
+                base, res = bee.visualize(f)
+                assert base is f and res.dtype == np.uint8
+                out[f"{mode}_{adapt}_{k}"] = res
+    bee = hb.HoneyBee(blur_sigma_px=0.0)
+    out["opponent_noblur_s40"] = bee.visualize(frames["s40"])[1]
+    # intermediates for the default species on s40: catches after adaptation + blur
+    bee = hb.HoneyBee()
+    img01 = ref_uvh.to_float01(frames["s40"])
+    hsi = hb.classic_rgb_to_hsi(img01, wavelengths=bee.lambdas)
+    rad = hsi * bee.E(bee.lambdas).astype(hsi.dtype)[None, None, :]
+    U = np.tensordot(rad, bee.UV_curve, axes=([2], [0]))
+    B = np.tensordot(rad, bee.Blue_curve, axes=([2], [0]))
+    G = np.tensordot(rad, bee.Green_curve, axes=([2], [0]))
+    out["catches_s40"] = np.stack([U, B, G])
+    out["curves"] = np.stack([bee.UV_curve, bee.Blue_curve, bee.Green_curve])
+    ref_uvh.cv2 = None
+    save("honeybee", **out)
+
+
+def g_mstpp():
+    """a25: reference MST_Plus_Plus with torch.manual_seed(0) weights (rounded to fp16 and
+    stored), outputs on two small frames; a26: pad/crop/tile index math of predict_torch.py."""
+    import torch
+
+    arch = _load("_ref_mstpp", os.path.join(REF, "ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py"))
+    torch.manual_seed(0)
+    model = arch.MST_Plus_Plus().eval()
+    sd = {k: v.half().float() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    rng = np.random.default_rng(31)
+    out = {}
+    for nm, (h, w) in (("60x70", (60, 70)), ("64x64", (64, 64))):
+        x = rng.random((1, 3, h, w), dtype=np.float32)
+        with torch.no_grad():
+            y = model(torch.from_numpy(x)).numpy()
+        out[f"x_{nm}"], out[f"y_{nm}"] = x, y
+    save("mstpp_io", **out)
+    save("mstpp_weights_fp16", **{k: v.numpy().astype(np.float16) for k, v in sd.items()})
+    print("   params:", sum(v.numel() for v in sd.values()), "tensors:", len(sd))
+    # predict_torch.py helpers (pure NumPy); stub its architecture import
+    stub = types.ModuleType("ml.MST_plus_plus.predict_code.architecture")
+    stub.model_generator = lambda *a, **k: None
+    for n in ("ml.MST_plus_plus", "ml.MST_plus_plus.predict_code"):
+        if n not in sys.modules:
+            m = types.ModuleType(n)
+            m.__path__ = [os.path.join(REF, *n.split(".")[0:1], *n.split(".")[1:])]
+            sys.modules[n] = m
+    sys.modules["ml.MST_plus_plus.predict_code.architecture"] = stub
+    pt = _load("_ref_predict_torch", os.path.join(REF, "ml/MST_plus_plus/predict_code/predict_torch.py"))
+    o2 = {}
+    img = rng.random((37, 45, 3), dtype=np.float32)
+    pad, pads = pt._pad_to_multiple_reflect(img, 16)
+    o2["img"], o2["pad16"], o2["pads16"] = img, pad, np.array(pads)
+    o2["crop16"] = pt._crop_pads(pad, pads)
+    o2["tiles_300_500_256_64"] = np.array(pt._tile_coords(300, 500, 256, 64))
+    o2["tiles_200_1100_256_64"] = np.array(pt._tile_coords(200, 1100, 256, 64))
+    o2["hann_8_6"] = pt._hann2d(8, 6)
+    o2["tf01_u8"] = pt._to_float01(noise_frame(9, 5, 6))
+    save("predict_torch_helpers", **o2)
+
+
+GENERATORS = {"srgb_tables": g_srgb_tables, "matrices": g_matrices, "dichromat": g_dichromat, "uv": g_uv,
+              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    for name, fn in GENERATORS.items():
+        if a.only and a.only != name:
+            continue
+        print(f"[{name}]")
+        fn()
