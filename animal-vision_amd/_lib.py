@@ -1,0 +1,79 @@
+"""ctypes binding of libavx.so (C ABI: include/avx.h).  No torch types cross this boundary.
+
+The library is the product: if it is missing this module raises at import -- there is no CPU path."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavx.so")
+
+AVX_OK = 0
+AVX_ERR_INVALID, AVX_ERR_NO_DEVICE, AVX_ERR_HIP, AVX_ERR_UNSUPPORTED, AVX_ERR_NOMEM = -1, -2, -3, -4, -5
+AVX_COLOR_MATRIX, AVX_COLOR_CAT_MERGE = 0, 1
+AVX_POST_NONE, AVX_POST_GAUSS, AVX_POST_ROWGAIN = 0, 1, 2
+AVX_MAX_KSIZE = 33
+
+
+class AvxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libavx error {code}: {msg}")
+        self.code = code
+
+
+class DichromatDesc(ctypes.Structure):
+    """avx_dichromat_desc (include/avx.h)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("color_mode", ctypes.c_int32),
+        ("matrix", ctypes.c_float * 9),
+        ("cat_alpha", ctypes.c_float),
+        ("cat_beta", ctypes.c_float),
+        ("post_mode", ctypes.c_int32),
+        ("ksize", ctypes.c_int32),
+        ("taps_host", ctypes.POINTER(ctypes.c_double)),
+        ("row_gain_host", ctypes.POINTER(ctypes.c_float)),
+        ("row_gain_clamp", ctypes.c_int32),
+        ("chroma_enable", ctypes.c_int32),
+        ("chroma_keep", ctypes.c_float),
+    ]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C animal-vision_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+    )
+lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_SIGS = {
+    "avx_abi_version": (_i, []),
+    "avx_device_count": (_i, []),
+    "avx_init": (_i, [_i, ctypes.POINTER(_vp)]),
+    "avx_destroy": (None, [_vp]),
+    "avx_last_error": (ctypes.c_char_p, [_vp]),
+    "avx_malloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "avx_free": (_i, [_vp, _vp]),
+    "avx_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "avx_host_free": (_i, [_vp, _vp]),
+    "avx_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "avx_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "avx_memset": (_i, [_vp, _vp, _i, _sz, _vp]),
+    "avx_stream_create": (_i, [_vp, ctypes.POINTER(_vp)]),
+    "avx_stream_destroy": (_i, [_vp, _vp]),
+    "avx_sync": (_i, [_vp, _vp]),
+    "avx_timer_start": (_i, [_vp, _vp]),
+    "avx_timer_stop": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "avx_dichromat_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(DichromatDesc), _vp]),
+    "avx_get_table": (_i, [_i, _vp, _sz]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = stale libavx.so: rebuild
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.avx_abi_version() != 1:
+    raise ImportError(f"libavx.so ABI {lib.avx_abi_version()} != 1 expected by this package: rebuild")

@@ -1,0 +1,6 @@
+"""Species registry; same export names as the reference's animals/__init__.py:1-32."""
+from .animal import Animal  # noqa: F401
+from ._dichromats import (  # noqa: F401
+    Bear, Cat, Cow, Deer, Dog, Elephant, Fox, Goat, Horse, Kangaroo, Lion, Panda, Pig, Rabbit, Raccoon,
+    Rat, Sheep, Squirrel, Tiger, Wolf,
+)

@@ -1,0 +1,77 @@
+"""The dichromat species (reference: animals/{dog,cat,...,tiger}.py), all on the fused HIP kernel.
+
+Each class keeps the reference's surface: no-argument constructor, `visualize(image) ->
+(baseline, out)` with `baseline is image` (dog.py:61) and out.dtype == image.dtype.
+Parameters: SURVEY.md Appendix A, each from the cited species file."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+from ..dichromat import DichromatOp, DichromatSpec
+from .animal import Animal
+from .animal_utils import check_input_image
+
+
+class _Dichromat(Animal):
+    SPEC: DichromatSpec = None  # type: ignore
+
+    def __init__(self):
+        self._op = None
+
+    def _operator(self) -> DichromatOp:
+        if self._op is None:
+            self._op = DichromatOp(self.SPEC)
+        return self._op
+
+    def visualize(self, image: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        assert check_input_image(image)  # dog.py:33
+        if image.dtype != np.uint8:
+            # The reference tolerates float / wider-int frames (animal_utils.py:45-48); its video,
+            # webcam and image renderers only ever produce uint8 (video.py:95).  Not silently
+            # re-routed to a CPU path: say so.
+            raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 frames, got {image.dtype}")
+        return image, self._operator()(image)
+
+
+def _mk(cls_name: str, spec: DichromatSpec, doc: str):
+    return type(cls_name, (_Dichromat,), {"SPEC": spec, "__doc__": doc})
+
+
+Dog = _mk("Dog", DichromatSpec("dog", 0.58, 0.65, sigma=3.5), "animals/dog.py:46,51")
+Squirrel = _mk("Squirrel", DichromatSpec("squirrel", 0.55, 1.05, sigma=0.7), "animals/squirrel.py:29,34")
+Elephant = _mk("Elephant", DichromatSpec("elephant", 0.60, 0.95, sigma=1.8), "animals/elephant.py:29,34")
+Lion = _mk("Lion", DichromatSpec("lion", 0.60, 0.95, sigma=1.2), "animals/lion.py:29,34")
+Tiger = _mk("Tiger", DichromatSpec("tiger", 0.60, 0.95, sigma=1.2), "animals/tiger.py:29,34")
+Bear = _mk("Bear", DichromatSpec("bear", 0.60, 0.95, sigma=1.6), "animals/bear.py:29,34")
+Wolf = _mk("Wolf", DichromatSpec("wolf", 0.65, 0.95, sigma=1.4), "animals/wolf.py:29,34")
+Fox = _mk("Fox", DichromatSpec("fox", 0.65, 0.98, sigma=1.3), "animals/fox.py:29,34")
+Raccoon = _mk("Raccoon", DichromatSpec("raccoon", 0.60, 0.98, sigma=2.0), "animals/raccoon.py:29,34")
+Rat = _mk("Rat", DichromatSpec("rat", 0.05, 0.86, post="scone", scone=(1.3, 0.5, 1.4, 0.25)), "animals/rat.py:29,34")
+# Streak-blur species: colour stage and parameters are in place, the per-row-sigma
+# kernel is the next row to land; constructing them works, visualize raises NotImplementedError.
+Sheep = _mk("Sheep", DichromatSpec("sheep", 0.74, 1.06, post="streak", streak=(0.48, 0.8, 2.2, 6.0)), "animals/sheep.py:30,35")
+Pig = _mk("Pig", DichromatSpec("pig", 0.89, 1.32, post="streak", streak=(0.5, 1.2, 2.5, 3.0)), "animals/pig.py:30,35,38 (chroma result discarded, Q4)")
+Cow = _mk("Cow", DichromatSpec("cow", 0.84, 1.07, post="streak", streak=(0.5, 0.9, 2.3, 6.5)), "animals/cow.py:29,34")
+Goat = _mk("Goat", DichromatSpec("goat", 0.75, 1.06, post="streak", streak=(0.5, 0.8, 2.4, 8.0)), "animals/goat.py:29,34")
+Horse = _mk("Horse", DichromatSpec("horse", 0.30, 1.02, post="streak", streak=(0.5, 0.8, 2.2, 6.0)), "animals/horse.py:29,34")
+Rabbit = _mk("Rabbit", DichromatSpec("rabbit", 0.20, 1.01, post="streak", streak=(0.52, 0.9, 2.5, 5.0), chroma=0.06), "animals/rabbit.py:29,34,37")
+Panda = _mk("Panda", DichromatSpec("panda", 0.58, 0.74, post="streak", streak=(0.52, 1.0, 2.1, 4.5), chroma=0.06), "animals/panda.py:29,34,37")
+Deer = _mk("Deer", DichromatSpec("deer", 0.60, 0.95, post="streak", streak=(0.5, 0.8, 2.6, 8.0)), "animals/deer.py:29,34")
+Kangaroo = _mk("Kangaroo", DichromatSpec("kangaroo", 0.60, 0.98, post="streak", streak=(0.55, 0.8, 2.3, 8.0)), "animals/kangaroo.py:29,34")
+
+
+class Cat(_Dichromat):
+    """animals/cat.py (Tina-animals side of the unresolved merge, quirk Q8): colour core :95-103,109.
+
+    The human-zoom baseline and the binocular FOV warp (cat.py:74-92) are geometric resampling
+    (SURVEY 8f row 1, cv2.resize / cv2.remap): ENABLE_FOV_WARP defaults to False here until those
+    kernels land, and the baseline returned is the input frame."""
+
+    SPEC = DichromatSpec("cat", 0.5, 1.0, color="cat_merge", sigma=1.0)
+    CAMERA_HFOV_DEG = 100.0
+    CAT_PER_EYE_HALF_FOV_DEG = 105.0
+    CAT_OVERLAP_DEG = 40.0
+    CAT_TO_HUMAN_RATIO = 1.30
+    ENABLE_FOV_WARP = False

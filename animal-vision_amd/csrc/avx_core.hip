@@ -1,0 +1,201 @@
+// csrc/avx_core.hip -- context, device memory, streams, HIP-event stopwatch of libavx.so.
+// Nothing here exists in the reference (pure Python, no device runtime: SURVEY.md 2.1); it is the
+// plumbing under the C ABI of include/avx.h.
+#include "avx_internal.h"
+#include "srgb_tables.h"
+
+static char g_init_err[512] = "";
+
+int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_init_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int avx_ensure_scratch(avx_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_cap) return AVX_OK;
+    if (ctx->d_scratch) AVX_HIP(ctx, hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr;
+    ctx->scratch_cap = 0;
+    size_t cap = bytes + bytes / 4;
+    AVX_HIP(ctx, hipMalloc(&ctx->d_scratch, cap));
+    ctx->scratch_cap = cap;
+    return AVX_OK;
+}
+
+extern "C" {
+
+int avx_abi_version(void) { return AVX_ABI_VERSION; }
+
+int avx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* avx_last_error(const avx_ctx* ctx) { return ctx ? ctx->err : g_init_err; }
+
+int avx_init(int device, avx_ctx** out_ctx) {
+    if (!out_ctx) return avx_fail(nullptr, AVX_ERR_INVALID, "avx_init: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = avx_device_count();
+    if (n <= 0) return avx_fail(nullptr, AVX_ERR_NO_DEVICE, "avx_init: no HIP device visible (libavx has no CPU path)");
+    if (device < 0 || device >= n)
+        return avx_fail(nullptr, AVX_ERR_NO_DEVICE, "avx_init: device %d out of range (0..%d)", device, n - 1);
+    avx_ctx* ctx = new avx_ctx();
+    ctx->device = device;
+#define INIT_HIP(call)                                                                                      \
+    do {                                                                                                    \
+        hipError_t e__ = (call);                                                                            \
+        if (e__ != hipSuccess) {                                                                            \
+            avx_fail(nullptr, AVX_ERR_HIP, "avx_init: %s failed: %s", #call, hipGetErrorString(e__));      \
+            delete ctx;                                                                                     \
+            return AVX_ERR_HIP;                                                                             \
+        }                                                                                                   \
+    } while (0)
+    INIT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    INIT_HIP(hipGetDeviceProperties(&prop, device));
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    INIT_HIP(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
+    INIT_HIP(hipEventCreate(&ctx->t0));
+    INIT_HIP(hipEventCreate(&ctx->t1));
+    INIT_HIP(hipMalloc((void**)&ctx->d_decode_lut, 256 * sizeof(float)));
+    INIT_HIP(hipMalloc((void**)&ctx->d_enc_thr_f32, 256 * sizeof(float)));
+    INIT_HIP(hipMalloc((void**)&ctx->d_enc_thr_f64, 256 * sizeof(double)));
+    INIT_HIP(hipMemcpy(ctx->d_decode_lut, kDecodeLutBits, 256 * 4, hipMemcpyHostToDevice));
+    INIT_HIP(hipMemset(ctx->d_enc_thr_f32, 0x7f, 256 * 4));  // pad entry: huge, never <= x
+    INIT_HIP(hipMemset(ctx->d_enc_thr_f64, 0x7f, 256 * 8));
+    INIT_HIP(hipMemcpy(ctx->d_enc_thr_f32, kEncThrF32Bits, 255 * 4, hipMemcpyHostToDevice));
+    INIT_HIP(hipMemcpy(ctx->d_enc_thr_f64, kEncThrF64Bits, 255 * 8, hipMemcpyHostToDevice));
+#undef INIT_HIP
+    *out_ctx = ctx;
+    return AVX_OK;
+}
+
+void avx_destroy(avx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->d_decode_lut) (void)hipFree(ctx->d_decode_lut);
+    if (ctx->d_enc_thr_f32) (void)hipFree(ctx->d_enc_thr_f32);
+    if (ctx->d_enc_thr_f64) (void)hipFree(ctx->d_enc_thr_f64);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_row_gain) (void)hipFree(ctx->d_row_gain);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
+    delete ctx;
+}
+
+int avx_malloc(avx_ctx* ctx, size_t bytes, void** out_dptr) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, out_dptr != nullptr, "avx_malloc: out_dptr is NULL");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out_dptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) return avx_fail(ctx, AVX_ERR_NOMEM, "avx_malloc: out of device memory (%zu bytes)", bytes);
+    AVX_HIP(ctx, e);
+    return AVX_OK;
+}
+
+int avx_free(avx_ctx* ctx, void* dptr) {
+    if (!ctx) return AVX_ERR_INVALID;
+    if (dptr) AVX_HIP(ctx, hipFree(dptr));
+    return AVX_OK;
+}
+
+int avx_host_alloc(avx_ctx* ctx, size_t bytes, void** out_hptr) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, out_hptr != nullptr, "avx_host_alloc: out_hptr is NULL");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    AVX_HIP(ctx, hipHostMalloc(out_hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return AVX_OK;
+}
+
+int avx_host_free(avx_ctx* ctx, void* hptr) {
+    if (!ctx) return AVX_ERR_INVALID;
+    if (hptr) AVX_HIP(ctx, hipHostFree(hptr));
+    return AVX_OK;
+}
+
+int avx_memcpy_h2d(avx_ctx* ctx, void* dst, const void* src_host, size_t bytes, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, dst && src_host, "avx_memcpy_h2d: NULL pointer");
+    AVX_HIP(ctx, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, avx_pick_stream(ctx, stream)));
+    return AVX_OK;
+}
+
+int avx_memcpy_d2h(avx_ctx* ctx, void* dst_host, const void* src, size_t bytes, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, dst_host && src, "avx_memcpy_d2h: NULL pointer");
+    AVX_HIP(ctx, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, avx_pick_stream(ctx, stream)));
+    return AVX_OK;
+}
+
+int avx_memset(avx_ctx* ctx, void* dst, int value, size_t bytes, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, dst != nullptr, "avx_memset: NULL pointer");
+    AVX_HIP(ctx, hipMemsetAsync(dst, value, bytes, avx_pick_stream(ctx, stream)));
+    return AVX_OK;
+}
+
+int avx_stream_create(avx_ctx* ctx, void** out_stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, out_stream != nullptr, "avx_stream_create: out_stream is NULL");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s;
+    AVX_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = (void*)s;
+    return AVX_OK;
+}
+
+int avx_stream_destroy(avx_ctx* ctx, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    if (stream) AVX_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    return AVX_OK;
+}
+
+int avx_sync(avx_ctx* ctx, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    if (stream)
+        AVX_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    else {
+        AVX_HIP(ctx, hipSetDevice(ctx->device));
+        AVX_HIP(ctx, hipDeviceSynchronize());
+    }
+    return AVX_OK;
+}
+
+int avx_timer_start(avx_ctx* ctx, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_HIP(ctx, hipEventRecord(ctx->t0, avx_pick_stream(ctx, stream)));
+    return AVX_OK;
+}
+
+int avx_timer_stop(avx_ctx* ctx, void* stream, float* out_ms) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, out_ms != nullptr, "avx_timer_stop: out_ms is NULL");
+    AVX_HIP(ctx, hipEventRecord(ctx->t1, avx_pick_stream(ctx, stream)));
+    AVX_HIP(ctx, hipEventSynchronize(ctx->t1));
+    AVX_HIP(ctx, hipEventElapsedTime(out_ms, ctx->t0, ctx->t1));
+    return AVX_OK;
+}
+
+int avx_get_table(int which, void* dst_host, size_t capacity) {
+    const void* src = nullptr;
+    size_t size = 0;
+    switch (which) {
+        case 0: src = kDecodeLutBits; size = sizeof(kDecodeLutBits); break;
+        case 1: src = kEncThrF32Bits; size = sizeof(kEncThrF32Bits); break;
+        case 2: src = kEncThrF64Bits; size = sizeof(kEncThrF64Bits); break;
+        default: return AVX_ERR_INVALID;
+    }
+    if (dst_host) memcpy(dst_host, src, capacity < size ? capacity : size);
+    return (int)size;
+}
+
+}  // extern "C"

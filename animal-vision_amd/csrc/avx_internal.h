@@ -1,0 +1,49 @@
+// csrc/avx_internal.h -- shared between the translation units of libavx.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/avx.h"
+
+struct avx_ctx {
+    int device = 0;
+    hipStream_t compute = nullptr;  // used when the caller passes stream == NULL
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    char err[512] = {0};
+    // constant tables (reference outputs, csrc/srgb_tables.h), resident for the ctx lifetime
+    float* d_decode_lut = nullptr;   // 256
+    float* d_enc_thr_f32 = nullptr;  // 255 (+1 pad)
+    double* d_enc_thr_f64 = nullptr; // 255 (+1 pad)
+    // lazily grown scratch
+    uint32_t* d_flags = nullptr;     // per-frame "any byte > 1" flags
+    size_t flags_cap = 0;
+    float* d_row_gain = nullptr;     // per-row gains (AVX_POST_ROWGAIN)
+    size_t row_gain_cap = 0;
+    void* d_scratch = nullptr;       // general scratch arena (UV path planes, histograms)
+    size_t scratch_cap = 0;
+    int num_cus = 256;
+};
+
+int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...);
+int avx_ensure_scratch(avx_ctx* ctx, size_t bytes);
+
+#define AVX_HIP(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return avx_fail((ctx), AVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define AVX_REQUIRE(ctx, cond, ...)                                  \
+    do {                                                             \
+        if (!(cond)) return avx_fail((ctx), AVX_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline hipStream_t avx_pick_stream(avx_ctx* ctx, void* stream) {
+    return stream ? (hipStream_t)stream : ctx->compute;
+}

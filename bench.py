@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/second of the per-frame hot path on MI355X (contract in the task prompt).
+
+A "step" is one pass of the hot path over one batch of synthetic frames that are already resident
+in HBM.  Default workload = BASELINE.json configs[1]: cat dichromat core on 1080p frames, 1 GPU.
+N > 1: one process per GPU (torch.distributed/RCCL for the barriers and the max-over-ranks only);
+the frame stream is sharded round-robin (frame i -> rank i mod N), no data-path collective ("weak").
+
+Prints ONE JSON line on rank 0.  `roofline` = algorithmic bytes per launch (6 B/px x pixels per
+launch) / the launch's duration measured with HIP events on the kernel's own stream;
+`cpu_baseline` = the oracle (NumPy + C++ restatement, 1 thread) timed on this box's host cores on a
+bounded sample of the same workload (N = 1, rank 0 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (species, H, W, frames per step)
+    "cat_1080p": ("cat", 1080, 1920, 32),
+    "dog_1080p": ("dog", 1080, 1920, 32),
+    "cat_4k": ("cat", 2160, 3840, 8),
+    "dog_4k": ("dog", 2160, 3840, 8),
+    "wolf_1080p": ("wolf", 1080, 1920, 32),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cat_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per step (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import animal_vision_amd as av
+    from animal_vision_amd import animals
+    from animal_vision_amd.dichromat import DichromatOp
+    from animal_vision_amd.synthetic import noise_frame
+
+    species, H, W, B = WORKLOADS[args.workload]
+    if args.batch > 0:
+        B = args.batch
+    ctx = av.get_context(local_rank)
+    op = DichromatOp(getattr(animals, species.capitalize()).SPEC, ctx)
+
+    # This rank's shard of the synthetic stream: global frame index i = rank + j*world (round-robin).
+    pool = [noise_frame(rank + j * world, H, W) for j in range(min(B, 4))]
+    batch = np.stack([pool[j % len(pool)] for j in range(B)])
+    d_in = ctx.upload(batch)
+    d_out = ctx.malloc(batch.nbytes)
+    stream = ctx.stream_create()
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        op.run_device(d_in, d_out, B, H, W, stream)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start(stream)
+    for _ in range(args.steps):
+        op.run_device(d_in, d_out, B, H, W, stream)
+    ev_ms = ctx.timer_stop(stream)  # HIP events on the launch stream; also fences it
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    mp_per_step = B * H * W / 1e6
+    value = world * mp_per_step * args.steps / elapsed
+    launch_s = ev_ms / 1e3 / args.steps
+    alg_bytes = 6.0 * B * H * W  # 3 B/px read + 3 B/px written
+    achieved = alg_bytes / launch_s / 1e9
+
+    result = {
+        "metric": "megapixels/sec per-frame pipeline",
+        "value": round(value, 1),
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if species == "cat" else "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{species} dichromat core, {W}x{H} uint8 frames, {B} frames/step per GPU, device-resident",
+                   "frames_per_step_per_gpu": B, "fps": round(value * 1e6 / (H * W), 1), "sharding": f"round-robin x{world}"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "dichromat fused launch (main + all<=1 fix-up)", "us_per_launch": round(launch_s * 1e6, 2)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_ref
+
+        spec = cpu_ref.DICHROMATS[species]
+        cpu_ref.dichromat_visualize(spec, pool[0][:64, :64].copy())  # warm the library
+        n, t_cpu0 = 0, time.perf_counter()
+        while True:
+            cpu_ref.dichromat_visualize(spec, pool[n % len(pool)])
+            n += 1
+            if time.perf_counter() - t_cpu0 > args.cpu_seconds or n >= 64:
+                break
+        t_cpu = time.perf_counter() - t_cpu0
+        result["cpu_baseline"] = {
+            "value": round(n * H * W / 1e6 / t_cpu, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames {W}x{H} through oracle/cpu_ref.dichromat_visualize (NumPy + C++ blur), "
+                      f"1 thread of {len(os.sched_getaffinity(0))} available",
+        }
+        got = ctx.download(d_out, batch.shape, np.uint8)
+        _, want = cpu_ref.dichromat_visualize(spec, pool[0])
+        result["parity_checked"] = bool(np.array_equal(got[0], want))
+
+    ctx.stream_destroy(stream)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+/* include/avx.h -- C ABI of libavx.so: the MI355X (gfx950) per-frame animal-vision hot path.
+ *
+ * This is the drop-in boundary.  The reference (Kyaw-Thiha/animal-vision) is pure
+ * Python and has no FFI of its own; the entry points below are what a ctypes binding added to the
+ * reference's shared helpers would call instead of their NumPy/OpenCV bodies.  Each entry point
+ * cites the reference interface it replaces (paths relative to the reference repo).  The
+ * reference-side stubs are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 (AVX_OK) or a negative avx_status; nothing throws across the ABI;
+ *     avx_last_error(ctx) returns a human-readable message for the last failure on that ctx;
+ *   - an avx_ctx is bound to ONE device and is single-threaded (one caller at a time), matching the
+ *     reference's one-frame-in-flight loop (main.py:60-72);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the ctx's own compute stream; a
+ *     torch.cuda.Stream.cuda_stream value is accepted as is); every launch is asynchronous on it;
+ *   - frame/plane pointers are DEVICE pointers unless the parameter name ends in `_host`;
+ *     the caller owns them; ctx owns only its scratch and its constant tables;
+ *   - images are C-contiguous HWC (H x W x 3), batches are N such frames back to back.
+ */
+#ifndef AVX_H
+#define AVX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVX_ABI_VERSION 1
+
+typedef struct avx_ctx avx_ctx;
+
+typedef enum avx_status {
+    AVX_OK = 0,
+    AVX_ERR_INVALID = -1,     /* bad argument (shape, mode, NULL pointer) */
+    AVX_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+    AVX_ERR_HIP = -3,         /* a HIP runtime call failed; see avx_last_error */
+    AVX_ERR_UNSUPPORTED = -4, /* valid request this build does not implement */
+    AVX_ERR_NOMEM = -5
+} avx_status;
+
+/* ---- context, memory, streams ---------------------------------------------------------------- */
+int avx_abi_version(void);
+int avx_device_count(void);                       /* 0 when no GPU is visible; never fails        */
+int avx_init(int device, avx_ctx** out_ctx);      /* AVX_ERR_NO_DEVICE when there is no such GPU  */
+void avx_destroy(avx_ctx* ctx);
+const char* avx_last_error(const avx_ctx* ctx);   /* ctx may be NULL: message of the last failed avx_init */
+
+int avx_malloc(avx_ctx* ctx, size_t bytes, void** out_dptr);
+int avx_free(avx_ctx* ctx, void* dptr);
+int avx_host_alloc(avx_ctx* ctx, size_t bytes, void** out_hptr); /* pinned host memory */
+int avx_host_free(avx_ctx* ctx, void* hptr);
+int avx_memcpy_h2d(avx_ctx* ctx, void* dst, const void* src_host, size_t bytes, void* stream);
+int avx_memcpy_d2h(avx_ctx* ctx, void* dst_host, const void* src, size_t bytes, void* stream);
+int avx_memset(avx_ctx* ctx, void* dst, int value, size_t bytes, void* stream);
+int avx_stream_create(avx_ctx* ctx, void** out_stream);
+int avx_stream_destroy(avx_ctx* ctx, void* stream);
+int avx_sync(avx_ctx* ctx, void* stream);         /* stream == NULL: whole device */
+
+/* HIP-event stopwatch ON `stream` (bench.py roofline leg: per-launch duration of the hot kernel). */
+int avx_timer_start(avx_ctx* ctx, void* stream);
+int avx_timer_stop(avx_ctx* ctx, void* stream, float* out_ms); /* records, synchronises, returns ms */
+
+/* ---- dichromat path: animals/animal_utils.py + animals/<species>.py template -------------------
+ *
+ * One fused launch replaces, for N uint8 frames,
+ *   get_normalized_image   animals/animal_utils.py:41-50   (uint8 -> f32, data-dependent /255)
+ *   srgb_to_linear         animals/animal_utils.py:5-11    (256-entry table of the reference's values)
+ *   pixels @ T.T           animals/dog.py:43-48            (FMA chain, f32)          [AVX_COLOR_MATRIX]
+ *     or sRGB_to_LMS / L-M merge / LMS_to_RGB   animals/cat.py:95-101  (f64 tail)   [AVX_COLOR_CAT_MERGE]
+ *   apply_acuity_blur      animals/animal_utils.py:121-145 (cv2.GaussianBlur semantics)   [AVX_POST_GAUSS]
+ *     or apply_s_cone_vertical_gain  animal_utils.py:206-259 (per-row blue gain)          [AVX_POST_ROWGAIN]
+ *   apply_chroma_compression  animal_utils.py:174-181 (optional)
+ *   clip -> linear_to_srgb -> clip -> (x*255+0.5).astype(uint8)   animals/dog.py:54-57
+ * Results are bit-identical to the reference executed in the build container (tests/golden). */
+enum { AVX_COLOR_MATRIX = 0, AVX_COLOR_CAT_MERGE = 1 };
+enum { AVX_POST_NONE = 0, AVX_POST_GAUSS = 1, AVX_POST_ROWGAIN = 2 };
+
+typedef struct avx_dichromat_desc {
+    uint32_t struct_size;      /* sizeof(avx_dichromat_desc), for ABI growth                         */
+    int32_t color_mode;        /* AVX_COLOR_*                                                        */
+    float matrix[9];           /* AVX_COLOR_MATRIX: T row-major, out_i = sum_j T[i][j]*in_j (Q1)      */
+    float cat_alpha;           /* AVX_COLOR_CAT_MERGE: LM = alpha*L + beta*M  (cat.py:98-99), both as   */
+    float cat_beta;            /*   float32: alpha = f32(a), beta = f32(1.0 - a) computed in double     */
+    int32_t post_mode;         /* AVX_POST_*                                                         */
+    int32_t ksize;             /* AVX_POST_GAUSS: odd tap count (same in x and y), 1..AVX_MAX_KSIZE   */
+    const double* taps_host;   /* AVX_POST_GAUSS: ksize normalised taps in double (getGaussianKernel);
+                                  the library rounds them to the compute type (f32, or f64 for cat)  */
+    const float* row_gain_host;/* AVX_POST_ROWGAIN: H per-row gains for channel 2 (host pointer)      */
+    int32_t row_gain_clamp;    /* AVX_POST_ROWGAIN: clip channel 2 to [0,1] after the gain            */
+    int32_t chroma_enable;     /* apply_chroma_compression after the post stage                      */
+    float chroma_keep;         /*   float32(1 - strength), the factor animal_utils.py:181 multiplies by */
+} avx_dichromat_desc;
+
+#define AVX_MAX_KSIZE 33
+
+int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W,
+                     const avx_dichromat_desc* desc, void* stream);
+
+/* The constant tables compiled into the library (reference outputs, see csrc/srgb_tables.h):
+ * which = 0: 256 x f32 decode LUT; 1: 255 x f32 encode thresholds; 2: 255 x f64 encode thresholds.
+ * Copies min(capacity, size) bytes to dst_host and returns the table's size in bytes. */
+int avx_get_table(int which, void* dst_host, size_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVX_H */

@@ -1,0 +1,102 @@
+"""GPU parity: fused HIP dichromat path (through the C ABI) vs golden vectors and the oracle.
+uint8 in, uint8 out: BIT-EXACT everywhere."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+GAUSS = ["dog", "cat", "squirrel", "elephant", "lion", "tiger", "bear", "wolf", "fox", "raccoon", "rat"]
+
+
+@pytest.fixture(scope="module")
+def av():
+    import animal_vision_amd as av
+
+    assert av.device_count() > 0, "no GPU visible"
+    return av
+
+
+def _species(av, name):
+    from animal_vision_amd import animals
+
+    return getattr(animals, name.capitalize())()
+
+
+@pytest.mark.parametrize("name", GAUSS)
+def test_species_vs_golden(av, name):
+    """Outputs of the reference's own <Species>.visualize (blur = shared OpenCV restatement)."""
+    g = load_golden("dichromat")
+    sp = _species(av, name)
+    n = 0
+    for k in ("n48", "s48", "n120", "dark"):
+        key = f"{name}_oracle_{k}"
+        if key not in g.files:
+            continue
+        frame = g[f"in_{k}"]
+        base, out = sp.visualize(frame)
+        assert base is frame and out.dtype == np.uint8 and out.shape == frame.shape
+        assert np.array_equal(out, g[key]), f"{key}: {int((out != g[key]).sum())} bytes differ"
+        n += 1
+    assert n >= 3
+
+
+@pytest.mark.parametrize("name", GAUSS)
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 4), (37, 91), (64, 64), (65, 129), (240, 320)])
+def test_species_vs_oracle_shapes(av, oracle, name, shape):
+    """Ragged tiles, frames smaller than the blur radius (multiple reflections), tile multiples."""
+    H, W = shape
+    frame = np.random.default_rng(1234 + H * 1000 + W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    _, want = oracle.dichromat_visualize(oracle.DICHROMATS[name], frame)
+    _, got = _species(av, name).visualize(frame)
+    assert np.array_equal(got, want), f"{name} {shape}: {int((got != want).sum())} bytes differ"
+
+
+def test_dark_frame_and_mixed_batch(av, oracle):
+    """a3 quirk: a frame whose bytes are all <= 1 is NOT divided by 255; decided per frame in a batch."""
+    rng = np.random.default_rng(5)
+    dark = rng.integers(0, 2, (33, 47, 3), dtype=np.uint8)
+    zeros = np.zeros((33, 47, 3), np.uint8)
+    normal = rng.integers(0, 256, (33, 47, 3), dtype=np.uint8)
+    almost = dark.copy()
+    almost[20, 30, 1] = 2  # one byte > 1 flips the whole frame to the /255 branch
+    batch = np.stack([normal, dark, zeros, almost, dark])
+    from animal_vision_amd.dichromat import DichromatOp
+    from animal_vision_amd.animals import Dog, Cat
+
+    for cls, nm in ((Dog, "dog"), (Cat, "cat")):
+        got = DichromatOp(cls.SPEC)(batch)
+        for i in range(batch.shape[0]):
+            _, want = oracle.dichromat_visualize(oracle.DICHROMATS[nm], batch[i])
+            assert np.array_equal(got[i], want), (nm, i)
+
+
+def test_full_1080p_dog_and_cat_bit_exact(av, oracle):
+    """BASELINE config sizes: one 1080p noise frame, bit-exact against the oracle."""
+    from animal_vision_amd.synthetic import noise_frame
+
+    frame = noise_frame(0, 1080, 1920)
+    for nm in ("dog", "cat"):
+        _, want = oracle.dichromat_visualize(oracle.DICHROMATS[nm], frame)
+        _, got = _species(av, nm).visualize(frame)
+        assert np.array_equal(got, want), f"{nm}: {int((got != want).sum())} bytes differ"
+
+
+def test_constant_frame_is_preserved_in_shape_and_flat(av):
+    """Size-independent property at 4K: a flat frame stays flat (blur of a constant; reflect-101 border)."""
+    frame = np.full((2160, 3840, 3), (200, 120, 40), np.uint8)
+    _, out = _species(av, "dog").visualize(frame)
+    assert out.shape == frame.shape
+    assert (out == out[0, 0]).all()
+
+
+def test_bad_arguments_raise(av):
+    from animal_vision_amd.animals import Dog
+
+    with pytest.raises(AssertionError):
+        Dog().visualize(np.zeros((4, 4), np.uint8))
+    with pytest.raises(AssertionError):
+        Dog().visualize(np.zeros((4, 4, 4), np.uint8))
+    with pytest.raises(NotImplementedError):
+        Dog().visualize(np.zeros((4, 4, 3), np.float32))

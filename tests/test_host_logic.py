@@ -1,0 +1,91 @@
+"""CPU-only: host logic of the product vs golden vectors / oracle, and the C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+import animal_vision_amd as av
+from animal_vision_amd import dichromat as D
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/avx.h declares is exported by libavx.so (no compute calls here)."""
+    hdr = open(os.path.join(ROOT, "include", "avx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(avx_[a-z0-9_]+)\s*\(", hdr))
+    assert {"avx_init", "avx_dichromat_u8", "avx_last_error"} <= names
+    lib = ctypes.CDLL(av._lib.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/avx.h but not exported: {missing}"
+    assert lib.avx_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly():
+    if av.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(av.AvxError) as e:
+        av.Context(0)
+    assert e.value.code == av._lib.AVX_ERR_NO_DEVICE
+    from animal_vision_amd.animals import Dog
+
+    with pytest.raises(av.AvxError):
+        Dog().visualize(np.zeros((4, 4, 3), np.uint8))
+
+
+def test_compiled_tables_are_the_reference_values():
+    g = load_golden("srgb_tables")
+    assert np.array_equal(av.get_table(0), g["decode_lut"])
+    assert np.array_equal(av.get_table(1), g["enc_thr_f32"])
+    assert np.array_equal(av.get_table(2), g["enc_thr_f64"])
+
+
+def test_collapse_matrix_matches_reference():
+    g = load_golden("collapse_matrices")
+    for (a, s), T in zip(g["pairs"].tolist(), g["T"]):
+        assert np.array_equal(D.collapse_LMS_matrix(a, s), T)
+
+
+def test_tap_generation_matches_oracle(oracle):
+    for sigma in (0.2, 0.7, 1.0, 1.2, 1.3, 1.4, 1.6, 1.8, 2.0, 3.5):
+        k = D.cv_auto_ksize(sigma)
+        assert k == oracle.cv_auto_ksize(sigma)
+        assert np.array_equal(D.gaussian_taps(k, sigma), oracle.gaussian_kernel(k, sigma, np.float64))
+    # sigma -> ksize table
+    assert [D.cv_auto_ksize(s) for s in (3.5, 1.0, 1.2, 1.4, 2.0, 0.7)] == [29, 9, 11, 13, 17, 7]
+
+
+def test_row_gain_matches_oracle(oracle):
+    for H in (1, 2, 24, 1080):
+        assert np.array_equal(D.s_cone_row_gain(H, 1.3, 0.5, power=1.4, extra_boost=0.25),
+                              oracle.s_cone_row_gain(H, 1.3, 0.5, power=1.4, extra_boost=0.25))
+
+
+def test_species_table_matches_oracle_table(oracle):
+    """Product species parameters == the oracle's independent restatement of Appendix A."""
+    from animal_vision_amd import animals as A
+
+    for name, ospec in oracle.DICHROMATS.items():
+        cls = getattr(A, name.capitalize())
+        s = cls.SPEC
+        assert (s.alpha, s.s_scale, s.post) == (ospec.alpha, ospec.s_scale, ospec.post), name
+        if s.post == "gauss":
+            assert s.sigma == ospec.sigma
+        if s.post == "streak":
+            assert s.streak == ospec.streak
+        used_chroma = None if ospec.chroma_discarded else ospec.chroma
+        assert s.chroma == used_chroma, name
+
+
+def test_reference_module_names_importable():
+    import importlib
+
+    for n in ("dog", "cat", "sheep", "pig", "cow", "goat", "rat", "horse", "rabbit", "panda", "squirrel",
+              "elephant", "lion", "wolf", "fox", "bear", "raccoon", "deer", "kangaroo", "tiger"):
+        m = importlib.import_module(f"animal_vision_amd.animals.{n}")
+        cls = getattr(m, n.capitalize())
+        inst = cls()  # registry instantiates with no arguments (utils.py:91-130)
+        assert hasattr(inst, "visualize")
