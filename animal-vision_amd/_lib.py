@@ -38,6 +38,7 @@ class DichromatDesc(ctypes.Structure):
         ("row_gain_clamp", ctypes.c_int32),
         ("chroma_enable", ctypes.c_int32),
         ("chroma_keep", ctypes.c_float),
+        ("variant", ctypes.c_int32),
     ]
 
 

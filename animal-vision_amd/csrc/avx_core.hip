@@ -71,6 +71,40 @@ int avx_init(int device, avx_ctx** out_ctx) {
     INIT_HIP(hipMemset(ctx->d_enc_thr_f64, 0x7f, 256 * 8));
     INIT_HIP(hipMemcpy(ctx->d_enc_thr_f32, kEncThrF32Bits, 255 * 4, hipMemcpyHostToDevice));
     INIT_HIP(hipMemcpy(ctx->d_enc_thr_f64, kEncThrF64Bits, 255 * 8, hipMemcpyHostToDevice));
+    // Bucket tables for the quantiser: pure bit logic on the threshold tables above.
+    for (int which = 0; which < 2; ++which) {
+        uint64_t tb[255];
+        const int shift = which == 0 ? 17 : 46;
+        for (int i = 0; i < 255; ++i) tb[i] = which == 0 ? (uint64_t)kEncThrF32Bits[i] : kEncThrF64Bits[i];
+        const uint64_t one_bits = which == 0 ? 0x3f800000ull : 0x3ff0000000000000ull;
+        const uint32_t lo = (uint32_t)(tb[0] >> shift), hi = (uint32_t)(one_bits >> shift);
+        const uint32_t n = hi - lo + 1;
+        if (n > 1024) {
+            avx_fail(nullptr, AVX_ERR_INVALID, "avx_init: quantiser bucket table too large (%u)", n);
+            delete ctx;
+            return AVX_ERR_INVALID;
+        }
+        uint8_t table[1024];
+        int n_fix = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            // non-negative IEEE floats order like their bit patterns
+            const uint64_t start = (uint64_t)(lo + k) << shift, next = (uint64_t)(lo + k + 1) << shift;
+            int le = 0, inside = 0;
+            for (int i = 0; i < 255; ++i) {
+                if (tb[i] <= start) ++le;
+                else if (tb[i] < next) ++inside;
+            }
+            table[k] = (uint8_t)le;
+            if (inside > n_fix) n_fix = inside;
+        }
+        uint8_t** dst = which == 0 ? &ctx->d_coarse_f32 : &ctx->d_coarse_f64;
+        INIT_HIP(hipMalloc((void**)dst, 1024));
+        INIT_HIP(hipMemset(*dst, 0, 1024));
+        INIT_HIP(hipMemcpy(*dst, table, n, hipMemcpyHostToDevice));
+        ctx->coarse_lo_key[which] = lo;
+        ctx->coarse_n_keys[which] = n;
+        ctx->coarse_n_fix[which] = n_fix;
+    }
 #undef INIT_HIP
     *out_ctx = ctx;
     return AVX_OK;
@@ -83,6 +117,8 @@ void avx_destroy(avx_ctx* ctx) {
     if (ctx->d_decode_lut) (void)hipFree(ctx->d_decode_lut);
     if (ctx->d_enc_thr_f32) (void)hipFree(ctx->d_enc_thr_f32);
     if (ctx->d_enc_thr_f64) (void)hipFree(ctx->d_enc_thr_f64);
+    if (ctx->d_coarse_f32) (void)hipFree(ctx->d_coarse_f32);
+    if (ctx->d_coarse_f64) (void)hipFree(ctx->d_coarse_f64);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_row_gain) (void)hipFree(ctx->d_row_gain);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);

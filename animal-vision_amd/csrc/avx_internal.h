@@ -18,6 +18,12 @@ struct avx_ctx {
     float* d_decode_lut = nullptr;   // 256
     float* d_enc_thr_f32 = nullptr;  // 255 (+1 pad)
     double* d_enc_thr_f64 = nullptr; // 255 (+1 pad)
+    // bucketed quantiser (csrc/dichromat.hip quantize_coarse): per top-bits bucket, #thresholds <= bucket start
+    uint8_t* d_coarse_f32 = nullptr;
+    uint8_t* d_coarse_f64 = nullptr;
+    uint32_t coarse_lo_key[2] = {0, 0};  // [0] f32 (bits >> 17), [1] f64 (bits >> 46)
+    uint32_t coarse_n_keys[2] = {0, 0};
+    int coarse_n_fix[2] = {0, 0};
     // lazily grown scratch
     uint32_t* d_flags = nullptr;     // per-frame "any byte > 1" flags
     size_t flags_cap = 0;

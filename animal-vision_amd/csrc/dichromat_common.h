@@ -1,0 +1,91 @@
+// csrc/dichromat_common.h -- device helpers and argument blocks shared by the dichromat kernels
+// (dichromat.hip: reference + 2-D tiled variants; dichromat_march.hip: marching strip variant).
+#pragma once
+#include "avx_internal.h"
+
+namespace avxk {
+
+constexpr int kThreads = 256;  // reference kernel workgroup
+
+template <typename T>
+struct Taps {
+    T k[AVX_MAX_KSIZE];
+};
+
+struct DichromatArgs {
+    const uint8_t* in;
+    uint8_t* out;
+    int n_frames, H, W;
+    int tiles_x, tiles_y;
+    int TW, TH;          // output tile
+    int r;               // blur radius (0 when no Gaussian)
+    float M[9];          // AVX_COLOR_MATRIX, or RGB->LMS for cat
+    double Bk[9];        // cat: LMS->RGB (float64)
+    float alpha, one_minus_alpha;
+    int post_mode;
+    const float* row_gain;  // device, H entries
+    int row_gain_clamp;
+    int chroma_enable;
+    float chroma_keep;   // float32(1 - strength)
+    const float* decode_lut;
+    const void* enc_thr;  // T[256]
+    uint32_t* flags;      // per frame: set when any byte > 1 was seen
+    unsigned long long* stamps;  // diagnostic builds only (8 accumulators), else NULL
+    int ablate;                  // AVX_ABLATE (tuning only): bit mask of phases to skip; 0 in production
+};
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// count of thresholds <= v (thr ascending, 255 real entries + 1 huge pad)
+template <typename T>
+__device__ __forceinline__ uint32_t quantize(T v, const T* __restrict__ thr) {
+    v = v < (T)0 ? (T)0 : (v > (T)1 ? (T)1 : v);
+    uint32_t lo = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+        // invariant: thr[lo-1] <= v (or lo == 0); test whether lo+step thresholds are all <= v
+        if (thr[lo + step - 1] <= v) lo += step;
+    }
+    return lo;  // 0..255
+}
+
+struct QuantCoarse {
+    const uint8_t* table;  // device: count of thresholds <= bucket start, per bucket
+    uint32_t lo_key;       // first bucket key (keys below it quantise to 0)
+    uint32_t n_keys;
+    int n_fix;             // max thresholds strictly inside one bucket (refinement steps)
+};
+
+__device__ __forceinline__ uint32_t key_of(float v) { return __float_as_uint(v) >> 17; }
+__device__ __forceinline__ uint32_t key_of(double v) { return (uint32_t)(__double_as_longlong(v) >> 46); }
+
+// out = #{k : thr[k] <= clip(v,0,1)} via a bucket table on the float's top bits + <= NFIX refinements.
+template <typename T, int NFIX>
+__device__ __forceinline__ uint32_t quantize_coarse(T v, const T* __restrict__ thr, const uint8_t* __restrict__ coarse, uint32_t lo_key) {
+    v = v < (T)0 ? (T)0 : (v > (T)1 ? (T)1 : v);
+    const uint32_t key = key_of(v);
+    uint32_t k = key < lo_key ? 0u : (uint32_t)coarse[key - lo_key];
+#pragma unroll
+    for (int i = 0; i < NFIX; ++i) k += (thr[k] <= v) ? 1u : 0u;  // thr[255] is a huge pad: never passes
+    return k;
+}
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { using type = float4; };
+template <> struct Vec16<double> { using type = double2; };
+template <typename T> struct Vec8;
+template <> struct Vec8<float> { using type = float2; };
+template <> struct Vec8<double> { using type = double; };
+
+
+}  // namespace avxk
+
+// variant 2 (dichromat_march.hip): returns AVX_ERR_UNSUPPORTED when no instantiation covers (type, radius).
+int avx_launch_dichromat_march(avx_ctx* ctx, avxk::DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, hipStream_t s);

@@ -1,0 +1,421 @@
+// csrc/dichromat_march.hip -- variant 2 of the fused dichromat path: the MARCHING STRIP kernel.
+//
+// Same arithmetic contract as dichromat.hip (bit-exact with oracle/avxref.cpp); different schedule,
+// designed around what the 2-D tile variant measured as its limits on MI355X (in-kernel stamps + PMC,
+// DESIGN.md): 10 barriers per 4096 px, 3 halo-sized planes in LDS (=> 2 waves/SIMD) and every phase
+// latency-bound.
+//
+//   * A 384-thread workgroup (128 column groups x 3 channels) owns a strip up to 512 px wide
+//     (256 for the float64 cat tail) and MARCHES down a chunk of rows, SY rows per iteration.
+//   * LDS holds only SY raw rows, SY decoded rows (3 channel planes) and SY output rows (~40 KiB):
+//     3 workgroups per CU.  No vertical halo is ever recomputed.
+//   * Each thread owns XPT adjacent columns of ONE channel.  Row pass: one 16-byte-vector window
+//     read per new row (lanes read consecutive vectors: conflict-free).  Column pass: the 2R+SY
+//     row window of its columns lives in REGISTERS and is shifted by SY per iteration - the column
+//     pass reads no LDS at all.
+//   * 3 barriers per SY x strip-width pixels; raw rows for iteration t+1 are in flight (registers)
+//     while iteration t computes.
+#include <cstdlib>
+
+#include "dichromat_common.h"
+
+using namespace avxk;
+
+namespace {
+
+constexpr int kMarchThreads = 384;
+constexpr int kGroups = 128;  // column groups per strip
+
+struct MarchGeom {
+    int nstrips, sw;   // strips per frame row, nominal strip width (multiple of XPT)
+    int nchunks, ch;   // row chunks per frame, rows per chunk (multiple of SY)
+    int xcd_remap;     // 1: blocks b and b+8 are neighbours (same XCD under round-robin dispatch)
+};
+
+template <typename T, int N> struct VecN;
+template <> struct VecN<float, 4> { using type = float4; };
+template <> struct VecN<float, 2> { using type = float2; };
+template <> struct VecN<double, 2> { using type = double2; };
+template <> struct VecN<double, 1> { using type = double; };
+
+template <typename T, int R, int SY, int XPT_>
+struct MarchCfg {
+    static constexpr int XPT = XPT_;                          // columns per thread = one LDS vector read
+    static constexpr int SW = XPT * kGroups;
+    static constexpr int AWS = SW + 2 * R;
+    static constexpr int NWV = 1 + (2 * R + XPT - 1) / XPT;   // vector reads per row window
+    static constexpr int NG4 = (AWS + 3) / 4;                 // decode groups (4 px) per row
+    static constexpr int PA0 = SW - XPT + NWV * XPT;
+    static constexpr int PA = ((PA0 > NG4 * 4 ? PA0 : NG4 * 4) + 3) / 4 * 4;
+    static constexpr int RAW_LEAD = 64;
+    static constexpr int RAWP = RAW_LEAD + ((AWS * 3 + 3 + 16 + 3) & ~3);
+    static constexpr int DPR = (RAWP - RAW_LEAD) / 4;
+    static constexpr int OUTP = SW * 3;
+    static constexpr int WIN = 2 * R + SY;                    // rows in a column window
+    static constexpr size_t off_thr = 0;
+    static constexpr size_t off_lut = off_thr + 256 * sizeof(T);
+    static constexpr size_t off_coarse = off_lut + 256 * sizeof(float);
+    static constexpr size_t off_ktab = off_coarse + 1024;
+    static constexpr size_t off_A = off_ktab + 64 * sizeof(T);
+    static constexpr size_t off_raw = off_A + (size_t)SY * 3 * PA * sizeof(T) + 64;
+    static constexpr size_t off_out = off_raw + (size_t)SY * RAWP;
+    static constexpr size_t lds_bytes = ((off_out + (size_t)SY * OUTP + 15) / 16) * 16;
+    static_assert(3 * R <= RAW_LEAD, "raw lead-in too small for this radius");
+    static_assert(lds_bytes <= 160 * 1024, "does not fit LDS");
+};
+
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);  // ({hi,lo} >> 8*sh) & 0xffffffff
+}
+
+template <typename T> struct Pair;
+template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Pair<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+// Packed arithmetic: P = {value for row/column a, value for row/column b}.  For float these are
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 - the only way to the 157 TFLOP/s f32 vector rate on
+// gfx950 (a plain wave64 VALU instruction holds its SIMD for 4 cycles); for double they lower to two
+// scalar instructions.  Each half is the same IEEE operation as the scalar contract.
+template <typename P> __device__ __forceinline__ P pfma(P a, P b, P c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <typename T, int COLOR, bool DARK, int R, int SY, int XPT_, int MINW, int NFIX>
+__global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(DichromatArgs a, Taps<T> taps, QuantCoarse qc, MarchGeom g) {
+    using C = MarchCfg<T, R, SY, XPT_>;
+    using P = typename Pair<T>::type;
+    constexpr int XPT = C::XPT;
+    constexpr int NWAVES = kMarchThreads / 64;
+    static_assert(SY % 2 == 0 && XPT % 2 == 0, "rows and columns are processed in pairs");
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* thr = reinterpret_cast<T*>(smem_raw + C::off_thr);
+    float* lut = reinterpret_cast<float*>(smem_raw + C::off_lut);
+    uint8_t* coarse = smem_raw + C::off_coarse;
+    T* ktab = reinterpret_cast<T*>(smem_raw + C::off_ktab);
+    P* A = reinterpret_cast<P*>(smem_raw + C::off_A);      // [SY/2][3][PA] of {row 2k, row 2k+1}
+    uint8_t* RAW = smem_raw + C::off_raw;                   // [SY][RAWP]
+    uint8_t* OUT = smem_raw + C::off_out;                   // [SY][OUTP]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bookkeeping on the SALU
+
+    // ---- which strip / chunk / frame ----------------------------------------------------------
+    int b = blockIdx.x;
+    if (g.xcd_remap) b = (b & 7) * ((int)gridDim.x >> 3) + (b >> 3);  // gridDim.x % 8 == 0 (host checked)
+    const int strip = b % g.nstrips;
+    const int chunk = (b / g.nstrips) % g.nchunks;
+    const int f = b / (g.nstrips * g.nchunks);
+    if (DARK && a.flags[f] != 0u) return;  // frame was not "all <= 1": the main pass is already right
+    const int xs = strip * g.sw, ys = chunk * g.ch;
+    const int vw = a.W - xs < g.sw ? a.W - xs : g.sw;    // valid output columns of this strip
+    const int ch = a.H - ys < g.ch ? a.H - ys : g.ch;    // valid output rows of this chunk
+    if (vw <= 0 || ch <= 0) return;
+    const size_t frame_bytes = (size_t)a.H * a.W * 3;
+    const uint8_t* fin = a.in + frame_bytes * f;
+    uint8_t* fout = a.out + frame_bytes * f;
+    const uint8_t* const in_end = a.in + frame_bytes * a.n_frames;
+    const int gx0 = xs - R > 0 ? xs - R : 0;
+    const int gx1 = xs + vw + R < a.W ? xs + vw + R : a.W;
+    const int row_bytes = (gx1 - gx0) * 3;
+    const int lead = gx0 - (xs - R);                       // halo pixels left of the image (0 off-border)
+    const bool border = (xs - R < 0) || (xs + vw + R > a.W);
+    const int aws = vw + 2 * R;                            // haloed width actually used
+
+    for (int i = tid; i < 256; i += kMarchThreads) {
+        thr[i] = reinterpret_cast<const T*>(a.enc_thr)[i];
+        lut[i] = a.decode_lut[i];
+    }
+    for (int i = tid; i < 1024; i += kMarchThreads) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
+    if (tid <= R) ktab[tid] = taps.k[R + tid];  // symmetric taps, by distance from the centre
+    __syncthreads();
+    P kk[R + 1];  // taps, splat into both halves, in VGPRs (via LDS: as SGPRs they spill through v_readlane)
+#pragma unroll
+    for (int d = 0; d <= R; ++d) { const T k = ktab[d]; kk[d] = P{k, k}; }
+
+    const int c = tid / kGroups;        // channel of this thread (uniform per wave: 128 = 2 waves)
+    const int xg = tid - c * kGroups;   // column group: columns xg*XPT .. xg*XPT+XPT-1 of the strip
+    const bool col_active = xg * XPT < vw;
+
+    // ---- raw row loads: (row, 64-dword segment) units dealt to waves; row math is scalar ---------
+    constexpr int NSEG = (C::DPR + 63) / 64;
+    constexpr int NLD = (SY * NSEG + NWAVES - 1) / NWAVES;
+    auto row_base = [&](int t, int s, uint32_t& shift) -> const uint8_t* {
+        const int gy = reflect101(ys - R + t * SY + s, a.H);
+        const uint8_t* rowp = fin + ((size_t)gy * a.W + gx0) * 3;
+        shift = (uint32_t)((uintptr_t)rowp & 3u);
+        return rowp - shift;
+    };
+    auto issue_raw_loads = [&](int t, uint32_t (&rv)[NLD]) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int u = wave + n * NWAVES;            // uniform
+            const int s = u / NSEG, seg = u - s * NSEG; // uniform
+            uint32_t v = 0;
+            if (s < SY) {
+                uint32_t shift;
+                const uint8_t* base = row_base(t, s, shift);
+                const int d = seg * 64 + lane;
+                if (d * 4 < (int)shift + row_bytes) {
+                    const uint8_t* p = base + (size_t)d * 4;
+                    if (p + 4 <= in_end) {
+                        v = *reinterpret_cast<const uint32_t*>(p);
+                    } else {  // last dword of the whole batch: do not read past the allocation
+                        for (int bb = 0; bb < 4; ++bb)
+                            if (p + bb < in_end) v |= (uint32_t)p[bb] << (8 * bb);
+                    }
+                }
+            }
+            rv[n] = v;
+        }
+    };
+    auto write_raw = [&](int t, const uint32_t (&rv)[NLD]) {
+        uint32_t seen = 0;
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int u = wave + n * NWAVES;
+            const int s = u / NSEG, seg = u - s * NSEG;
+            if (s < SY) {
+                const int d = seg * 64 + lane;
+                if (d < C::DPR) {
+                    *reinterpret_cast<uint32_t*>(RAW + (size_t)s * C::RAWP + C::RAW_LEAD + d * 4) = rv[n];
+                    if (!DARK) {
+                        uint32_t shift;
+                        (void)row_base(t, s, shift);
+                        const int b0 = d * 4 - (int)shift;  // row byte index of this dword's byte 0
+                        uint32_t m = 0xfefefefeu;           // "byte > 1" detector, masked to the row's own bytes
+                        if (b0 < 0) m &= 0xffffffffu << (8 * (-b0));
+                        if (b0 + 4 > row_bytes) m &= b0 >= row_bytes ? 0u : 0xffffffffu >> (8 * (b0 + 4 - row_bytes));
+                        seen |= rv[n] & m;
+                    }
+                }
+            }
+        }
+        if (!DARK && seen) a.flags[f] = 1u;  // benign race: every writer stores the same value
+    };
+    // ---- output rows of iteration t: OUT (LDS) -> HBM -------------------------------------------
+    // Store granularity is the same for every row of the strip: 16 bytes when row pitch, strip origin
+    // and width allow it (all standard video sizes), else 4 bytes, else single bytes.
+    const int nbytes = vw * 3;
+    const uintptr_t o0 = (uintptr_t)(fout + (size_t)xs * 3);
+    const uintptr_t pitch = (uintptr_t)a.W * 3;
+    const int gran = (((o0 | pitch | (uintptr_t)nbytes) & 15u) == 0) ? 16 : ((((o0 | pitch | (uintptr_t)nbytes) & 3u) == 0) ? 4 : 1);
+    auto store_out = [&](int t) {
+        const int per_row = nbytes / gran;
+#pragma unroll 1
+        for (int v = tid; v < SY * per_row; v += kMarchThreads) {
+            const int i = v / per_row, e = v - i * per_row;
+            const int rel = t * SY + i - 2 * R;
+            if (rel < 0 || rel >= ch) continue;
+            uint8_t* grow = fout + ((size_t)(ys + rel) * a.W + xs) * 3;
+            const uint8_t* orow = OUT + (size_t)i * C::OUTP;
+            if (gran == 16) reinterpret_cast<uint4*>(grow)[e] = reinterpret_cast<const uint4*>(orow)[e];
+            else if (gran == 4) reinterpret_cast<uint32_t*>(grow)[e] = reinterpret_cast<const uint32_t*>(orow)[e];
+            else grow[e] = orow[e];
+        }
+    };
+
+    // Column windows in registers: cw[xp][j] = {row j @ column 2xp, row j @ column 2xp+1}, newest row last.
+    P cw[XPT / 2][C::WIN];
+#pragma unroll
+    for (int xp = 0; xp < XPT / 2; ++xp)
+#pragma unroll
+        for (int j = 0; j < C::WIN; ++j) cw[xp][j] = P{(T)0, (T)0};
+
+    const int n_iter = (ch + 2 * R + SY - 1) / SY;
+    uint32_t rv[NLD];
+    issue_raw_loads(0, rv);
+#pragma unroll 1
+    for (int t = 0; t < n_iter; ++t) {
+        // ---- S1: previous outputs -> HBM, raw rows -> LDS, next raw rows -> registers ------------
+        if (t > 0 && !(a.ablate & 32)) store_out(t - 1);
+        if (!(a.ablate & 16)) write_raw(t, rv);
+        if (t + 1 < n_iter && !(a.ablate & 16)) issue_raw_loads(t + 1, rv);
+        __syncthreads();
+        // ---- S2: decode.  One item = 4 pixels x 2 rows: raw bytes -> decode table -> colour chain on
+        //      {row a, row b} pairs -> A in the row-paired layout the row pass reads. -----------------
+#pragma unroll 1
+        for (int item = (a.ablate & 1) ? (1 << 30) : tid; item < (SY / 2) * C::NG4; item += kMarchThreads) {
+            const int sp = item / C::NG4, q4 = item - sp * C::NG4;
+            if (q4 * 4 >= aws) continue;
+            uint32_t code[2][4][3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = 2 * sp + h;
+                uint32_t shift;
+                (void)row_base(t, s, shift);
+                const int boff = C::RAW_LEAD + (int)shift - 3 * lead + 12 * q4;  // LDS byte offset of pixel lx = 4*q4
+                const uint32_t* dw = reinterpret_cast<const uint32_t*>(RAW + (size_t)s * C::RAWP + (boff & ~3));
+                const uint32_t sh = (uint32_t)boff & 3u;
+                const uint32_t d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3];
+                const uint32_t u0 = alignbyte(d1, d0, sh), u1 = alignbyte(d2, d1, sh), u2 = alignbyte(d3, d2, sh);
+                code[h][0][0] = u0 & 255u; code[h][0][1] = (u0 >> 8) & 255u; code[h][0][2] = (u0 >> 16) & 255u;
+                code[h][1][0] = u0 >> 24;  code[h][1][1] = u1 & 255u;        code[h][1][2] = (u1 >> 8) & 255u;
+                code[h][2][0] = (u1 >> 16) & 255u; code[h][2][1] = u1 >> 24; code[h][2][2] = u2 & 255u;
+                code[h][3][0] = (u2 >> 8) & 255u; code[h][3][1] = (u2 >> 16) & 255u; code[h][3][2] = u2 >> 24;
+            }
+            P o[3][4];
+            using F2 = typename Pair<float>::type;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                F2 c0, c1, c2;
+                if (DARK) {  // get_normalized_image skips /255 when max <= 1: codes 0/1 are 0.0/1.0
+                    c0 = F2{code[0][p][0] ? 1.0f : 0.0f, code[1][p][0] ? 1.0f : 0.0f};
+                    c1 = F2{code[0][p][1] ? 1.0f : 0.0f, code[1][p][1] ? 1.0f : 0.0f};
+                    c2 = F2{code[0][p][2] ? 1.0f : 0.0f, code[1][p][2] ? 1.0f : 0.0f};
+                } else {
+                    c0 = F2{lut[code[0][p][0]], lut[code[1][p][0]]};
+                    c1 = F2{lut[code[0][p][1]], lut[code[1][p][1]]};
+                    c2 = F2{lut[code[0][p][2]], lut[code[1][p][2]]};
+                }
+                // out_i = fma(c2, M[i][2], fma(c1, M[i][1], c0*M[i][0]))   (dog.py:47 as an FMA chain)
+                const F2 l = pfma(c2, F2{a.M[2], a.M[2]}, pfma(c1, F2{a.M[1], a.M[1]}, c0 * F2{a.M[0], a.M[0]}));
+                const F2 m = pfma(c2, F2{a.M[5], a.M[5]}, pfma(c1, F2{a.M[4], a.M[4]}, c0 * F2{a.M[3], a.M[3]}));
+                const F2 sv = pfma(c2, F2{a.M[8], a.M[8]}, pfma(c1, F2{a.M[7], a.M[7]}, c0 * F2{a.M[6], a.M[6]}));
+                if constexpr (COLOR == AVX_COLOR_MATRIX) {
+                    o[0][p] = P{(T)l.x, (T)l.y};
+                    o[1][p] = P{(T)m.x, (T)m.y};
+                    o[2][p] = P{(T)sv.x, (T)sv.y};
+                } else {
+                    const F2 lm = F2{a.alpha, a.alpha} * l + F2{a.one_minus_alpha, a.one_minus_alpha} * m;  // mul, mul, add (cat.py:99)
+                    using D2 = typename Pair<double>::type;
+                    const D2 dlm = D2{(double)lm.x, (double)lm.y}, ds = D2{(double)sv.x, (double)sv.y};
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const D2 r = pfma(ds, D2{a.Bk[3 * cc + 2], a.Bk[3 * cc + 2]},
+                                          pfma(dlm, D2{a.Bk[3 * cc + 1], a.Bk[3 * cc + 1]}, dlm * D2{a.Bk[3 * cc], a.Bk[3 * cc]}));
+                        o[cc][p] = P{(T)r.x, (T)r.y};
+                    }
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                P* dst = A + ((size_t)(sp * 3 + cc)) * C::PA + q4 * 4;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dst[p] = o[cc][p];
+            }
+        }
+        if (border) {  // BORDER_REFLECT_101 in x: halo entries outside the image copy their mirror pixel
+            __syncthreads();
+            const int nl = lead, nr = (xs + vw + R) - gx1;  // halo pixels left / right of the image
+            for (int item = tid; item < (SY / 2) * 3 * (nl + nr); item += kMarchThreads) {
+                const int e = item % (nl + nr), pl = item / (nl + nr);
+                const int lx = e < nl ? e : (gx1 - (xs - R)) + (e - nl);
+                const int src = reflect101(xs - R + lx, a.W) - (xs - R);
+                A[(size_t)pl * C::PA + lx] = A[(size_t)pl * C::PA + src];
+            }
+        }
+        __syncthreads();
+        // ---- S3: row pass for the SY new rows (two rows per packed op), then the column pass and the
+        //      quantiser from the register windows (two columns per packed op). ----------------------
+        if (col_active) {
+#pragma unroll
+            for (int xp = 0; xp < XPT / 2; ++xp)
+#pragma unroll
+                for (int j = 0; j < 2 * R; ++j) cw[xp][j] = cw[xp][j + SY];
+#pragma unroll
+            for (int sp = 0; sp < ((a.ablate & 2) ? 0 : SY / 2); ++sp) {
+                const P* src = A + ((size_t)(sp * 3 + c)) * C::PA + xg * XPT;
+                P w[XPT + 2 * R];  // {row 2sp, row 2sp+1} at columns xg*XPT + i
+#pragma unroll
+                for (int i = 0; i < XPT + 2 * R; ++i) w[i] = src[i];
+                P acc[XPT];
+#pragma unroll
+                for (int x = 0; x < XPT; ++x) {
+                    P sacc = w[x] * kk[R];  // tap 0 is at distance R from the centre
+#pragma unroll
+                    for (int j = 1; j <= 2 * R; ++j) sacc = pfma(w[x + j], kk[j < R ? R - j : j - R], sacc);
+                    acc[x] = sacc;
+                }
+#pragma unroll
+                for (int xp = 0; xp < XPT / 2; ++xp) {  // {rows} x columns -> rows x {columns}
+                    cw[xp][2 * R + 2 * sp] = P{acc[2 * xp].x, acc[2 * xp + 1].x};
+                    cw[xp][2 * R + 2 * sp + 1] = P{acc[2 * xp].y, acc[2 * xp + 1].y};
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one row-pair window live at a time (register budget)
+            }
+#pragma unroll
+            for (int i = 0; i < ((a.ablate & 4) ? 0 : SY); ++i) {
+#pragma unroll
+                for (int xp = 0; xp < XPT / 2; ++xp) {
+                    P sacc = cw[xp][R + i] * kk[0];
+#pragma unroll
+                    for (int j = 1; j <= R; ++j) sacc = pfma(cw[xp][R + i + j] + cw[xp][R + i - j], kk[j], sacc);
+                    uint32_t q0, q1;
+                    if (a.ablate & 8) {
+                        q0 = (uint32_t)(sacc.x * (T)255); q1 = (uint32_t)(sacc.y * (T)255);
+                    } else {
+                        q0 = quantize_coarse<T, NFIX>(sacc.x, thr, coarse, qc.lo_key);
+                        q1 = quantize_coarse<T, NFIX>(sacc.y, thr, coarse, qc.lo_key);
+                    }
+                    uint8_t* dst = OUT + (size_t)i * C::OUTP + (xg * XPT + 2 * xp) * 3 + c;
+                    dst[0] = (uint8_t)q0;
+                    dst[3] = (uint8_t)q1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    store_out(n_iter - 1);
+}
+
+template <typename T, int COLOR, int R, int SY, int XPT, int MINW, int NFIX>
+int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, const QuantCoarse& qc, hipStream_t s) {
+    using C = MarchCfg<T, R, SY, XPT>;
+    Taps<T> taps;
+    for (int i = 0; i < AVX_MAX_KSIZE; ++i) taps.k[i] = (T)0;
+    for (int i = 0; i < d->ksize; ++i) taps.k[i] = (T)d->taps_host[i];
+    auto kmain = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, MINW, NFIX>;
+    auto kdark = dichromat_march_kernel<T, COLOR, true, R, SY, XPT, MINW, NFIX>;
+    const size_t lds = C::lds_bytes;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)kmain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)kdark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    AVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kmain, kMarchThreads, lds));
+    if (per_cu < 1) per_cu = 1;
+    MarchGeom g{};
+    g.nstrips = (a.W + C::SW - 1) / C::SW;
+    g.sw = ((a.W + g.nstrips - 1) / g.nstrips + C::XPT - 1) / C::XPT * C::XPT;
+    // Chunks: one resident wave of equal workgroups when the batch allows it (no tail), else one
+    // chunk per (frame, strip); never shorter than 8*SY rows (priming costs 2R rows per chunk).
+    const long resident = (long)ctx->num_cus * per_cu;
+    const long cols = (long)a.n_frames * g.nstrips;
+    long nchunks = cols >= resident ? 1 : (resident + cols - 1) / cols;
+    const char* e = getenv("AVX_MARCH_CHUNKS");
+    if (e) nchunks = atol(e);
+    const long max_chunks = a.H / (8 * SY) > 0 ? a.H / (8 * SY) : 1;
+    if (nchunks > max_chunks) nchunks = max_chunks;
+    if (nchunks < 1) nchunks = 1;
+    g.ch = (int)(((a.H + nchunks - 1) / nchunks + SY - 1) / SY * SY);
+    g.nchunks = (a.H + g.ch - 1) / g.ch;
+    const long total = cols * g.nchunks;
+    AVX_REQUIRE(ctx, total < (1L << 30), "avx_dichromat_u8: too many workgroups");
+    g.xcd_remap = (total % 8 == 0) ? 1 : 0;
+    AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
+    hipLaunchKernelGGL(kmain, dim3((unsigned)total), dim3(kMarchThreads), lds, s, a, taps, qc, g);
+    AVX_HIP(ctx, hipGetLastError());
+    // Fix-up for frames whose every byte is <= 1 (get_normalized_image does not divide those by 255);
+    // every workgroup of any other frame exits on its first instruction.
+    hipLaunchKernelGGL(kdark, dim3((unsigned)total), dim3(kMarchThreads), lds, s, a, taps, qc, g);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+}  // namespace
+
+int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, hipStream_t s) {
+    constexpr int NF = 2;
+    const int w = f64_cat ? 1 : 0;
+    AVX_REQUIRE(ctx, ctx->coarse_n_fix[w] <= NF, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[w], NF);
+    QuantCoarse qc{f64_cat ? ctx->d_coarse_f64 : ctx->d_coarse_f32, ctx->coarse_lo_key[w], ctx->coarse_n_keys[w], ctx->coarse_n_fix[w]};
+    if (f64_cat) {
+        if (a.r == 4) return launch_march<double, AVX_COLOR_CAT_MERGE, 4, 4, 2, 3, NF>(ctx, a, d, qc, s);
+        return AVX_ERR_UNSUPPORTED;
+    }
+    switch (a.r) {
+        // <R, SY, XPT, min waves/SIMD>, from A/B runs on MI355X: 2 columns per thread keeps the
+        // row-window reads conflict-free (16-byte lane stride) and the register windows under 128 VGPRs.
+#define AVX_MARCH_F32(RR, XX, MW) case RR: return launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, MW, NF>(ctx, a, d, qc, s);
+        AVX_MARCH_F32(1, 4, 3) AVX_MARCH_F32(3, 4, 3) AVX_MARCH_F32(4, 2, 3) AVX_MARCH_F32(5, 2, 3) AVX_MARCH_F32(6, 2, 3)
+        AVX_MARCH_F32(7, 2, 3) AVX_MARCH_F32(8, 2, 3) AVX_MARCH_F32(9, 2, 3) AVX_MARCH_F32(14, 2, 2)
+#undef AVX_MARCH_F32
+        default: return AVX_ERR_UNSUPPORTED;
+    }
+}

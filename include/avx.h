@@ -91,6 +91,7 @@ typedef struct avx_dichromat_desc {
     int32_t row_gain_clamp;    /* AVX_POST_ROWGAIN: clip channel 2 to [0,1] after the gain            */
     int32_t chroma_enable;     /* apply_chroma_compression after the post stage                      */
     float chroma_keep;         /*   float32(1 - strength), the factor animal_utils.py:181 multiplies by */
+    int32_t variant;           /* 0 = auto; A/B only: 1 = reference kernel, 2 = 2-D tiled, 3 = marching strip */
 } avx_dichromat_desc;
 
 #define AVX_MAX_KSIZE 33

@@ -91,6 +91,35 @@ def test_constant_frame_is_preserved_in_shape_and_flat(av):
     assert (out == out[0, 0]).all()
 
 
+@pytest.mark.parametrize("name", ["dog", "cat", "wolf"])
+def test_tuned_kernel_equals_reference_kernel(av, name):
+    """A/B inside the library: every kernel variant produces the same bytes."""
+    from animal_vision_amd import animals
+    from animal_vision_amd.dichromat import DichromatOp
+
+    spec = getattr(animals, name.capitalize()).SPEC
+    rng = np.random.default_rng(77)
+    batch = rng.integers(0, 256, (3, 200, 328, 3), dtype=np.uint8)
+    batch[1] = rng.integers(0, 2, (200, 328, 3), dtype=np.uint8)  # an all-<=1 frame inside the batch
+    outs = []
+    for variant in (1, 2, 3, 0):  # reference, 2-D tiled, marching strip, auto
+        op = DichromatOp(spec)
+        op.desc.variant = variant
+        outs.append(op(batch))
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
+
+
+def test_unaligned_widths_and_device_offsets(av, oracle):
+    """Widths with W*3 % 4 != 0 (byte-granular store path) and W % 16 != 0 (dword path)."""
+    for (H, W) in [(70, 66), (70, 68), (33, 131), (129, 63)]:
+        frame = np.random.default_rng(H * W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+        for nm in ("dog", "cat", "squirrel"):
+            _, want = oracle.dichromat_visualize(oracle.DICHROMATS[nm], frame)
+            _, got = _species(av, nm).visualize(frame)
+            assert np.array_equal(got, want), (nm, H, W)
+
+
 def test_bad_arguments_raise(av):
     from animal_vision_amd.animals import Dog
 

@@ -1,0 +1,32 @@
+#!/bin/bash
+# PMC counter passes for one workload (separate runs per counter group; --pmc only, no trace domains).
+set -o pipefail
+export TMPDIR=/tmp
+WL=${WL:-wolf_1080p}
+mkdir -p gpurun_out/pmc
+i=0
+while read -r group; do
+  [ -z "$group" ] && continue
+  i=$((i+1))
+  rm -rf gpurun_out/pmc/p$i
+  timeout -k 10 300 rocprofv3 --pmc $group --output-format csv -d gpurun_out/pmc/p$i -- python bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc/p$i.out 2> gpurun_out/pmc/p$i.err || { tail -5 gpurun_out/pmc/p$i.err; }
+done <<GROUPS
+SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
+SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA
+FETCH_SIZE
+WRITE_SIZE
+GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
+GROUPS
+python - <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        k = "main" if "_kernel<" in k and ", false," in k else ("dark" if "_kernel<" in k else k[:40])
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print("==", k)
+    for c, v in sorted(d.items()):
+        print(f"  {c:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+PY
