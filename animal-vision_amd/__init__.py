@@ -9,4 +9,6 @@ from ._lib import AvxError  # noqa: F401
 from .runtime import Context, DeviceBuffer, device_count, get_context, get_table  # noqa: F401
 from .dichromat import DichromatOp, DichromatSpec, collapse_LMS_matrix, cv_auto_ksize, gaussian_taps  # noqa: F401
 
+from . import uv  # noqa: F401
+
 __version__ = "0.1.0"

@@ -42,6 +42,30 @@ class DichromatDesc(ctypes.Structure):
     ]
 
 
+class HoneybeeDesc(ctypes.Structure):
+    """avx_honeybee_desc (include/avx.h)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("source", ctypes.c_int32),
+        ("rgb_matrix", ctypes.c_float * 9),
+        ("hsi", ctypes.c_void_p),
+        ("hsi_layout", ctypes.c_int32),
+        ("hsi_dtype", ctypes.c_int32),
+        ("bands", ctypes.c_int32),
+        ("weights_host", ctypes.POINTER(ctypes.c_float)),
+        ("adaptation", ctypes.c_int32),
+        ("eps", ctypes.c_float),
+        ("blur_ksize", ctypes.c_int32),
+        ("blur_taps_host", ctypes.POINTER(ctypes.c_double)),
+        ("mapping", ctypes.c_int32),
+        ("custom_matrix", ctypes.c_float * 9),
+        ("mixed_alpha", ctypes.c_float),
+    ]
+
+
+AVX_MAP = {"falsecolor": 0, "custom_matrix": 1, "opponent": 2, "uv_purple_yellow": 3, "falsecolor_uv_mixed": 4}
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -70,6 +94,12 @@ _SIGS = {
     "avx_timer_stop": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "avx_dichromat_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(DichromatDesc), _vp]),
     "avx_get_table": (_i, [_i, _vp, _sz]),
+    "avx_percentile": (_i, [_vp, _vp, _sz, ctypes.c_double, ctypes.POINTER(ctypes.c_double), _vp]),
+    "avx_spectral_integrate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "avx_plane_stats": (_i, [_vp, _vp, _i, _sz, _i, ctypes.c_float, _vp, _vp]),
+    "avx_planes_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "avx_rgb_to_hsi_lobes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_float, _vp, _vp]),
+    "avx_honeybee_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(HoneybeeDesc), _vp, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = stale libavx.so: rebuild

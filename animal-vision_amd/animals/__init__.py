@@ -4,3 +4,4 @@ from ._dichromats import (  # noqa: F401
     Bear, Cat, Cow, Deer, Dog, Elephant, Fox, Goat, Horse, Kangaroo, Lion, Panda, Pig, Rabbit, Raccoon,
     Rat, Sheep, Squirrel, Tiger, Wolf,
 )
+from .honeybee import HoneyBee  # noqa: F401

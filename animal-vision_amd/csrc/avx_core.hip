@@ -122,6 +122,7 @@ void avx_destroy(avx_ctx* ctx) {
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_row_gain) (void)hipFree(ctx->d_row_gain);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->uv_small) (void)hipFree(ctx->uv_small);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->compute) (void)hipStreamDestroy(ctx->compute);

@@ -29,7 +29,8 @@ struct avx_ctx {
     size_t flags_cap = 0;
     float* d_row_gain = nullptr;     // per-row gains (AVX_POST_ROWGAIN)
     size_t row_gain_cap = 0;
-    void* d_scratch = nullptr;       // general scratch arena (UV path planes, histograms)
+    void* uv_small = nullptr;        // UV path: partial statistics, histogram, select state, percentiles
+    void* d_scratch = nullptr;       // general scratch arena (UV path planes)
     size_t scratch_cap = 0;
     int num_cus = 256;
 };

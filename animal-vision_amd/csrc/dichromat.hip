@@ -199,7 +199,6 @@ int launch_simple(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, h
 //                  threshold quantiser -> uint8 tile in LDS
 //   store    uint8 tile -> HBM with 16-byte (or 4-byte / 1-byte on odd widths) stores
 // The arithmetic (operation order, fma placement) is exactly the contract at the top of this file.
-constexpr int kTiledThreads = 512;
 
 __host__ __device__ constexpr int round_up_odd_multiple(int v, int m) {
     // smallest p >= v with p % m == 0 and (p / m) odd

@@ -1,0 +1,706 @@
+// csrc/uv.hip -- UV / spectral path kernels for gfx950.
+//
+// Replaces, per frame, the NumPy bodies of (paths relative to the reference):
+//   classic_rgb_to_hsi analytic lobes   ml/classic_rgb_to_hsi/classic_rgb_to_hsi.py:47-82   (a13)
+//   hsi * E, tensordot cone catches      animals/honeybee.py:125-135                          (a15, a16)
+//   integrate_band / bandpass weights    uv_helpers.py:142-146                                (a17)
+//   von_kries_white_patch / gray_world   uv_helpers.py:195-206, safe_norm :47-53              (a18)
+//   gaussian_blur                        uv_helpers.py:67-73 (cv2 semantics, shared contract) (a19)
+//   np.percentile (linear interpolation) uv_mappers.py:32,61-62,73,104,142                    (a20, a21)
+//   map_opponent / falsecolor / ...      uv_mappers.py:29-144, then honeybee.py:166-173        (a20, a21, a11)
+//
+// Float contract: within 1e-4 relative of the reference for the spectral math (the transcendental
+// functions - atan2f, powf - are the device's); exact order statistics for the percentiles; the
+// final uint8 encode uses the same threshold table as the dichromat path.
+// Layout: K float32 planes of H*W (struct-of-arrays: every pass streams planes with 16-byte accesses).
+#include <hip/hip_fp16.h>
+
+#include "dichromat_common.h"
+
+using namespace avxk;
+
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Per-block partial {min, max, sum} of up to 16 planes -> partials[block][k][3] (sum kept in double).
+struct Stat3 { float mn, mx; double sum; };
+
+template <int KMAX>
+__device__ __forceinline__ void block_stats_store(const float (&mn)[KMAX], const float (&mx)[KMAX], const double (&sm)[KMAX], int K,
+                                                  Stat3* partials) {
+    __shared__ float s_mn[kT / 64][KMAX], s_mx[kT / 64][KMAX];
+    __shared__ double s_sm[kT / 64][KMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < K; ++k) {
+        const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+        const double c = wave_sum(sm[k]);
+        if (lane == 0) { s_mn[wave][k] = a; s_mx[wave][k] = b; s_sm[wave][k] = c; }
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float a = s_mn[0][threadIdx.x], b = s_mx[0][threadIdx.x];
+        double c = s_sm[0][threadIdx.x];
+        for (int w = 1; w < kT / 64; ++w) { a = fminf(a, s_mn[w][threadIdx.x]); b = fmaxf(b, s_mx[w][threadIdx.x]); c += s_sm[w][threadIdx.x]; }
+        partials[(size_t)blockIdx.x * K + threadIdx.x] = Stat3{a, b, c};
+    }
+}
+
+// ---- RGB uint8 -> K planes through the decode table and a K x 3 matrix (folded lobes x illuminant x
+//      receptor curves).  4 pixels (12 bytes = 3 aligned dwords) per thread. --------------------------
+template <int KMAX>
+__global__ __launch_bounds__(kT) void k_rgb_to_planes(const uint8_t* __restrict__ in, size_t n, const float* __restrict__ lut_g,
+                                                      const float* __restrict__ mat /*K x 3 device*/, int K, float* __restrict__ out,
+                                                      Stat3* partials) {
+    __shared__ float lut[256];
+    __shared__ float m[KMAX * 3];
+    for (int i = threadIdx.x; i < 256; i += kT) lut[i] = lut_g[i];
+    for (int i = threadIdx.x; i < K * 3; i += kT) m[i] = mat[i];
+    __syncthreads();
+    float mn[KMAX], mx[KMAX];
+    double sm[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; sm[k] = 0.0; }
+    const size_t nq = n / 4;
+    const bool aligned = ((uintptr_t)in & 3u) == 0 && ((uintptr_t)out & 15u) == 0 && (n % 4 == 0);
+    for (size_t q = (size_t)blockIdx.x * kT + threadIdx.x; q < nq + 1; q += (size_t)gridDim.x * kT) {
+        const size_t p0 = q * 4;
+        const int cnt = q < nq ? 4 : (int)(n - p0);
+        if (cnt <= 0) break;
+        uint32_t code[4][3];
+        if (cnt == 4 && ((uintptr_t)in & 3u) == 0) {
+            const uint32_t* d = reinterpret_cast<const uint32_t*>(in + p0 * 3);
+            const uint32_t u0 = d[0], u1 = d[1], u2 = d[2];
+            code[0][0] = u0 & 255u; code[0][1] = (u0 >> 8) & 255u; code[0][2] = (u0 >> 16) & 255u;
+            code[1][0] = u0 >> 24;  code[1][1] = u1 & 255u;        code[1][2] = (u1 >> 8) & 255u;
+            code[2][0] = (u1 >> 16) & 255u; code[2][1] = u1 >> 24; code[2][2] = u2 & 255u;
+            code[3][0] = (u2 >> 8) & 255u; code[3][1] = (u2 >> 16) & 255u; code[3][2] = u2 >> 24;
+        } else {
+            for (int p = 0; p < 4; ++p)
+                for (int c = 0; c < 3; ++c) code[p][c] = p < cnt ? in[(p0 + p) * 3 + c] : 0u;
+        }
+        float c0[4], c1[4], c2[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { c0[p] = lut[code[p][0]]; c1[p] = lut[code[p][1]]; c2[p] = lut[code[p][2]]; }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                float v[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    v[p] = fma_t(c2[p], m[3 * k + 2], fma_t(c1[p], m[3 * k + 1], c0[p] * m[3 * k]));
+                    if (p < cnt) { mn[k] = fminf(mn[k], v[p]); mx[k] = fmaxf(mx[k], v[p]); sm[k] += (double)v[p]; }
+                }
+                float* o = out + (size_t)k * n + p0;
+                if (cnt == 4 && aligned) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int p = 0; p < cnt; ++p) o[p] = v[p];
+            }
+        }
+    }
+    block_stats_store<KMAX>(mn, mx, sm, K, partials);
+}
+
+// ---- HSI cube -> K planes: out_k = sum_b cube_b * w[k][b] (sequential over b, f32 accumulate) -------
+// layout 0: NHWC (pixel-major, bands contiguous)   layout 1: NCHW (band planes).  dtype 0: f32, 1: f16.
+template <int KMAX>
+__global__ __launch_bounds__(kT) void k_spectral_integrate(const void* __restrict__ cube, int layout, int dtype, size_t n, int B,
+                                                           const float* __restrict__ w_g /*K x B*/, int K, float* __restrict__ out,
+                                                           Stat3* partials) {
+    extern __shared__ float w[];  // K*B
+    for (int i = threadIdx.x; i < K * B; i += kT) w[i] = w_g[i];
+    __syncthreads();
+    float mn[KMAX], mx[KMAX];
+    double sm[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; sm[k] = 0.0; }
+    for (size_t p = (size_t)blockIdx.x * kT + threadIdx.x; p < n; p += (size_t)gridDim.x * kT) {
+        float acc[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) acc[k] = 0.0f;
+        for (int b = 0; b < B; ++b) {
+            const size_t idx = layout == 0 ? p * B + b : (size_t)b * n + p;
+            const float x = dtype == 0 ? reinterpret_cast<const float*>(cube)[idx]
+                                       : __half2float(reinterpret_cast<const __half*>(cube)[idx]);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) acc[k] = fma_t(x, w[k * B + b], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                out[(size_t)k * n + p] = acc[k];
+                mn[k] = fminf(mn[k], acc[k]); mx[k] = fmaxf(mx[k], acc[k]); sm[k] += (double)acc[k];
+            }
+    }
+    block_stats_store<KMAX>(mn, mx, sm, K, partials);
+}
+
+// ---- plain statistics of existing planes ----------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(kT) void k_plane_stats(const float* __restrict__ planes, size_t n, int K, Stat3* partials) {
+    float mn[KMAX], mx[KMAX];
+    double sm[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; sm[k] = 0.0; }
+    for (size_t p = (size_t)blockIdx.x * kT + threadIdx.x; p < n; p += (size_t)gridDim.x * kT)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) { const float v = planes[(size_t)k * n + p]; mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v); sm[k] += (double)v; }
+    block_stats_store<KMAX>(mn, mx, sm, K, partials);
+}
+
+// Final reduction (one block) -> stats[k] = {min, max, mean, denominator}; the denominator is what the
+// next pass divides by: adapt 0: 1 | 1 white_patch: max(max, eps) | 2 gray_world: max(mean, eps)
+// | 3 safe_norm: (max - min), with stats.x = min subtracted first (uv_helpers.py:47-53).
+__global__ void k_finalize_stats(const Stat3* partials, int nblocks, int K, size_t n, int adapt, float eps, float4* stats) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    float a = 3.4e38f, b = -3.4e38f;
+    double c = 0.0;
+    for (int i = 0; i < nblocks; ++i) { const Stat3 s = partials[(size_t)i * K + k]; a = fminf(a, s.mn); b = fmaxf(b, s.mx); c += s.sum; }
+    const float mean = (float)(c / (double)n);
+    float den = 1.0f;
+    if (adapt == 1) den = fmaxf(b, eps);
+    else if (adapt == 2) den = fmaxf(mean, eps);
+    else if (adapt == 3) den = b - a;
+    stats[k] = make_float4(a, b, mean, den);
+}
+
+// ---- plane blur: out = GaussianBlur((in - sub) / den), cv2 semantics, shared arithmetic contract ----
+// sub/den come from stats (mode 0: none, 1: divide by stats.w, 3: safe_norm -> (x - min)/(max - min), or
+// zeros when the range is < 1e-9).  Runtime radius (k <= 33); r == 0 is the pure rescale.
+struct BlurArgs {
+    const float* in; float* out; int K, H, W, r; const float4* stats; int scale_mode;
+    float taps[AVX_MAX_KSIZE];
+};
+
+__device__ __forceinline__ float rescale(float v, int mode, float4 st) {
+    if (mode == 1) return v / st.w;
+    if (mode == 3) return (st.y - st.x) < 1e-9f ? 0.0f : (v - st.x) / (st.y - st.x);
+    return v;
+}
+
+__global__ __launch_bounds__(kT) void k_plane_blur(BlurArgs a) {
+    constexpr int TW = 64, TH = 32;
+    extern __shared__ float sm[];
+    const int r = a.r, AW = TW + 2 * r, AH = TH + 2 * r;
+    float* A = sm;             // AH x AW
+    float* Bm = sm + AH * AW;  // AH x TW
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int total = tiles_x * tiles_y * a.K;
+    const size_t n = (size_t)a.H * a.W;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int k = tile / (tiles_x * tiles_y), t2 = tile - k * tiles_x * tiles_y;
+        const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
+        const float* src = a.in + (size_t)k * n;
+        float* dst = a.out + (size_t)k * n;
+        const float4 st = a.scale_mode ? a.stats[k] : make_float4(0.f, 0.f, 0.f, 1.f);
+        for (int i = threadIdx.x; i < AH * AW; i += kT) {
+            const int ly = i / AW, lx = i - ly * AW;
+            const int gy = reflect101(y0 - r + ly, a.H), gx = reflect101(x0 - r + lx, a.W);
+            A[i] = rescale(src[(size_t)gy * a.W + gx], a.scale_mode, st);
+        }
+        __syncthreads();
+        const float* colsrc = A;
+        int sw = AW;
+        if (r > 0) {
+            const int nt = 2 * r + 1;
+            for (int i = threadIdx.x; i < AH * TW; i += kT) {
+                const int ly = i / TW, x = i - ly * TW;
+                const float* row = A + ly * AW + x;
+                float s = row[0] * a.taps[0];
+                for (int j = 1; j < nt; ++j) s = fma_t(row[j], a.taps[j], s);
+                Bm[i] = s;
+            }
+            __syncthreads();
+            colsrc = Bm;
+            sw = TW;
+        }
+        for (int i = threadIdx.x; i < TH * TW; i += kT) {
+            const int y = i / TW, x = i - y * TW;
+            if (y0 + y >= a.H || x0 + x >= a.W) continue;
+            const float* col = colsrc + (y + r) * sw + x;
+            float s;
+            if (r > 0) {
+                s = col[0] * a.taps[r];
+                for (int j = 1; j <= r; ++j) s = fma_t(col[j * sw] + col[-j * sw], a.taps[r + j], s);
+            } else {
+                s = col[0];
+            }
+            dst[(size_t)(y0 + y) * a.W + x0 + x] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- exact order statistic: 3-pass radix select on order-preserving keys ---------------------------
+struct SelState {
+    uint32_t prefix, mask;      // key bits fixed so far
+    unsigned long long rank;    // remaining 0-based rank inside the selected prefix
+    uint32_t key_lo, key_hi;    // results: key of x[k] and of x[k+1]
+    uint32_t cnt_in_bin;        // size of the finally selected bin (duplicates of x[k])
+    uint32_t next_key;          // smallest key > key_lo
+};
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(kT) void k_sel_hist(const float* __restrict__ x, size_t n, int shift, int bits, const SelState* st,
+                                                 uint32_t* hist) {
+    __shared__ uint32_t h[2048];
+    const int nb = 1 << bits;
+    for (int i = threadIdx.x; i < nb; i += kT) h[i] = 0;
+    __syncthreads();
+    const uint32_t prefix = st->prefix, mask = st->mask;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
+        const uint32_t k = f2key(x[i]);
+        if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += kT)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ void k_sel_init(SelState* st, unsigned long long rank) {
+    if (threadIdx.x != 0) return;
+    st->prefix = 0; st->mask = 0; st->rank = rank; st->key_lo = 0; st->key_hi = 0; st->cnt_in_bin = 0; st->next_key = 0xffffffffu;
+}
+
+__global__ void k_sel_pick(uint32_t* hist, int shift, int bits, SelState* st, int last) {
+    if (threadIdx.x != 0) return;
+    const int nb = 1 << bits;
+    unsigned long long r = st->rank, cum = 0;
+    int b = 0;
+    for (; b < nb; ++b) {
+        const unsigned long long c = hist[b];
+        if (cum + c > r) break;
+        cum += c;
+    }
+    if (b == nb) b = nb - 1;  // rank beyond the data (cannot happen for rank < n)
+    st->prefix |= (uint32_t)b << shift;
+    st->mask |= (uint32_t)(nb - 1) << shift;
+    st->rank = r - cum;
+    if (last) { st->key_lo = st->prefix; st->cnt_in_bin = hist[b]; st->next_key = 0xffffffffu; }
+    for (int i = 0; i < nb; ++i) hist[i] = 0;
+}
+
+__global__ __launch_bounds__(kT) void k_sel_next(const float* __restrict__ x, size_t n, SelState* st) {
+    const uint32_t k0 = st->key_lo;
+    uint32_t best = 0xffffffffu;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
+        const uint32_t k = f2key(x[i]);
+        if (k > k0 && k < best) best = k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o); best = t < best ? t : best; }
+    if ((threadIdx.x & 63) == 0 && best != 0xffffffffu) atomicMin(&st->next_key, best);
+}
+
+// np.percentile's _lerp for a float32 array: everything in float32 (NumPy matches the virtual index and
+// gamma to the array dtype): diff = b - a; a + diff*t; and b - diff*(1-t) where t >= 0.5.
+__global__ void k_sel_lerp(const SelState* st, float gamma, int has_next, double* out) {
+    if (threadIdx.x != 0) return;
+    const float a = key2f(st->key_lo);
+    float b = a;
+    if (has_next && st->rank + 1 >= st->cnt_in_bin) b = st->next_key == 0xffffffffu ? a : key2f(st->next_key);
+    const float diff = b - a;
+    float r = a + diff * gamma;
+    if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
+    *out = (double)r;  // a float32 value (np.percentile returns np.float32 here)
+}
+
+// ---- opponent prep / maps / encode ------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void k_opponent_prep(const float* __restrict__ UBG, size_t n, float* __restrict__ radius, float* __restrict__ L) {
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
+        const float U = UBG[i], B = UBG[n + i], G = UBG[2 * n + i];
+        const float O1 = G - B, O2 = B - U;
+        L[i] = ((U + B) + G) / 3.0f;
+        radius[i] = __fsqrt_rn(O1 * O1 + O2 * O2);
+    }
+}
+
+struct MapArgs {
+    const float* UBG; size_t n; uint8_t* out; int mode;
+    const double* pct;       // device: percentiles (mode-dependent)
+    float eps; float M[9]; float alpha; float* mixed;  // mixed: 3 planes (mode 4, pass 1)
+    const float* enc_thr; const uint8_t* coarse; uint32_t lo_key; int pass;
+};
+
+__device__ __forceinline__ double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+__device__ __forceinline__ float clip01f(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+__device__ __forceinline__ void falsecolor(float U, float B, float G, const double* pct, float eps, float (&rgb)[3]) {
+    // uv_mappers.py:29-42: x / max(float(P95), eps) in float32
+    const float dU = fmaxf((float)pct[0], eps), dB = fmaxf((float)pct[1], eps), dG = fmaxf((float)pct[2], eps);
+    const float Un = U / dU, Bn = B / dB, Gn = G / dG;
+    rgb[0] = clip01f(0.85f * Un + 0.10f * Gn);
+    rgb[1] = clip01f(0.80f * Gn + 0.20f * Bn);
+    rgb[2] = clip01f(0.70f * Bn + 0.40f * Un);
+}
+
+__device__ __forceinline__ float s2l(float v) { return v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f); }
+
+__device__ __forceinline__ void purple_yellow_soft(float U, double p98, float eps, float (&rgb)[3]) {
+    // uv_mappers.py:90-132 with the default u_gamma 0.90, accent_gamma 0.85, accent_strength 0.05
+    const float denom = fmaxf((float)p98, eps);
+    const float u = powf(clip01f(U / denom), 0.90f);
+    const float c0[3] = {s2l(176.f / 255.f), s2l(124.f / 255.f), s2l(232.f / 255.f)};
+    const float c1[3] = {s2l(255.f / 255.f), s2l(211.f / 255.f), s2l(138.f / 255.f)};
+    const float w = powf(u, 0.85f);
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = ((1.0f - u) * c0[c] + u * c1[c]) + (0.05f * w) * (c0[c] - 0.5f);
+    const float Y = (0.2126f * v[0] + 0.7152f * v[1] + 0.0722f * v[2]) + eps;
+    const float Yt = clip01f(0.22f + 0.55f * u);
+    float gain = Yt / Y;
+    gain = gain < 0.6f ? 0.6f : (gain > 1.6f ? 1.6f : gain);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float t = v[c] * gain; rgb[c] = clip01f(t / (1.0f + 0.6f * t)); }
+}
+
+__global__ __launch_bounds__(kT) void k_map_encode(MapArgs a) {
+    __shared__ float thr[256];
+    __shared__ uint8_t coarse[1024];
+    for (int i = threadIdx.x; i < 256; i += kT) thr[i] = a.enc_thr[i];
+    for (int i = threadIdx.x; i < 1024; i += kT) coarse[i] = a.coarse[i];
+    __syncthreads();
+    const size_t n = a.n;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
+        const float U = a.UBG[i], B = a.UBG[n + i], G = a.UBG[2 * n + i];
+        float rgb[3];
+        if (a.mode == 2) {  // map_opponent, uv_mappers.py:53-64 (sat/val/hsv in float64 like the reference)
+            const float O1 = G - B, O2 = B - U;
+            const float L = ((U + B) + G) / 3.0f;
+            const float angle = atan2f(O2, O1);
+            const float hue = (angle + 3.14159265358979323846f) / 6.28318530717958647692f;
+            const float radius = __fsqrt_rn(O1 * O1 + O2 * O2);
+            // np.percentile returns float32 here, so sat/val stay float32; in hsv_to_rgb `h*6.0 - i` mixes
+            // float32 with int32, which NumPy promotes to float64: f, q, t are float64, p is float32.
+            const float sat = clip01f(radius / ((float)a.pct[0] + a.eps));
+            const float val = clip01f(L / ((float)a.pct[1] + a.eps));
+            const float h6 = hue * 6.0f;
+            const float fi = floorf(h6);
+            const int ii = (int)fi;
+            const double f = (double)h6 - (double)ii;
+            const float p = val * (1.0f - sat);
+            const float q = (float)((double)val * (1.0 - f * (double)sat));
+            const float t = (float)((double)val * (1.0 - (1.0 - f) * (double)sat));
+            const int im = ((ii % 6) + 6) % 6;
+            rgb[0] = im == 0 ? val : im == 1 ? q : im == 2 ? p : im == 3 ? p : im == 4 ? t : val;
+            rgb[1] = im == 0 ? t : im == 1 ? val : im == 2 ? val : im == 3 ? q : im == 4 ? p : p;
+            rgb[2] = im == 0 ? p : im == 1 ? p : im == 2 ? t : im == 3 ? val : im == 4 ? val : q;
+        } else if (a.mode == 0) {
+            falsecolor(U, B, G, a.pct, a.eps, rgb);
+        } else if (a.mode == 1) {  // map_linear_matrix: [U,B,G] @ M.T as an FMA chain
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = fma_t(G, a.M[3 * c + 2], fma_t(B, a.M[3 * c + 1], U * a.M[3 * c]));
+        } else if (a.mode == 3) {
+            purple_yellow_soft(U, a.pct[0], 1e-8f, rgb);
+        } else {  // mode 4: falsecolor_uv_mixed (uv_mappers.py:135-144), two passes around P99(mixed)
+            float base[3], tint[3];
+            falsecolor(U, B, G, a.pct, 1e-8f, base);
+            purple_yellow_soft(U, a.pct[3], 1e-8f, tint);
+            const float al = a.alpha;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = (1.0f - al) * base[c] + al * tint[c];
+            if (a.pass == 1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.mixed[(size_t)c * n + i] = rgb[c];
+                continue;
+            }
+            const double p99 = a.pct[4];
+            if (p99 > 1e-8) {
+                const float d = (float)(p99 > 1.0 ? p99 : 1.0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] / d;
+            }
+        }
+        // honeybee.py:166-173: clip -> linear_to_srgb -> *255+0.5 -> uint8, as the threshold count
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.out[i * 3 + c] = (uint8_t)quantize_coarse<float, 2>(rgb[c], thr, coarse, a.lo_key);
+    }
+}
+
+// ---- analytic RGB -> HSI cube (a13), for the drop-in classic_rgb_to_hsi --------------------------------
+__global__ __launch_bounds__(kT) void k_lobes_cube(const void* __restrict__ in, int in_u8, const float* __restrict__ lut_g, size_t n, int B,
+                                                   const float* __restrict__ gains /*B x 3: gB,gG,gR*/, float denom, float* __restrict__ out) {
+    extern __shared__ float g[];
+    __shared__ float lut[256];
+    for (int i = threadIdx.x; i < 3 * B; i += kT) g[i] = gains[i];
+    for (int i = threadIdx.x; i < 256; i += kT) lut[i] = lut_g[i];
+    __syncthreads();
+    for (size_t p = (size_t)blockIdx.x * kT + threadIdx.x; p < n; p += (size_t)gridDim.x * kT) {
+        float c0, c1, c2;
+        if (in_u8) {
+            const uint8_t* q = reinterpret_cast<const uint8_t*>(in) + p * 3;
+            c0 = lut[q[0]]; c1 = lut[q[1]]; c2 = lut[q[2]];
+        } else {  // float frame: srgb_to_linear applied as coded (Q6: also to already-linear inputs)
+            const float* q = reinterpret_cast<const float*>(in) + p * 3;
+            c0 = s2l(q[0]); c1 = s2l(q[1]); c2 = s2l(q[2]);
+        }
+        float* o = out + p * B;
+        for (int b = 0; b < B; ++b) {
+            // spec = gR*R + gG*G + gB*Bc (classic_rgb_to_hsi.py:70), then / (denom + 1e-8), clamp_min(0)
+            const float s = (g[3 * b + 2] * c2 + g[3 * b + 1] * c1) + g[3 * b] * c0;
+            o[b] = fmaxf(s / denom, 0.0f);
+        }
+    }
+}
+
+int grid_for(avx_ctx* ctx, size_t items) {
+    const size_t want = (items + kT - 1) / kT;
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+}  // namespace
+
+// ======================================= C ABI =======================================================
+struct UvScratch {
+    Stat3* partials; float4* stats; uint32_t* hist; SelState* sel; double* pct; float* mat;
+};
+
+static int uv_small_scratch(avx_ctx* ctx, UvScratch* s) {
+    // fixed small block at the start of the arena
+    const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + 2048 * 4 + sizeof(SelState) + 16 * 8 + 16 * 129 * 4 + 4096;
+    if (ctx->uv_small == nullptr) {
+        AVX_HIP(ctx, hipMalloc(&ctx->uv_small, need));
+    }
+    char* p = (char*)ctx->uv_small;
+    s->partials = (Stat3*)p; p += (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3);
+    s->stats = (float4*)p; p += 16 * sizeof(float4);
+    s->hist = (uint32_t*)p; p += 2048 * 4;
+    s->sel = (SelState*)p; p += sizeof(SelState) + 8;
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    s->pct = (double*)p; p += 16 * 8;
+    s->mat = (float*)p;
+    return AVX_OK;
+}
+
+// exact np.percentile(x, q) (linear interpolation) of n device floats -> *out_dev (device double)
+static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size_t n, double q, double* out_dev, hipStream_t s) {
+    // NumPy (2.x) evaluates the virtual index in the array's dtype: float32(n-1) * (float32(q)/float32(100)).
+    const float vi = (float)(n - 1) * ((float)q / 100.0f);
+    float lo = floorf(vi);
+    if (lo < 0) lo = 0;
+    if (lo > (float)(n - 1)) lo = (float)(n - 1);
+    const float gamma = vi - lo;
+    const int has_next = (size_t)lo + 1 < n;
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, s, u.sel, (unsigned long long)lo);
+    AVX_HIP(ctx, hipMemsetAsync(u.hist, 0, 2048 * 4, s));
+    const int g = grid_for(ctx, n);
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int p = 0; p < 3; ++p) {
+        hipLaunchKernelGGL(k_sel_hist, dim3(g), dim3(kT), 0, s, x, n, shifts[p], bits[p], u.sel, u.hist);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(64), 0, s, u.hist, shifts[p], bits[p], u.sel, p == 2 ? 1 : 0);
+    }
+    if (has_next) hipLaunchKernelGGL(k_sel_next, dim3(g), dim3(kT), 0, s, x, n, u.sel);
+    hipLaunchKernelGGL(k_sel_lerp, dim3(1), dim3(64), 0, s, u.sel, gamma, has_next, out_dev);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+extern "C" {
+
+int avx_percentile(avx_ctx* ctx, const float* data, size_t n, double q, double* out_host, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, data && out_host && n > 0 && q >= 0.0 && q <= 100.0, "avx_percentile: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, &u);
+    if (rc) return rc;
+    rc = run_percentile(ctx, u, data, n, q, u.pct, s);
+    if (rc) return rc;
+    AVX_HIP(ctx, hipMemcpyAsync(out_host, u.pct, sizeof(double), hipMemcpyDeviceToHost, s));
+    AVX_HIP(ctx, hipStreamSynchronize(s));
+    return AVX_OK;
+}
+
+int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype, int H, int W, int B, const float* weights_host, int K,
+                           float* out_planes, float* stats_host, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, hsi && weights_host && out_planes, "avx_spectral_integrate: NULL pointer");
+    AVX_REQUIRE(ctx, H > 0 && W > 0 && B > 0 && B <= 129 && K > 0 && K <= 16, "avx_spectral_integrate: bad shape H=%d W=%d B=%d K=%d", H, W, B, K);
+    AVX_REQUIRE(ctx, (layout == 0 || layout == 1) && (dtype == 0 || dtype == 1), "avx_spectral_integrate: bad layout/dtype");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, &u);
+    if (rc) return rc;
+    const size_t n = (size_t)H * W;
+    AVX_HIP(ctx, hipMemcpyAsync(u.mat, weights_host, sizeof(float) * K * B, hipMemcpyHostToDevice, s));
+    const int g = grid_for(ctx, n);
+    hipLaunchKernelGGL(k_spectral_integrate<16>, dim3(g), dim3(kT), sizeof(float) * K * B, s, hsi, layout, dtype, n, B, u.mat, K, out_planes, u.partials);
+    hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(64), 0, s, u.partials, g, K, n, 0, 0.0f, u.stats);
+    AVX_HIP(ctx, hipGetLastError());
+    if (stats_host) {
+        AVX_HIP(ctx, hipMemcpyAsync(stats_host, u.stats, sizeof(float4) * K, hipMemcpyDeviceToHost, s));
+        AVX_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return AVX_OK;
+}
+
+int avx_planes_gaussian_blur(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize, const double* taps_host,
+                             int scale_mode, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, in && out && in != out, "avx_planes_gaussian_blur: NULL or aliased planes");
+    AVX_REQUIRE(ctx, K > 0 && K <= 16 && H > 0 && W > 0, "avx_planes_gaussian_blur: bad shape");
+    AVX_REQUIRE(ctx, ksize >= 1 && ksize <= AVX_MAX_KSIZE && (ksize & 1), "avx_planes_gaussian_blur: ksize %d must be odd, 1..%d", ksize, AVX_MAX_KSIZE);
+    AVX_REQUIRE(ctx, ksize == 1 || taps_host, "avx_planes_gaussian_blur: taps_host is NULL");
+    AVX_REQUIRE(ctx, scale_mode == 0 || scale_mode == 1 || scale_mode == 3, "avx_planes_gaussian_blur: bad scale_mode");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, &u);
+    if (rc) return rc;
+    BlurArgs a{};
+    a.in = in; a.out = out; a.K = K; a.H = H; a.W = W; a.r = ksize / 2; a.stats = u.stats; a.scale_mode = scale_mode;
+    for (int i = 0; i < ksize; ++i) a.taps[i] = ksize == 1 ? 1.0f : (float)taps_host[i];
+    const int AW = 64 + 2 * a.r, AH = 32 + 2 * a.r;
+    const size_t lds = sizeof(float) * ((size_t)AH * AW + (size_t)AH * 64);
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_plane_blur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long tiles = (long)((W + 63) / 64) * ((H + 31) / 32) * K;
+    const int g = (int)(tiles < (long)ctx->num_cus * 4 ? tiles : (long)ctx->num_cus * 4);
+    hipLaunchKernelGGL(k_plane_blur, dim3(g), dim3(kT), lds, s, a);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+int avx_plane_stats(avx_ctx* ctx, const float* planes, int K, size_t n, int adapt, float eps, float* stats_host, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, planes && K > 0 && K <= 16 && n > 0 && adapt >= 0 && adapt <= 3, "avx_plane_stats: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, &u);
+    if (rc) return rc;
+    const int g = grid_for(ctx, n);
+    hipLaunchKernelGGL(k_plane_stats<16>, dim3(g), dim3(kT), 0, s, planes, n, K, u.partials);
+    hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(64), 0, s, u.partials, g, K, n, adapt, eps, u.stats);
+    AVX_HIP(ctx, hipGetLastError());
+    if (stats_host) {
+        AVX_HIP(ctx, hipMemcpyAsync(stats_host, u.stats, sizeof(float4) * K, hipMemcpyDeviceToHost, s));
+        AVX_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return AVX_OK;
+}
+
+int avx_rgb_to_hsi_lobes(avx_ctx* ctx, const void* in_hwc, int in_is_u8, int H, int W, int B, const float* gains_host, float denom,
+                         float* out_hwb, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, in_hwc && gains_host && out_hwb && H > 0 && W > 0 && B >= 2 && B <= 129, "avx_rgb_to_hsi_lobes: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, &u);
+    if (rc) return rc;
+    AVX_HIP(ctx, hipMemcpyAsync(u.mat, gains_host, sizeof(float) * 3 * B, hipMemcpyHostToDevice, s));
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(k_lobes_cube, dim3(grid_for(ctx, n)), dim3(kT), sizeof(float) * 3 * B, s, in_hwc, in_is_u8, ctx->d_decode_lut, n, B,
+                       u.mat, denom, out_hwb);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+// Whole honeybee tail for n_frames frames (honeybee.py:125-175); see include/avx.h.
+int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W, const avx_honeybee_desc* d,
+                    float* debug_planes, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_honeybee_desc), "avx_honeybee_u8: desc is NULL or struct_size mismatch");
+    AVX_REQUIRE(ctx, out_hwc && n_frames >= 0 && H > 0 && W > 0, "avx_honeybee_u8: bad arguments");
+    AVX_REQUIRE(ctx, d->source == 0 || d->source == 1, "avx_honeybee_u8: bad source");
+    AVX_REQUIRE(ctx, d->source == 1 ? (d->hsi && d->weights_host && d->bands > 0 && d->bands <= 129) : (in_hwc != nullptr), "avx_honeybee_u8: missing input");
+    AVX_REQUIRE(ctx, d->adaptation >= 0 && d->adaptation <= 2 && d->mapping >= 0 && d->mapping <= 4, "avx_honeybee_u8: bad adaptation/mapping");
+    AVX_REQUIRE(ctx, d->blur_ksize == 0 || ((d->blur_ksize & 1) && d->blur_ksize <= AVX_MAX_KSIZE && d->blur_taps_host), "avx_honeybee_u8: bad blur");
+    if (n_frames == 0) return AVX_OK;
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, &u);
+    if (rc) return rc;
+    const size_t n = (size_t)H * W;
+    rc = avx_ensure_scratch(ctx, sizeof(float) * n * 9 + 256);
+    if (rc) return rc;
+    float* raw = (float*)ctx->d_scratch;      // 3 planes: catches
+    float* ubg = raw + 3 * n;                 // 3 planes: adapted + blurred
+    float* aux = ubg + 3 * n;                 // 3 planes: radius/L, or mixed
+    const int g = grid_for(ctx, n);
+    if (d->source == 0) AVX_HIP(ctx, hipMemcpyAsync(u.mat, d->rgb_matrix, sizeof(float) * 9, hipMemcpyHostToDevice, s));
+    else AVX_HIP(ctx, hipMemcpyAsync(u.mat, d->weights_host, sizeof(float) * 3 * d->bands, hipMemcpyHostToDevice, s));
+    for (int f = 0; f < n_frames; ++f) {
+        uint8_t* out = out_hwc + (size_t)f * n * 3;
+        // 1-3) catches U, B, G (+ per-plane statistics)
+        if (d->source == 0) {
+            hipLaunchKernelGGL(k_rgb_to_planes<3>, dim3(g), dim3(kT), 0, s, in_hwc + (size_t)f * n * 3, n, ctx->d_decode_lut, u.mat, 3, raw, u.partials);
+        } else {
+            const size_t esz = d->hsi_dtype == 0 ? 4 : 2;
+            const char* cube = (const char*)d->hsi + (size_t)f * n * d->bands * esz;
+            hipLaunchKernelGGL(k_spectral_integrate<3>, dim3(g), dim3(kT), sizeof(float) * 3 * d->bands, s, (const void*)cube, d->hsi_layout, d->hsi_dtype, n,
+                               d->bands, u.mat, 3, raw, u.partials);
+        }
+        // 4) von Kries denominators
+        hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(64), 0, s, u.partials, g, 3, n, d->adaptation, d->eps, u.stats);
+        // 5) (x / white) then Gaussian blur
+        {
+            BlurArgs a{};
+            a.in = raw; a.out = ubg; a.K = 3; a.H = H; a.W = W; a.r = d->blur_ksize / 2; a.stats = u.stats; a.scale_mode = d->adaptation ? 1 : 0;
+            for (int i = 0; i < d->blur_ksize; ++i) a.taps[i] = (float)d->blur_taps_host[i];
+            const int AW = 64 + 2 * a.r, AH = 32 + 2 * a.r;
+            const size_t lds = sizeof(float) * ((size_t)AH * AW + (size_t)AH * 64);
+            AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_plane_blur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const long tiles = (long)((W + 63) / 64) * ((H + 31) / 32) * 3;
+            const int gb = (int)(tiles < (long)ctx->num_cus * 4 ? tiles : (long)ctx->num_cus * 4);
+            hipLaunchKernelGGL(k_plane_blur, dim3(gb), dim3(kT), lds, s, a);
+        }
+        if (debug_planes) AVX_HIP(ctx, hipMemcpyAsync(debug_planes + (size_t)f * 3 * n, ubg, sizeof(float) * 3 * n, hipMemcpyDeviceToDevice, s));
+        // 6) percentiles the mapping needs, then map + encode
+        MapArgs m{};
+        m.UBG = ubg; m.n = n; m.out = out; m.mode = d->mapping; m.pct = u.pct; m.eps = d->eps; m.alpha = d->mixed_alpha; m.mixed = aux;
+        for (int i = 0; i < 9; ++i) m.M[i] = d->custom_matrix[i];
+        m.enc_thr = ctx->d_enc_thr_f32; m.coarse = ctx->d_coarse_f32; m.lo_key = ctx->coarse_lo_key[0]; m.pass = 0;
+        if (d->mapping == 2) {
+            hipLaunchKernelGGL(k_opponent_prep, dim3(g), dim3(kT), 0, s, ubg, n, aux, aux + n);
+            if ((rc = run_percentile(ctx, u, aux, n, 95.0, u.pct + 0, s))) return rc;
+            if ((rc = run_percentile(ctx, u, aux + n, n, 95.0, u.pct + 1, s))) return rc;
+        } else if (d->mapping == 0 || d->mapping == 4) {
+            for (int k = 0; k < 3; ++k)
+                if ((rc = run_percentile(ctx, u, ubg + (size_t)k * n, n, 95.0, u.pct + k, s))) return rc;
+        }
+        if (d->mapping == 3) { if ((rc = run_percentile(ctx, u, ubg, n, 98.0, u.pct + 0, s))) return rc; }
+        if (d->mapping == 4) {
+            if ((rc = run_percentile(ctx, u, ubg, n, 98.0, u.pct + 3, s))) return rc;
+            m.pass = 1;
+            hipLaunchKernelGGL(k_map_encode, dim3(g), dim3(kT), 0, s, m);
+            if ((rc = run_percentile(ctx, u, aux, 3 * n, 99.0, u.pct + 4, s))) return rc;
+            m.pass = 2;
+        }
+        hipLaunchKernelGGL(k_map_encode, dim3(g), dim3(kT), 0, s, m);
+        AVX_HIP(ctx, hipGetLastError());
+    }
+    return AVX_OK;
+}
+
+}  // extern "C"

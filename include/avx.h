@@ -99,6 +99,62 @@ typedef struct avx_dichromat_desc {
 int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W,
                      const avx_dichromat_desc* desc, void* stream);
 
+/* ---- UV / spectral path: uv_helpers.py, uv_mappers.py, ml/classic_rgb_to_hsi, animals/honeybee.py ----
+ *
+ * Planes are float32, K x (H*W), struct-of-arrays.  Float contract: within 1e-4 relative of the reference
+ * (device atan2f/powf); order statistics are exact; uint8 encode uses the reference's threshold table. */
+
+/* np.percentile(data, q) with linear interpolation (uv_mappers.py:32,61-62,73,104,142): exact order
+ * statistics by radix select on device, NumPy's _lerp formula; blocks until the value is on the host. */
+int avx_percentile(avx_ctx* ctx, const float* data, size_t n, double q, double* out_host, void* stream);
+
+/* integrate_band / cone catches (uv_helpers.py:142-146, honeybee.py:125-135): out_k = sum_b hsi_b * w[k][b].
+ * layout 0 = HxWxB (NHWC), 1 = BxHxW (NCHW, what a torch model emits); dtype 0 = float32, 1 = float16.
+ * weights_host: K x B with the illuminant already folded in.  stats_host (optional): K x {min,max,mean,1}. */
+int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype, int H, int W, int B,
+                           const float* weights_host, int K, float* out_planes, float* stats_host, void* stream);
+
+/* {min, max, mean, denominator} per plane (safe_norm uv_helpers.py:47-53, von_kries_* :195-206).
+ * adapt: 0 none (den 1), 1 white_patch max(max,eps), 2 gray_world max(mean,eps), 3 safe_norm (max-min).
+ * The result stays on the device for the next avx_planes_gaussian_blur; stats_host (optional) copies it. */
+int avx_plane_stats(avx_ctx* ctx, const float* planes, int K, size_t n, int adapt, float eps, float* stats_host, void* stream);
+
+/* uv_helpers.gaussian_blur (uv_helpers.py:67-73, cv2 semantics) on K planes, optionally rescaling each plane by
+ * the statistics of the last avx_plane_stats / avx_spectral_integrate first: scale_mode 0 none, 1 x/den,
+ * 3 safe_norm.  ksize == 1: rescale only.  taps_host: ksize normalised taps in double. */
+int avx_planes_gaussian_blur(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize,
+                             const double* taps_host, int scale_mode, void* stream);
+
+/* classic_rgb_to_hsi analytic branch (ml/classic_rgb_to_hsi/classic_rgb_to_hsi.py:47-82): HxWx3 frame (uint8, or
+ * float32 that is linearised as coded) -> HxWxB float32 cube.  gains_host: B x 3 lobe gains in input-channel
+ * order (quirk Q5), denom: mean lobe sum + 1e-8. */
+int avx_rgb_to_hsi_lobes(avx_ctx* ctx, const void* in_hwc, int in_is_u8, int H, int W, int B, const float* gains_host,
+                         float denom, float* out_hwb, void* stream);
+
+/* HoneyBee.visualize steps 1-7 (animals/honeybee.py:99-175) for N uint8 frames, all passes on the device:
+ * catches -> von Kries -> Gaussian blur -> percentiles -> map_* -> clip -> OETF -> uint8. */
+enum { AVX_MAP_FALSECOLOR = 0, AVX_MAP_CUSTOM_MATRIX = 1, AVX_MAP_OPPONENT = 2, AVX_MAP_UV_PURPLE_YELLOW = 3, AVX_MAP_FALSECOLOR_UV_MIXED = 4 };
+typedef struct avx_honeybee_desc {
+    uint32_t struct_size;
+    int32_t source;            /* 0: uint8 RGB frames + rgb_matrix (analytic lobes x illuminant x cone curves folded
+                                  to 3x3, the route honeybee.py actually takes); 1: an HSI cube + weights_host  */
+    float rgb_matrix[9];       /* source 0: [U,B,G]_k = sum_j rgb_matrix[k][j] * linear_channel_j                  */
+    const void* hsi;           /* source 1: device cube(s), N of them back to back                                */
+    int32_t hsi_layout, hsi_dtype, bands;
+    const float* weights_host; /* source 1: 3 x bands (illuminant folded in)                                      */
+    int32_t adaptation;        /* 0 none, 1 white_patch, 2 gray_world (honeybee.py:137-141)                       */
+    float eps;
+    int32_t blur_ksize;        /* 0: no blur; else odd taps of uv_helpers.gaussian_blur                            */
+    const double* blur_taps_host;
+    int32_t mapping;           /* AVX_MAP_*                                                                       */
+    float custom_matrix[9];
+    float mixed_alpha;         /* falsecolor_uv_mixed alpha (honeybee.py:162 passes 0.45)                          */
+} avx_honeybee_desc;
+
+/* debug_planes (optional, device, N x 3 x H*W floats): receives U,B,G after adaptation + blur. */
+int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W,
+                    const avx_honeybee_desc* desc, float* debug_planes, void* stream);
+
 /* The constant tables compiled into the library (reference outputs, see csrc/srgb_tables.h):
  * which = 0: 256 x f32 decode LUT; 1: 255 x f32 encode thresholds; 2: 255 x f64 encode thresholds.
  * Copies min(capacity, size) bytes to dst_host and returns the table's size in bytes. */

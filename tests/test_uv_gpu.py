@@ -1,0 +1,143 @@
+"""GPU parity of the UV / spectral path (csrc/uv.hip through the C ABI) vs the oracle and golden vectors.
+
+Tolerances (north_star): float spectral math within 1e-4 relative; order statistics exact; the shared
+Gaussian contract bit-exact; final uint8 within 1 code (device atan2f/powf differ from NumPy's by ulps,
+which can move a value across a quantiser threshold) on a small fraction of bytes."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def uv():
+    import animal_vision_amd as av
+    from animal_vision_amd import uv
+
+    assert av.device_count() > 0
+    return uv
+
+
+def _u8_close(got, want, max_frac=2e-3):
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"max |diff| = {d.max()}"
+    frac = float((d > 0).mean())
+    assert frac <= max_frac, f"{frac:.2e} of bytes differ by 1"
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 65537, 1 << 20])
+@pytest.mark.parametrize("q", [0.0, 50.0, 95.0, 98.0, 99.0, 100.0])
+def test_percentile_matches_numpy(uv, n, q):
+    rng = np.random.default_rng(n + int(q))
+    x = (rng.random(n, dtype=np.float32) ** 3) * 4.0 - 0.5  # mixed signs, skewed
+    got = uv.percentile(x, q)
+    want = float(np.percentile(x, q))
+    assert got == want, (n, q, got, want)
+
+
+def test_percentile_duplicates_and_constants(uv):
+    x = np.zeros(10000, np.float32)
+    x[9000:] = 1.0
+    for q in (50.0, 89.99, 90.0, 95.0):
+        assert uv.percentile(x, q) == float(np.percentile(x, q))
+    x = np.full(333, 0.25, np.float32)
+    assert uv.percentile(x, 95.0) == 0.25
+    x = np.round(np.random.default_rng(1).random(50000, dtype=np.float32) * 16) / 16  # heavy ties
+    for q in (5.0, 95.0, 99.0):
+        assert uv.percentile(x, q) == float(np.percentile(x, q))
+
+
+def test_spectral_integrate_vs_oracle(uv, oracle):
+    g = load_golden("uv_helpers")
+    cube, lam = g["cube31"], g["lam31"]
+    for i, (lo, hi) in enumerate(g["bp_bands"][:5].tolist()):
+        got = uv.integrate_band(cube, lam, lo, hi)
+        np.testing.assert_allclose(got, g["ib_31"][i], rtol=1e-5, atol=1e-7)
+    # K = 10 mantis bands on an 81-band cube, NHWC float32 and NCHW float16
+    rng = np.random.default_rng(3)
+    lam81 = np.linspace(300.0, 700.0, 81, dtype=np.float32)
+    cube81 = rng.random((40, 52, 81), dtype=np.float32)
+    Wk = np.stack([uv.bandpass_weights(lam81, lo, hi) for lo, hi in oracle.MANTIS_BANDS])
+    want = np.stack([oracle.integrate_band(cube81, lam81, lo, hi) for lo, hi in oracle.MANTIS_BANDS])
+    got, stats = uv.spectral_integrate(cube81, Wk, return_stats=True)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(stats[:, 0], want.reshape(10, -1).min(1), rtol=1e-5)
+    np.testing.assert_allclose(stats[:, 1], want.reshape(10, -1).max(1), rtol=1e-5)
+    np.testing.assert_allclose(stats[:, 2], want.reshape(10, -1).mean(1), rtol=1e-5)
+    chw16 = np.ascontiguousarray(cube81.transpose(2, 0, 1)).astype(np.float16)
+    got16 = uv.spectral_integrate(chw16, Wk, layout="nchw")
+    want16 = np.tensordot(chw16.astype(np.float32), Wk, axes=([0], [1])).transpose(2, 0, 1)
+    np.testing.assert_allclose(got16, want16, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("sigma", [0.2, 0.7, 1.0, 1.2, 3.0])
+@pytest.mark.parametrize("shape", [(36, 44), (5, 3), (70, 130, 3)])
+def test_gaussian_blur_bit_exact_with_shared_contract(uv, oracle, sigma, shape):
+    img = np.random.default_rng(int(sigma * 10) + len(shape)).random(shape, dtype=np.float32)
+    assert np.array_equal(uv.gaussian_blur(img, sigma), oracle.gaussian_blur(img, sigma))
+
+
+def test_safe_norm_and_von_kries_scaling(uv, oracle):
+    g = load_golden("uv_helpers")
+    U, B, G = g["U"], g["B"], g["G"]
+    assert np.array_equal(uv.safe_norm(U), g["safe_norm_U"])
+    assert np.array_equal(uv.safe_norm(np.full((4, 5), 0.25, np.float32)), g["safe_norm_const"])
+    planes = np.stack([U, B, G])
+    assert np.array_equal(uv.planes_blur(planes, 1, 0.0, scale="white_patch"), g["vk_wp"])
+    np.testing.assert_allclose(uv.planes_blur(planes, 1, 0.0, scale="gray_world"), g["vk_gw"], rtol=2e-6)
+
+
+def test_classic_rgb_to_hsi_vs_reference_golden(uv):
+    g = load_golden("lobes")
+    for nm in ("31", "81", "129"):
+        got = uv.classic_rgb_to_hsi(g["img"], wavelengths=g[f"lam{nm}"])
+        assert got.shape == g[f"hsi{nm}"].shape and got.dtype == np.float32
+        np.testing.assert_allclose(got, g[f"hsi{nm}"], rtol=1e-5, atol=1e-7)
+
+
+def test_honeybee_vs_reference_golden(uv):
+    """Outputs of the reference HoneyBee class (every mapping mode x adaptation)."""
+    from animal_vision_amd.animals import HoneyBee
+
+    g = load_golden("honeybee")
+    checked = 0
+    for key in g.files:
+        tail = key.rsplit("_", 1)[-1]
+        if tail not in ("s40", "n40") or key.startswith(("in_", "catches")):
+            continue
+        head = key[: -len(tail) - 1]
+        if head == "opponent_noblur":
+            bee = HoneyBee(blur_sigma_px=0.0)
+        else:
+            adapt = "white_patch" if head.endswith("white_patch") else "gray_world"
+            mode = head[: -len(adapt) - 1]
+            bee = HoneyBee(mapping_mode=mode, adaptation=adapt, custom_matrix=g["custom_matrix"] if mode == "custom_matrix" else None)
+        frame = g[f"in_{tail}"]
+        base, out = bee.visualize(frame)
+        assert base is frame and out.dtype == np.uint8 and out.shape == frame.shape
+        # 40x56 frames: allow a handful of +-1 codes
+        _u8_close(out, g[key], max_frac=5e-3)
+        checked += 1
+    assert checked >= 20
+
+
+def test_honeybee_planes_and_1080p_vs_oracle(uv, oracle):
+    from animal_vision_amd.animals import HoneyBee
+    from animal_vision_amd.synthetic import structured_frame
+
+    frame = structured_frame(0, 1080, 1920)
+    bee = HoneyBee()
+    out, planes = bee._operator()(frame, return_planes=True)
+    lam = np.linspace(400.0, 700.0, 31, dtype=np.float32)
+    hsi = oracle.classic_rgb_to_hsi_lobes(oracle.to_float01(frame), lam)
+    U, B, G = oracle.honeybee_catches(hsi, lam)
+    U, B, G = oracle.von_kries_white_patch(U, B, G)
+    want_planes = np.stack([oracle.gaussian_blur(p, 0.2) for p in (U, B, G)])
+    np.testing.assert_allclose(planes, want_planes, rtol=1e-4, atol=1e-6)
+    want, _ = oracle.honeybee_tail(*oracle.honeybee_catches(hsi, lam), np.uint8)
+    _u8_close(out, want)
+    # the HSI-cube source (what the MST++ route feeds) agrees with the folded-RGB source
+    out2 = bee._operator()(frame, hsi=hsi, hsi_layout="nhwc")
+    _u8_close(out2, want)
