@@ -89,3 +89,49 @@ def test_reference_module_names_importable():
         cls = getattr(m, n.capitalize())
         inst = cls()  # registry instantiates with no arguments (utils.py:91-130)
         assert hasattr(inst, "visualize")
+
+
+# ---- UV / spectral host tables (product code in animal_vision_amd/uv.py) vs reference goldens ----------
+def test_uv_host_tables_match_reference():
+    from animal_vision_amd import uv
+
+    g = load_golden("uv_helpers")
+    assert np.array_equal(uv.D65_like(g["lam31"]), g["d65_31"])
+    assert np.array_equal(uv.D65_like(g["lam81"]), g["d65_81"])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i, (lo, hi) in enumerate(g["bp_bands"].tolist()):
+            assert np.array_equal(uv.bandpass_weights(g["lam31"], lo, hi), g["bp_31"][i], equal_nan=True)
+            assert np.array_equal(uv.bandpass_weights(g["lam81"], lo, hi), g["bp_81"][i], equal_nan=True)
+    hb = load_golden("honeybee")
+    lam = np.linspace(400.0, 700.0, 31, dtype=np.float32)
+    assert np.array_equal(np.stack(uv.honeybee_cone_curves(lam)), hb["curves"])
+    assert [uv.uv_blur_ksize(s) for s in (0.2, 0.7, 1.0, 1.2, 3.0)] == [3, 7, 7, 9, 19]
+
+
+def test_folded_rgb_matrix_reproduces_reference_catches(oracle):
+    """K x 3 folded matrix (lobes x illuminant x cone curves) vs the reference's band-by-band catches."""
+    from animal_vision_amd import uv
+
+    hb = load_golden("honeybee")
+    lam = np.linspace(400.0, 700.0, 31, dtype=np.float32)
+    E = uv.D65_like(lam)
+    Wk = np.stack([E * c for c in uv.honeybee_cone_curves(lam)])
+    M = uv.fold_rgb_matrix(Wk, lam)
+    lin = oracle.uv_srgb_to_linear(oracle.to_float01(hb["in_s40"])).astype(np.float64)
+    got = np.tensordot(lin, M.astype(np.float64), axes=([2], [1])).transpose(2, 0, 1)
+    np.testing.assert_allclose(got, hb["catches_s40"], rtol=2e-6, atol=1e-9)  # tolerance: 1e-4 allowed, 2e-6 achieved
+    gains, denom = uv.lobe_tables(lam)
+    g2, d2 = oracle.lobe_tables(lam)
+    np.testing.assert_allclose(gains, g2, rtol=2e-7)
+    assert abs(denom - d2) < 3e-7
+
+
+def test_honeybee_constructor_surface():
+    from animal_vision_amd.animals import HoneyBee
+
+    bee = HoneyBee()
+    assert bee.mapping_mode == "opponent" and bee.adaptation == "white_patch" and bee.blur_sigma_px == 0.2
+    assert bee.lambdas.shape == (31,) and bee.lambdas.dtype == np.float32
+    assert bee.onnx_path.endswith("mst_plus_plus.onnx")
+    with pytest.raises(AssertionError):
+        bee.visualize(np.zeros((4, 4), np.uint8))
