@@ -71,6 +71,30 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "or `make -C animal-vision_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback."
     )
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as the one in
+    /opt/rocm that libavx.so is linked against); whichever loads first wins the SONAME, and if it is the
+    system copy, torch afterwards initialises a second runtime and reports "No HIP GPUs are available".
+    Loading torch's copy first (without importing torch) makes libavx.so and torch share it."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
+_preload_torch_hip_runtime()
 lib = ctypes.CDLL(LIB_PATH)
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -90,6 +114,7 @@ _SIGS = {
     "avx_stream_create": (_i, [_vp, ctypes.POINTER(_vp)]),
     "avx_stream_destroy": (_i, [_vp, _vp]),
     "avx_sync": (_i, [_vp, _vp]),
+    "avx_device_sync": (_i, [_vp]),
     "avx_timer_start": (_i, [_vp, _vp]),
     "avx_timer_stop": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "avx_dichromat_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(DichromatDesc), _vp]),

@@ -60,7 +60,6 @@ int avx_init(int device, avx_ctx** out_ctx) {
     hipDeviceProp_t prop;
     INIT_HIP(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    INIT_HIP(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
     INIT_HIP(hipEventCreate(&ctx->t0));
     INIT_HIP(hipEventCreate(&ctx->t1));
     INIT_HIP(hipMalloc((void**)&ctx->d_decode_lut, 256 * sizeof(float)));
@@ -125,7 +124,6 @@ void avx_destroy(avx_ctx* ctx) {
     if (ctx->uv_small) (void)hipFree(ctx->uv_small);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
-    if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
     delete ctx;
 }
 
@@ -198,12 +196,15 @@ int avx_stream_destroy(avx_ctx* ctx, void* stream) {
 
 int avx_sync(avx_ctx* ctx, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
-    if (stream)
-        AVX_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
-    else {
-        AVX_HIP(ctx, hipSetDevice(ctx->device));
-        AVX_HIP(ctx, hipDeviceSynchronize());
-    }
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    AVX_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return AVX_OK;
+}
+
+int avx_device_sync(avx_ctx* ctx) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    AVX_HIP(ctx, hipDeviceSynchronize());
     return AVX_OK;
 }
 

@@ -11,7 +11,6 @@
 
 struct avx_ctx {
     int device = 0;
-    hipStream_t compute = nullptr;  // used when the caller passes stream == NULL
     hipEvent_t t0 = nullptr, t1 = nullptr;
     char err[512] = {0};
     // constant tables (reference outputs, csrc/srgb_tables.h), resident for the ctx lifetime
@@ -51,6 +50,8 @@ int avx_ensure_scratch(avx_ctx* ctx, size_t bytes);
         if (!(cond)) return avx_fail((ctx), AVX_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// `stream` is a hipStream_t; NULL is HIP's null stream, exactly as in HIP (torch's default stream is 0).
 static inline hipStream_t avx_pick_stream(avx_ctx* ctx, void* stream) {
-    return stream ? (hipStream_t)stream : ctx->compute;
+    (void)ctx;
+    return (hipStream_t)stream;
 }

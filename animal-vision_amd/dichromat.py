@@ -141,7 +141,7 @@ class DichromatOp:
                 s_top, s_bottom, power, boost = self.spec.scone
                 self._gain = s_cone_row_gain(H, s_top, s_bottom, power=power, extra_boost=boost)
             self.desc.row_gain_host = self._gain.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-        ctx._check(lib.avx_dichromat_u8(ctx._h, d_in.ptr, d_out.ptr, n_frames, H, W, ctypes.byref(self.desc), stream))
+        ctx._check(lib.avx_dichromat_u8(ctx._h, d_in.ptr, d_out.ptr, n_frames, H, W, ctypes.byref(self.desc), ctx._s(stream)))
 
     def __call__(self, image: np.ndarray) -> np.ndarray:
         """uint8 HxWx3 (or NxHxWx3) host frame(s) -> same shape uint8, via upload/kernel/download."""

@@ -1,0 +1,211 @@
+"""MST++ (Cai et al., NTIRE 2022) inference module for PyTorch-ROCm.
+
+Same network, same state-dict keys as the reference's
+ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py (MS_MSA :88-139, FeedForward :141-158,
+MSAB :160-186, MST :188-268, MST_Plus_Plus :270-293; 227 tensors, 1,619,625 parameters), written
+inference-only and NHWC-first for MI355X instead of as a module tree:
+
+  * activations stay channels-last (N*H*W, C) so every 1x1 conv / Linear is one GEMM on a 2-D view;
+  * to_q/to_k/to_v run as ONE GEMM against the stacked (3C x C) weight (one pass over x, not three);
+  * spectral attention works on the d x d Gram matrix: L2-normalising q and k over all pixels
+    (F.normalize(dim=-1), :127-128) is folded into the 31x31 result as a division by the outer product
+    of column norms, so the normalised N x C tensors are never materialised;
+  * `attn @ v` followed by `proj` (:132-135) collapses to one GEMM: v @ M + b with
+    M = blockdiag(attn_h^T) @ W_proj^T (C x C), exact in real arithmetic;
+  * weights live in a flat dict under the reference's key names; `load_reference_state_dict` strips the
+    DataParallel 'module.' prefix like architecture/__init__.py:36-40.
+
+Half precision mirrors predict_torch.py:109 (fp16 autocast): GEMMs/convs in fp16, norms/softmax/
+LayerNorm statistics in fp32."""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+DIM = 31
+
+
+def _msab_keys(prefix: str, dim: int) -> Dict[str, tuple]:
+    a, f = f"{prefix}.blocks.0.0", f"{prefix}.blocks.0.1"
+    return {
+        f"{a}.to_q.weight": (dim, dim), f"{a}.to_k.weight": (dim, dim), f"{a}.to_v.weight": (dim, dim),
+        f"{a}.rescale": (dim // DIM, 1, 1), f"{a}.proj.weight": (dim, dim), f"{a}.proj.bias": (dim,),
+        f"{a}.pos_emb.0.weight": (dim, 1, 3, 3), f"{a}.pos_emb.2.weight": (dim, 1, 3, 3),
+        f"{f}.fn.net.0.weight": (4 * dim, dim, 1, 1), f"{f}.fn.net.2.weight": (4 * dim, 1, 3, 3),
+        f"{f}.fn.net.4.weight": (dim, 4 * dim, 1, 1), f"{f}.norm.weight": (dim,), f"{f}.norm.bias": (dim,),
+    }
+
+
+def reference_key_names(stage: int = 3) -> Dict[str, tuple]:
+    """name -> shape of every tensor in the reference's MST_Plus_Plus().state_dict()."""
+    keys: Dict[str, tuple] = {"conv_in.weight": (DIM, 3, 3, 3)}
+    for s in range(stage):
+        p = f"body.{s}"
+        keys[f"{p}.embedding.weight"] = (DIM, DIM, 3, 3)
+        d = DIM
+        for i in range(2):
+            keys.update(_msab_keys(f"{p}.encoder_layers.{i}.0", d))
+            keys[f"{p}.encoder_layers.{i}.1.weight"] = (2 * d, d, 4, 4)
+            d *= 2
+        keys.update(_msab_keys(f"{p}.bottleneck", d))
+        for i in range(2):
+            keys[f"{p}.decoder_layers.{i}.0.weight"] = (d, d // 2, 2, 2)
+            keys[f"{p}.decoder_layers.{i}.0.bias"] = (d // 2,)
+            keys[f"{p}.decoder_layers.{i}.1.weight"] = (d // 2, d, 1, 1)
+            keys.update(_msab_keys(f"{p}.decoder_layers.{i}.2", d // 2))
+            d //= 2
+        keys[f"{p}.mapping.weight"] = (DIM, DIM, 3, 3)
+    keys["conv_out.weight"] = (DIM, DIM, 3, 3)
+    return keys
+
+
+class MSTPlusPlus(torch.nn.Module):
+    def __init__(self, stage: int = 3):
+        super().__init__()
+        self.stage = stage
+        self._shapes = reference_key_names(stage)
+        self.w = torch.nn.ParameterDict({self._pk(k): torch.nn.Parameter(torch.zeros(s), requires_grad=False) for k, s in self._shapes.items()})
+        self._prepared: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def _pk(k: str) -> str:
+        return k.replace(".", "__")
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def load_reference_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> "MSTPlusPlus":
+        """Accepts the reference's checkpoint['state_dict'] (or a bare state_dict), 'module.' prefixes and all."""
+        if "state_dict" in sd and not any(k.endswith(".weight") for k in sd):
+            sd = sd["state_dict"]
+        sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in sd.items()}
+        missing = [k for k in self._shapes if k not in sd]
+        extra = [k for k in sd if k not in self._shapes]
+        if strict and (missing or extra):
+            raise KeyError(f"state_dict mismatch: missing {missing[:3]}..., unexpected {extra[:3]}...")
+        with torch.no_grad():
+            for k, shape in self._shapes.items():
+                if k in sd:
+                    t = torch.as_tensor(sd[k])
+                    if tuple(t.shape) != tuple(shape):
+                        raise ValueError(f"{k}: shape {tuple(t.shape)} != {shape}")
+                    self.w[self._pk(k)].copy_(t.to(self.w[self._pk(k)].dtype))
+        self._prepared.clear()
+        return self
+
+    def reference_state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: self.w[self._pk(k)].detach() for k in self._shapes}
+
+    def init_seeded(self, seed: int = 0) -> "MSTPlusPlus":
+        """Random weights (no checkpoint ships with the reference): N(0, 0.02) linears like
+        MST._init_weights (:231-238), unit LayerNorm, Kaiming-uniform-scale convs."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for k, shape in self._shapes.items():
+                p = self.w[self._pk(k)]
+                if k.endswith("norm.weight") or k.endswith("rescale"):
+                    p.fill_(1.0)
+                elif k.endswith("bias"):
+                    p.zero_()
+                elif len(shape) == 2:
+                    p.copy_(torch.randn(shape, generator=g) * 0.02)
+                else:
+                    fan_in = shape[1] * shape[2] * shape[3]
+                    bound = (1.0 / fan_in) ** 0.5
+                    p.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
+        self._prepared.clear()
+        return self
+
+    def _p(self, k: str) -> torch.Tensor:
+        return self.w[self._pk(k)]
+
+    def _prep(self, name: str, build):
+        """Derived weights (stacked QKV, 2-D views of 1x1 convs), cached per dtype/device."""
+        ref = self._p("conv_in.weight")
+        key = f"{name}|{ref.dtype}|{ref.device}"
+        t = self._prepared.get(key)
+        if t is None:
+            t = build()
+            self._prepared[key] = t
+        return t
+
+    # ---- blocks (x is NHWC) ------------------------------------------------------------------------
+    def _conv_nhwc(self, x: torch.Tensor, w: torch.Tensor, **kw) -> torch.Tensor:
+        y = F.conv2d(x.permute(0, 3, 1, 2), w, **kw)  # NCHW view of channels-last memory: no copy
+        return y.permute(0, 2, 3, 1)
+
+    def _ms_msa(self, x: torch.Tensor, p: str, heads: int) -> torch.Tensor:
+        b, h, w, c = x.shape
+        n = h * w
+        x2 = x.reshape(b, n, c)
+        wqkv = self._prep(p + ".qkv", lambda: torch.cat([self._p(p + ".to_q.weight"), self._p(p + ".to_k.weight"), self._p(p + ".to_v.weight")], 0).t().contiguous())
+        qkv = x2 @ wqkv  # (b, n, 3c): one GEMM, one pass over x
+        q, k, v = qkv[..., :c], qkv[..., c : 2 * c], qkv[..., 2 * c :]
+        d = c // heads
+        # Gram matrix per head over ALL pixels (the global contraction of :129), fp32 accumulate
+        qh = q.reshape(b, n, heads, d).permute(0, 2, 1, 3)  # (b, heads, n, d)
+        kh = k.reshape(b, n, heads, d).permute(0, 2, 1, 3)
+        gram = torch.matmul(kh.transpose(-2, -1), qh).float()  # (b, heads, d, d): [i][j] = k_i . q_j
+        nq = torch.linalg.vector_norm(q.float(), dim=1).reshape(b, heads, 1, d).clamp_min(1e-12)  # F.normalize eps
+        nk = torch.linalg.vector_norm(k.float(), dim=1).reshape(b, heads, d, 1).clamp_min(1e-12)
+        attn = gram / (nk * nq)
+        attn = attn * self._p(p + ".rescale").float().reshape(1, heads, 1, 1)
+        attn = attn.softmax(dim=-1)  # over j
+        # out_c = proj(concat_h(attn_h @ v_h)) == v @ M + bias,  M = blockdiag(attn_h^T) @ W_proj^T
+        wp = self._p(p + ".proj.weight")  # (c_out, c_in)
+        wp_h = wp.t().reshape(heads, d, c).float()  # rows of W_proj^T grouped by head: (heads, d, c)
+        M = torch.matmul(attn.transpose(-2, -1), wp_h.unsqueeze(0)).reshape(b, c, c).to(x.dtype)  # (b, c, c)
+        out_c = torch.baddbmm(self._p(p + ".proj.bias").to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
+        vi = v.reshape(b, h, w, c)
+        pe = self._conv_nhwc(vi, self._p(p + ".pos_emb.0.weight"), padding=1, groups=c)
+        pe = self._conv_nhwc(F.gelu(pe), self._p(p + ".pos_emb.2.weight"), padding=1, groups=c)
+        return out_c + pe
+
+    def _ffn(self, x: torch.Tensor, p: str) -> torch.Tensor:
+        b, h, w, c = x.shape
+        y = F.layer_norm(x.float(), (c,), self._p(p + ".norm.weight").float(), self._p(p + ".norm.bias").float()).to(x.dtype)
+        w1 = self._prep(p + ".w1", lambda: self._p(p + ".fn.net.0.weight").reshape(4 * c, c).t().contiguous())
+        w2 = self._prep(p + ".w2", lambda: self._p(p + ".fn.net.4.weight").reshape(c, 4 * c).t().contiguous())
+        y = F.gelu(y.reshape(b, h * w, c) @ w1).reshape(b, h, w, 4 * c)
+        y = F.gelu(self._conv_nhwc(y, self._p(p + ".fn.net.2.weight"), padding=1, groups=4 * c))
+        return (y.reshape(b, h * w, 4 * c) @ w2).reshape(b, h, w, c)
+
+    def _msab(self, x: torch.Tensor, p: str, heads: int) -> torch.Tensor:
+        x = self._ms_msa(x, p + ".blocks.0.0", heads) + x
+        return self._ffn(x, p + ".blocks.0.1") + x
+
+    def _mst(self, x: torch.Tensor, p: str) -> torch.Tensor:
+        fea = self._conv_nhwc(x, self._p(p + ".embedding.weight"), padding=1)
+        skips: List[torch.Tensor] = []
+        heads = 1
+        for i in range(2):
+            fea = self._msab(fea, f"{p}.encoder_layers.{i}.0", heads)
+            skips.append(fea)
+            fea = self._conv_nhwc(fea, self._p(f"{p}.encoder_layers.{i}.1.weight"), stride=2, padding=1)
+            heads *= 2
+        fea = self._msab(fea, p + ".bottleneck", heads)
+        for i in range(2):
+            up = F.conv_transpose2d(fea.permute(0, 3, 1, 2), self._p(f"{p}.decoder_layers.{i}.0.weight"),
+                                    self._p(f"{p}.decoder_layers.{i}.0.bias"), stride=2).permute(0, 2, 3, 1)
+            heads //= 2
+            cat = torch.cat([up, skips[1 - i]], dim=-1)
+            b, h, w, c2 = cat.shape
+            wf = self._prep(f"{p}.fuse{i}", lambda: self._p(f"{p}.decoder_layers.{i}.1.weight").reshape(c2 // 2, c2).t().contiguous())
+            fea = (cat.reshape(b, h * w, c2) @ wf).reshape(b, h, w, c2 // 2)
+            fea = self._msab(fea, f"{p}.decoder_layers.{i}.2", heads)
+        return self._conv_nhwc(fea, self._p(p + ".mapping.weight"), padding=1) + x
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (b, 3, H, W) in [0, 1] -> (b, 31, H, W).  Same pad-to-8 / crop as MST_Plus_Plus.forward :279-293."""
+        b, c, h_inp, w_inp = x.shape
+        pad_h, pad_w = (8 - h_inp % 8) % 8, (8 - w_inp % 8) % 8
+        if pad_h or pad_w:
+            x = F.pad(x, [0, pad_w, 0, pad_h], mode="reflect")
+        x = x.to(self._p("conv_in.weight").dtype).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)  # NHWC view
+        x = self._conv_nhwc(x, self._p("conv_in.weight"), padding=1)
+        hfe = x
+        for s in range(self.stage):
+            hfe = self._mst(hfe, f"body.{s}")
+        hfe = self._conv_nhwc(hfe, self._p("conv_out.weight"), padding=1) + x
+        return hfe.permute(0, 3, 1, 2)[:, :, :h_inp, :w_inp]

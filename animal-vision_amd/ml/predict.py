@@ -1,0 +1,110 @@
+"""Predictor harness around MSTPlusPlus: the semantics of the reference's
+ml/MST_plus_plus/predict_code/predict_torch.py (predict_rgb_to_hsi_torch :249-310): float01 ->
+reflect-pad H,W to a multiple of `stride` split on both sides (:171-183) -> NCHW -> model under fp16
+-> crop -> HxWx31 float32.  Full-frame only: MI355X has 288 GB of HBM, and MST++'s spectral attention
+contracts over every pixel of the frame, so the reference's OOM tile fallback (:199-235) is neither
+needed nor equivalent."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def to_float01(img: np.ndarray) -> np.ndarray:
+    """predict_torch.py:12-19."""
+    if np.issubdtype(img.dtype, np.integer):
+        return img.astype(np.float32) / 255.0
+    x = img.astype(np.float32)
+    if x.max() > 1.001:
+        x = np.clip(x / 255.0, 0.0, 1.0)
+    return x
+
+
+def pad_amounts(H: int, W: int, mult: int) -> Tuple[int, int, int, int]:
+    """(top, bottom, left, right) of predict_torch.py:22-34: total padding split floor/ceil."""
+    if mult is None or mult <= 0:
+        return 0, 0, 0, 0
+    Hn, Wn = ((H + mult - 1) // mult) * mult, ((W + mult - 1) // mult) * mult
+    py, px = Hn - H, Wn - W
+    return py // 2, py - py // 2, px // 2, px - px // 2
+
+
+def pad_to_multiple_reflect(x: np.ndarray, mult: int):
+    pads = pad_amounts(x.shape[0], x.shape[1], mult)
+    if pads == (0, 0, 0, 0):
+        return x, pads
+    t, b, l, r = pads
+    return np.pad(x, ((t, b), (l, r), (0, 0)), mode="reflect"), pads
+
+
+def crop_pads(x: np.ndarray, pads) -> np.ndarray:
+    """predict_torch.py:37-40."""
+    t, b, l, r = pads
+    H, W = x.shape[:2]
+    return x[t : H - b if b else H, l : W - r if r else W, :]
+
+
+class MSTPlusPlusPredictor:
+    """RGB frame -> 31-band cube on the GPU.  weights: None (seeded random init: no checkpoint ships with the
+    reference and there is no network), a path to a local .pth, or a state_dict."""
+
+    def __init__(self, weights=None, *, seed: int = 0, half: bool = True, stride: int = 16, device: Optional[str] = None):
+        import torch
+
+        from .mst_plus_plus import MSTPlusPlus
+
+        self.torch = torch
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device)
+        self.half = bool(half) and self.device.type == "cuda"
+        self.stride = stride
+        model = MSTPlusPlus()
+        if weights is None:
+            model.init_seeded(seed)
+        elif isinstance(weights, (str, bytes)):
+            model.load_reference_state_dict(torch.load(weights, map_location="cpu", weights_only=True), strict=False)
+        else:
+            model.load_reference_state_dict(weights)
+        self.model = model.to(self.device).eval()
+        if self.half:
+            self.model = self.model.half()
+
+    def predict_device(self, frame_dev):
+        """uint8 (H,W,3) torch tensor on the device -> (31, H, W) contiguous tensor (fp16 when half)."""
+        torch = self.torch
+        H, W, _ = frame_dev.shape
+        x = frame_dev.to(torch.float32).div_(255.0).permute(2, 0, 1).unsqueeze(0)  # 1x3xHxW
+        t, b, l, r = pad_amounts(H, W, self.stride)
+        if t or b or l or r:
+            x = torch.nn.functional.pad(x, [l, r, t, b], mode="reflect")
+        y = self.model(x.half() if self.half else x)
+        return y[0, :, t : t + H, l : l + W].contiguous()
+
+    def predict(self, image: np.ndarray) -> np.ndarray:
+        """predict_rgb_to_hsi_torch for one image: HxWx3 (uint8 or float) -> HxWx31 float32."""
+        torch = self.torch
+        x01, pads = pad_to_multiple_reflect(to_float01(image), self.stride)
+        xt = torch.from_numpy(np.ascontiguousarray(x01.transpose(2, 0, 1))[None]).to(self.device)
+        y = self.model(xt.half() if self.half else xt.float())
+        hsi = y[0].permute(1, 2, 0).float().cpu().numpy()
+        return crop_pads(hsi, pads).astype(np.float32, copy=False)
+
+    def honeybee(self, image: np.ndarray, op) -> np.ndarray:
+        """uint8 frame -> MST++ cube -> HoneybeeOp (csrc/uv.hip), the cube handed over on the device:
+        the (31,H,W) tensor's data_ptr goes straight into avx_honeybee_u8 on torch's current stream."""
+        torch = self.torch
+        if self.device.type != "cuda":
+            raise RuntimeError("MST++ -> libavx hand-off needs the GPU (no CPU path)")
+        from ..runtime import DeviceBuffer
+
+        H, W, _ = image.shape
+        frame = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)
+        cube = self.predict_device(frame)
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        ctx = op._ctx()
+        stream = torch.cuda.current_stream().cuda_stream
+        op.run_device(None, DeviceBuffer(ctx, out.data_ptr(), out.numel(), owned=False), 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=1,
+                      hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
+        return out.cpu().numpy()

@@ -74,6 +74,12 @@ class Context:
             raise AvxError(rc, lib.avx_last_error(None).decode())
         self._h = h.value
         self.device = int(device)
+        # The context's own stream: what every op uses when the caller names none.  (In the C ABI NULL is
+        # HIP's null stream, so that a torch default-stream handle of 0 means what torch means by it.)
+        self.stream = self.stream_create()
+
+    def _s(self, stream):
+        return self.stream if stream is None else stream
 
     # -- errors --------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -82,6 +88,9 @@ class Context:
 
     def close(self):
         if self._h:
+            if getattr(self, "stream", None):
+                lib.avx_stream_destroy(self._h, self.stream)
+                self.stream = None
             lib.avx_destroy(self._h)
             self._h = None
 
@@ -105,9 +114,8 @@ class Context:
         if dst is None:
             dst = self.malloc(a.nbytes)
         assert dst.nbytes >= a.nbytes
-        self._check(lib.avx_memcpy_h2d(self._h, dst.ptr, a.ctypes.data, a.nbytes, stream))
-        if stream is None or not getattr(arr, "_avx_pinned", False):
-            self.sync(stream)  # pageable source: do not let the caller free it under the copy
+        self._check(lib.avx_memcpy_h2d(self._h, dst.ptr, a.ctypes.data, a.nbytes, self._s(stream)))
+        self.sync(stream)  # pageable source: do not let the caller free it under the copy
         return dst
 
     def download(self, src: DeviceBuffer, shape, dtype, out: Optional[np.ndarray] = None, stream=None, sync=True) -> np.ndarray:
@@ -116,13 +124,13 @@ class Context:
             out = np.empty(shape, dtype)
         nbytes = int(np.prod(shape)) * dtype.itemsize
         assert out.nbytes >= nbytes and out.flags["C_CONTIGUOUS"] and src.nbytes >= nbytes
-        self._check(lib.avx_memcpy_d2h(self._h, out.ctypes.data, src.ptr, nbytes, stream))
+        self._check(lib.avx_memcpy_d2h(self._h, out.ctypes.data, src.ptr, nbytes, self._s(stream)))
         if sync:
             self.sync(stream)
         return out
 
     def memset(self, buf: DeviceBuffer, value: int, nbytes: Optional[int] = None, stream=None):
-        self._check(lib.avx_memset(self._h, buf.ptr, value, buf.nbytes if nbytes is None else nbytes, stream))
+        self._check(lib.avx_memset(self._h, buf.ptr, value, buf.nbytes if nbytes is None else nbytes, self._s(stream)))
 
     # -- streams / timing ----------------------------------------------------------------------
     def stream_create(self) -> int:
@@ -134,14 +142,17 @@ class Context:
         self._check(lib.avx_stream_destroy(self._h, s))
 
     def sync(self, stream=None):
-        self._check(lib.avx_sync(self._h, stream))
+        self._check(lib.avx_sync(self._h, self._s(stream)))
+
+    def device_sync(self):
+        self._check(lib.avx_device_sync(self._h))
 
     def timer_start(self, stream=None):
-        self._check(lib.avx_timer_start(self._h, stream))
+        self._check(lib.avx_timer_start(self._h, self._s(stream)))
 
     def timer_stop(self, stream=None) -> float:
         ms = ctypes.c_float()
-        self._check(lib.avx_timer_stop(self._h, stream, ctypes.byref(ms)))
+        self._check(lib.avx_timer_stop(self._h, self._s(stream), ctypes.byref(ms)))
         return float(ms.value)
 
 

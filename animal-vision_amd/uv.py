@@ -98,7 +98,7 @@ def percentile(x: np.ndarray, q: float, ctx: Optional[Context] = None) -> float:
     d = ctx.upload(a)
     out = ctypes.c_double()
     try:
-        ctx._check(lib.avx_percentile(ctx._h, d.ptr, a.size, float(q), ctypes.byref(out), None))
+        ctx._check(lib.avx_percentile(ctx._h, d.ptr, a.size, float(q), ctypes.byref(out), ctx.stream))
     finally:
         d.free()
     return float(out.value)
@@ -123,7 +123,7 @@ def spectral_integrate(hsi: np.ndarray, weights_kb: np.ndarray, *, layout: str =
     stats = np.empty((K, 4), np.float32)
     try:
         ctx._check(lib.avx_spectral_integrate(ctx._h, d_in.ptr, 0 if layout == "nhwc" else 1, 0 if cube.dtype == np.float32 else 1,
-                                              H, W, B, w.ctypes.data, K, d_out.ptr, stats.ctypes.data, None))
+                                              H, W, B, w.ctypes.data, K, d_out.ptr, stats.ctypes.data, ctx.stream))
         out = ctx.download(d_out, (K, H, W), np.float32)
     finally:
         d_in.free()
@@ -149,9 +149,9 @@ def planes_blur(planes: np.ndarray, ksize: int, sigma: float, *, scale: str = "n
     taps = gaussian_taps(ksize, sigma) if ksize > 1 else np.ones(1)
     try:
         if adapt:
-            ctx._check(lib.avx_plane_stats(ctx._h, d_in.ptr, K, H * W, adapt, float(eps), None, None))
+            ctx._check(lib.avx_plane_stats(ctx._h, d_in.ptr, K, H * W, adapt, float(eps), None, ctx.stream))
         ctx._check(lib.avx_planes_gaussian_blur(ctx._h, d_in.ptr, d_out.ptr, K, H, W, ksize, taps.ctypes.data,
-                                                {0: 0, 1: 1, 2: 1, 3: 3}[adapt], None))
+                                                {0: 0, 1: 1, 2: 1, 3: 3}[adapt], ctx.stream))
         out = ctx.download(d_out, a.shape, np.float32)
     finally:
         d_in.free()
@@ -195,7 +195,7 @@ def classic_rgb_to_hsi(frame: np.ndarray, *, wavelengths: np.ndarray = np.linspa
     d_in = ctx.upload(src)
     d_out = ctx.malloc(4 * H * W * B)
     try:
-        ctx._check(lib.avx_rgb_to_hsi_lobes(ctx._h, d_in.ptr, 1 if is_u8 else 0, H, W, B, gains.ctypes.data, float(denom), d_out.ptr, None))
+        ctx._check(lib.avx_rgb_to_hsi_lobes(ctx._h, d_in.ptr, 1 if is_u8 else 0, H, W, B, gains.ctypes.data, float(denom), d_out.ptr, ctx.stream))
         out = ctx.download(d_out, (H, W, B), np.float32)
     finally:
         d_in.free()
@@ -252,7 +252,7 @@ class HoneybeeOp:
         else:
             d.source, d.hsi = 0, None
         ctx._check(lib.avx_honeybee_u8(ctx._h, d_in.ptr if d_in else None, d_out.ptr, n_frames, H, W, ctypes.byref(d),
-                                       debug.ptr if debug else None, stream))
+                                       debug.ptr if debug else None, ctx._s(stream)))
 
     def __call__(self, image: np.ndarray, *, hsi: Optional[np.ndarray] = None, hsi_layout: str = "nhwc", return_planes: bool = False):
         if image.dtype != np.uint8:

@@ -11,8 +11,8 @@
  *     avx_last_error(ctx) returns a human-readable message for the last failure on that ctx;
  *   - an avx_ctx is bound to ONE device and is single-threaded (one caller at a time), matching the
  *     reference's one-frame-in-flight loop (main.py:60-72);
- *   - `stream` is a hipStream_t passed as void* (NULL = the ctx's own compute stream; a
- *     torch.cuda.Stream.cuda_stream value is accepted as is); every launch is asynchronous on it;
+ *   - `stream` is a hipStream_t passed as void*, with HIP's own meaning: NULL is the null (default) stream,
+ *     a torch.cuda.Stream.cuda_stream value is accepted as is; every launch is asynchronous on it;
  *   - frame/plane pointers are DEVICE pointers unless the parameter name ends in `_host`;
  *     the caller owns them; ctx owns only its scratch and its constant tables;
  *   - images are C-contiguous HWC (H x W x 3), batches are N such frames back to back.
@@ -56,7 +56,8 @@ int avx_memcpy_d2h(avx_ctx* ctx, void* dst_host, const void* src, size_t bytes, 
 int avx_memset(avx_ctx* ctx, void* dst, int value, size_t bytes, void* stream);
 int avx_stream_create(avx_ctx* ctx, void** out_stream);
 int avx_stream_destroy(avx_ctx* ctx, void* stream);
-int avx_sync(avx_ctx* ctx, void* stream);         /* stream == NULL: whole device */
+int avx_sync(avx_ctx* ctx, void* stream);         /* hipStreamSynchronize(stream) */
+int avx_device_sync(avx_ctx* ctx);                /* hipDeviceSynchronize() */
 
 /* HIP-event stopwatch ON `stream` (bench.py roofline leg: per-launch duration of the hot kernel). */
 int avx_timer_start(avx_ctx* ctx, void* stream);
