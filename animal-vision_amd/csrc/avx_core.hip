@@ -15,14 +15,38 @@ int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
-int avx_ensure_scratch(avx_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->scratch_cap) return AVX_OK;
-    if (ctx->d_scratch) AVX_HIP(ctx, hipFree(ctx->d_scratch));
-    ctx->d_scratch = nullptr;
-    ctx->scratch_cap = 0;
+avx_ws* avx_workspace(avx_ctx* ctx, hipStream_t stream) {
+    for (int i = 0; i < ctx->n_ws; ++i)
+        if (ctx->ws[i].used && ctx->ws[i].stream == stream) return &ctx->ws[i];
+    if (ctx->n_ws >= avx_ctx::kMaxWorkspaces) {
+        avx_fail(ctx, AVX_ERR_NOMEM, "more than %d distinct streams used with one context", avx_ctx::kMaxWorkspaces);
+        return nullptr;
+    }
+    avx_ws* w = &ctx->ws[ctx->n_ws++];
+    w->stream = stream;
+    w->used = true;
+    return w;
+}
+
+static void avx_ws_release(avx_ws* w) {
+    if (w->d_flags) (void)hipFree(w->d_flags);
+    if (w->d_row_gain) (void)hipFree(w->d_row_gain);
+    if (w->uv_small) (void)hipFree(w->uv_small);
+    if (w->d_scratch) (void)hipFree(w->d_scratch);
+    *w = avx_ws();
+}
+
+int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes) {
+    if (bytes <= ws->scratch_cap) return AVX_OK;
+    if (ws->d_scratch) {
+        AVX_HIP(ctx, hipStreamSynchronize(ws->stream));  // launches still reading the old arena
+        AVX_HIP(ctx, hipFree(ws->d_scratch));
+    }
+    ws->d_scratch = nullptr;
+    ws->scratch_cap = 0;
     size_t cap = bytes + bytes / 4;
-    AVX_HIP(ctx, hipMalloc(&ctx->d_scratch, cap));
-    ctx->scratch_cap = cap;
+    AVX_HIP(ctx, hipMalloc(&ws->d_scratch, cap));
+    ws->scratch_cap = cap;
     return AVX_OK;
 }
 
@@ -118,10 +142,7 @@ void avx_destroy(avx_ctx* ctx) {
     if (ctx->d_enc_thr_f64) (void)hipFree(ctx->d_enc_thr_f64);
     if (ctx->d_coarse_f32) (void)hipFree(ctx->d_coarse_f32);
     if (ctx->d_coarse_f64) (void)hipFree(ctx->d_coarse_f64);
-    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-    if (ctx->d_row_gain) (void)hipFree(ctx->d_row_gain);
-    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-    if (ctx->uv_small) (void)hipFree(ctx->uv_small);
+    for (int i = 0; i < ctx->n_ws; ++i) avx_ws_release(&ctx->ws[i]);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     delete ctx;
@@ -190,7 +211,18 @@ int avx_stream_create(avx_ctx* ctx, void** out_stream) {
 
 int avx_stream_destroy(avx_ctx* ctx, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
-    if (stream) AVX_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    if (stream) {
+        AVX_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+        for (int i = 0; i < ctx->n_ws; ++i)
+            if (ctx->ws[i].used && ctx->ws[i].stream == (hipStream_t)stream) {  // free its workspace, compact the table
+                avx_ws_release(&ctx->ws[i]);
+                ctx->ws[i] = ctx->ws[ctx->n_ws - 1];
+                ctx->ws[ctx->n_ws - 1] = avx_ws();
+                --ctx->n_ws;
+                break;
+            }
+        AVX_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    }
     return AVX_OK;
 }
 

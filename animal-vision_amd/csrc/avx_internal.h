@@ -9,6 +9,18 @@
 
 #include "../../include/avx.h"
 
+struct avx_ws {
+    hipStream_t stream = nullptr;
+    bool used = false;
+    uint32_t* d_flags = nullptr;     // per-frame "any byte > 1" flags
+    size_t flags_cap = 0;
+    float* d_row_gain = nullptr;     // per-row gains (AVX_POST_ROWGAIN)
+    size_t row_gain_cap = 0;
+    void* uv_small = nullptr;        // UV path: partial statistics, histogram, select state, percentiles
+    void* d_scratch = nullptr;       // scratch arena (UV path planes)
+    size_t scratch_cap = 0;
+};
+
 struct avx_ctx {
     int device = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -23,19 +35,18 @@ struct avx_ctx {
     uint32_t coarse_lo_key[2] = {0, 0};  // [0] f32 (bits >> 17), [1] f64 (bits >> 46)
     uint32_t coarse_n_keys[2] = {0, 0};
     int coarse_n_fix[2] = {0, 0};
-    // lazily grown scratch
-    uint32_t* d_flags = nullptr;     // per-frame "any byte > 1" flags
-    size_t flags_cap = 0;
-    float* d_row_gain = nullptr;     // per-row gains (AVX_POST_ROWGAIN)
-    size_t row_gain_cap = 0;
-    void* uv_small = nullptr;        // UV path: partial statistics, histogram, select state, percentiles
-    void* d_scratch = nullptr;       // general scratch arena (UV path planes)
-    size_t scratch_cap = 0;
+    // Per-stream workspaces: launches on different streams may be in flight together (pipeline.py keeps
+    // `depth` frames in flight), so anything a launch writes and a later kernel of the same launch reads
+    // is keyed by the stream it was enqueued on.
+    static constexpr int kMaxWorkspaces = 32;
+    avx_ws ws[kMaxWorkspaces];
+    int n_ws = 0;
     int num_cus = 256;
 };
 
 int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...);
-int avx_ensure_scratch(avx_ctx* ctx, size_t bytes);
+avx_ws* avx_workspace(avx_ctx* ctx, hipStream_t stream);  // find or create; NULL when all slots are taken
+int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes);
 
 #define AVX_HIP(ctx, call)                                                                          \
     do {                                                                                            \

@@ -540,8 +540,9 @@ int launch_tiled(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
         if constexpr ((R == 6 || R == 14 || R == 4) && TW == 64 && NT == 512) {
             auto kst = dichromat_tiled_kernel<T, COLOR, false, R, TW, TH, NT, NFIX, true>;
             AVX_HIP(ctx, hipFuncSetAttribute((const void*)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            AVX_HIP(ctx, avx_ensure_scratch(ctx, 64) == AVX_OK ? hipSuccess : hipErrorOutOfMemory);
-            a.stamps = (unsigned long long*)ctx->d_scratch;
+            avx_ws* wst = avx_workspace(ctx, s);
+            AVX_HIP(ctx, (wst && avx_ensure_scratch(ctx, wst, 64) == AVX_OK) ? hipSuccess : hipErrorOutOfMemory);
+            a.stamps = (unsigned long long*)wst->d_scratch;
             AVX_HIP(ctx, hipMemsetAsync(a.stamps, 0, 64, s));
             AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
             hipLaunchKernelGGL(kst, dim3(grid), dim3(NT), lds, s, a, taps, qc);
@@ -583,6 +584,8 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
     if (n_frames == 0) return AVX_OK;
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
     DichromatArgs a{};
     a.in = in_hwc;
     a.out = out_hwc;
@@ -598,26 +601,26 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
     }
     if (d->post_mode == AVX_POST_ROWGAIN) {
         AVX_REQUIRE(ctx, d->row_gain_host != nullptr, "avx_dichromat_u8: row_gain_host is NULL");
-        if ((size_t)H > ctx->row_gain_cap) {
-            if (ctx->d_row_gain) AVX_HIP(ctx, hipFree(ctx->d_row_gain));
-            ctx->d_row_gain = nullptr;
-            ctx->row_gain_cap = 0;
-            AVX_HIP(ctx, hipMalloc((void**)&ctx->d_row_gain, sizeof(float) * H));
-            ctx->row_gain_cap = H;
+        if ((size_t)H > ws->row_gain_cap) {
+            if (ws->d_row_gain) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_row_gain)); }
+            ws->d_row_gain = nullptr;
+            ws->row_gain_cap = 0;
+            AVX_HIP(ctx, hipMalloc((void**)&ws->d_row_gain, sizeof(float) * H));
+            ws->row_gain_cap = H;
         }
-        AVX_HIP(ctx, hipMemcpyAsync(ctx->d_row_gain, d->row_gain_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
-        a.row_gain = ctx->d_row_gain;
+        AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, d->row_gain_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
+        a.row_gain = ws->d_row_gain;
         a.row_gain_clamp = d->row_gain_clamp;
     }
-    if ((size_t)n_frames > ctx->flags_cap) {
-        if (ctx->d_flags) AVX_HIP(ctx, hipFree(ctx->d_flags));
-        ctx->d_flags = nullptr;
-        ctx->flags_cap = 0;
+    if ((size_t)n_frames > ws->flags_cap) {
+        if (ws->d_flags) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_flags)); }
+        ws->d_flags = nullptr;
+        ws->flags_cap = 0;
         size_t cap = (size_t)n_frames < 64 ? 64 : (size_t)n_frames;
-        AVX_HIP(ctx, hipMalloc((void**)&ctx->d_flags, sizeof(uint32_t) * cap));
-        ctx->flags_cap = cap;
+        AVX_HIP(ctx, hipMalloc((void**)&ws->d_flags, sizeof(uint32_t) * cap));
+        ws->flags_cap = cap;
     }
-    a.flags = ctx->d_flags;
+    a.flags = ws->d_flags;
     { const char* e = getenv("AVX_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     a.chroma_enable = d->chroma_enable;
     a.chroma_keep = d->chroma_keep;

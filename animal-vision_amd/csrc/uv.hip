@@ -482,13 +482,15 @@ struct UvScratch {
     Stat3* partials; float4* stats; uint32_t* hist; SelState* sel; double* pct; float* mat;
 };
 
-static int uv_small_scratch(avx_ctx* ctx, UvScratch* s) {
-    // fixed small block at the start of the arena
+static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_ws** out_ws = nullptr) {
+    avx_ws* ws = avx_workspace(ctx, stream);
+    if (!ws) return AVX_ERR_NOMEM;
+    if (out_ws) *out_ws = ws;
     const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + 2048 * 4 + sizeof(SelState) + 16 * 8 + 16 * 129 * 4 + 4096;
-    if (ctx->uv_small == nullptr) {
-        AVX_HIP(ctx, hipMalloc(&ctx->uv_small, need));
+    if (ws->uv_small == nullptr) {
+        AVX_HIP(ctx, hipMalloc(&ws->uv_small, need));
     }
-    char* p = (char*)ctx->uv_small;
+    char* p = (char*)ws->uv_small;
     s->partials = (Stat3*)p; p += (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3);
     s->stats = (float4*)p; p += 16 * sizeof(float4);
     s->hist = (uint32_t*)p; p += 2048 * 4;
@@ -530,7 +532,7 @@ int avx_percentile(avx_ctx* ctx, const float* data, size_t n, double q, double* 
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     UvScratch u;
-    int rc = uv_small_scratch(ctx, &u);
+    int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     rc = run_percentile(ctx, u, data, n, q, u.pct, s);
     if (rc) return rc;
@@ -548,7 +550,7 @@ int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype,
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     UvScratch u;
-    int rc = uv_small_scratch(ctx, &u);
+    int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     const size_t n = (size_t)H * W;
     AVX_HIP(ctx, hipMemcpyAsync(u.mat, weights_host, sizeof(float) * K * B, hipMemcpyHostToDevice, s));
@@ -574,7 +576,7 @@ int avx_planes_gaussian_blur(avx_ctx* ctx, const float* in, float* out, int K, i
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     UvScratch u;
-    int rc = uv_small_scratch(ctx, &u);
+    int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     BlurArgs a{};
     a.in = in; a.out = out; a.K = K; a.H = H; a.W = W; a.r = ksize / 2; a.stats = u.stats; a.scale_mode = scale_mode;
@@ -595,7 +597,7 @@ int avx_plane_stats(avx_ctx* ctx, const float* planes, int K, size_t n, int adap
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     UvScratch u;
-    int rc = uv_small_scratch(ctx, &u);
+    int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     const int g = grid_for(ctx, n);
     hipLaunchKernelGGL(k_plane_stats<16>, dim3(g), dim3(kT), 0, s, planes, n, K, u.partials);
@@ -615,7 +617,7 @@ int avx_rgb_to_hsi_lobes(avx_ctx* ctx, const void* in_hwc, int in_is_u8, int H, 
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     UvScratch u;
-    int rc = uv_small_scratch(ctx, &u);
+    int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     AVX_HIP(ctx, hipMemcpyAsync(u.mat, gains_host, sizeof(float) * 3 * B, hipMemcpyHostToDevice, s));
     const size_t n = (size_t)H * W;
@@ -639,12 +641,13 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     UvScratch u;
-    int rc = uv_small_scratch(ctx, &u);
+    avx_ws* ws = nullptr;
+    int rc = uv_small_scratch(ctx, s, &u, &ws);
     if (rc) return rc;
     const size_t n = (size_t)H * W;
-    rc = avx_ensure_scratch(ctx, sizeof(float) * n * 9 + 256);
+    rc = avx_ensure_scratch(ctx, ws, sizeof(float) * n * 9 + 256);
     if (rc) return rc;
-    float* raw = (float*)ctx->d_scratch;      // 3 planes: catches
+    float* raw = (float*)ws->d_scratch;       // 3 planes: catches
     float* ubg = raw + 3 * n;                 // 3 planes: adapted + blurred
     float* aux = ubg + 3 * n;                 // 3 planes: radius/L, or mixed
     const int g = grid_for(ctx, n);

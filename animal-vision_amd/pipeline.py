@@ -1,0 +1,161 @@
+"""The frame loop (reference: main.py:53-72 `video`, one frame in flight, synchronous) as a pipelined,
+sharded device loop.
+
+  * Sharding: frames are independent, so frame i belongs to rank i mod world (round-robin,
+    BASELINE.json config 4).  One process per GPU; NO collective on the data path.  torch.distributed
+    (RCCL over xGMI on the GPU box, gloo in CPU tests) carries only the start/stop barriers and the
+    reduction of per-rank statistics.
+  * Pipelining inside a rank: `depth` slots, each with its own HIP stream, pinned host buffers and HBM
+    buffers; a frame's H2D copy, kernels and D2H copy are enqueued in order on its slot's stream, so the
+    copies of frames i+1 / i-1 overlap the kernels of frame i (different streams), and the host only
+    blocks on a slot when it comes around again."""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+
+# ---------------------------------------------------------------- sharding (pure host logic) --------
+def shard_indices(n_frames: int, rank: int, world: int) -> List[int]:
+    """Global frame indices owned by `rank`: i mod world == rank."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(range(rank, n_frames, world))
+
+
+def owner_of(frame_index: int, world: int) -> int:
+    return frame_index % world
+
+
+def merge_in_order(per_rank: List[List[Tuple[int, object]]]) -> List[object]:
+    """Re-interleave per-rank (index, item) lists into stream order; checks every index appears once."""
+    flat = sorted((i, item) for lst in per_rank for i, item in lst)
+    idx = [i for i, _ in flat]
+    if idx != list(range(len(idx))):
+        raise ValueError("frame indices are not a permutation of 0..n-1")
+    return [item for _, item in flat]
+
+
+@dataclass
+class StreamStats:
+    frames: int = 0
+    pixels: int = 0
+    seconds: float = 0.0
+    ranks: int = 1
+
+    @property
+    def megapixels_per_second(self) -> float:
+        return self.pixels / 1e6 / self.seconds if self.seconds > 0 else 0.0
+
+
+def reduce_stats(local: StreamStats, dist=None) -> StreamStats:
+    """Whole-job statistics: frames and pixels summed over ranks, wall time = max over ranks."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    import torch
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    s = torch.tensor([float(local.frames), float(local.pixels)], dtype=torch.float64, device=dev)
+    t = torch.tensor([local.seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return StreamStats(int(s[0].item()), int(s[1].item()), float(t.item()), dist.get_world_size())
+
+
+# ---------------------------------------------------------------- device pipeline -------------------
+@dataclass
+class _Slot:
+    stream: int
+    h_in: object
+    h_out: object
+    d_in: object
+    d_out: object
+    index: int = -1
+    busy: bool = False
+
+
+class FramePipeline:
+    """Runs `op.run_device(d_in, d_out, 1, H, W, stream=...)` (DichromatOp / HoneybeeOp) over a stream of
+    uint8 frames with `depth` frames in flight."""
+
+    def __init__(self, op, H: int, W: int, *, ctx=None, depth: int = 3):
+        from .runtime import get_context
+
+        self.op, self.H, self.W, self.depth = op, H, W, depth
+        self.ctx = ctx or getattr(op, "ctx", None) or get_context()
+        if getattr(op, "ctx", None) is None:
+            op.ctx = self.ctx
+        nbytes = H * W * 3
+        self.slots = [
+            _Slot(self.ctx.stream_create(), self.ctx.pinned((H, W, 3), np.uint8), self.ctx.pinned((H, W, 3), np.uint8),
+                  self.ctx.malloc(nbytes), self.ctx.malloc(nbytes))
+            for _ in range(depth)
+        ]
+
+    def close(self):
+        for s in self.slots:
+            self.ctx.sync(s.stream)
+            self.ctx.stream_destroy(s.stream)
+            s.h_in.free(); s.h_out.free(); s.d_in.free(); s.d_out.free()
+        self.slots = []
+
+    def _retire(self, s: _Slot, emit: Callable[[int, np.ndarray], None]):
+        if s.busy:
+            self.ctx.sync(s.stream)
+            emit(s.index, s.h_out.array.copy())
+            s.busy = False
+
+    def run(self, frames: Iterator[Tuple[int, np.ndarray]], emit: Callable[[int, np.ndarray], None]) -> StreamStats:
+        """frames: (global index, HxWx3 uint8) pairs owned by this rank; emit(index, out) in submission order."""
+        from ._lib import lib
+
+        ctx, n, t0 = self.ctx, 0, time.perf_counter()
+        nbytes = self.H * self.W * 3
+        for k, (index, frame) in enumerate(frames):
+            s = self.slots[k % self.depth]
+            self._retire(s, emit)
+            if frame.shape != (self.H, self.W, 3) or frame.dtype != np.uint8:
+                raise ValueError(f"frame {index}: expected uint8 {(self.H, self.W, 3)}, got {frame.dtype} {frame.shape}")
+            s.h_in.array[...] = frame
+            ctx._check(lib.avx_memcpy_h2d(ctx._h, s.d_in.ptr, s.h_in.ptr, nbytes, s.stream))
+            self.op.run_device(s.d_in, s.d_out, 1, self.H, self.W, stream=s.stream)
+            ctx._check(lib.avx_memcpy_d2h(ctx._h, s.h_out.ptr, s.d_out.ptr, nbytes, s.stream))
+            s.index, s.busy = index, True
+            n += 1
+        for j in range(self.depth):  # drain in submission order
+            self._retire(self.slots[(n + j) % self.depth], emit)
+        return StreamStats(n, n * self.H * self.W, time.perf_counter() - t0)
+
+
+def run_video(animal_op, renderer, *, rank: int = 0, world: int = 1, depth: int = 3, split_compare: bool = False, dist=None) -> StreamStats:
+    """main.py:53-72 on the device: read -> visualize -> (split-compose) -> render, this rank's shard only."""
+    from .renderers.video import split_compose
+
+    first = renderer.get_image()
+    if first is None:
+        return reduce_stats(StreamStats(), dist)
+    H, W, _ = first.shape
+    pipe = FramePipeline(animal_op, H, W, depth=depth)
+    originals = {}
+
+    def frames():
+        i, f = 0, first
+        while f is not None:
+            if owner_of(i, world) == rank:
+                if split_compare:
+                    originals[i] = f
+                yield i, f
+            i += 1
+            f = renderer.get_image()
+
+    def emit(i, out):
+        renderer.render(split_compose(originals.pop(i), out) if split_compare else out)
+
+    try:
+        stats = pipe.run(frames(), emit)
+    finally:
+        pipe.close()
+    return reduce_stats(stats, dist)

@@ -1,0 +1,54 @@
+"""GPU: the pipelined frame loop (depth-3 slots, one HIP stream each, pinned staging) returns exactly what the
+one-frame-at-a-time species call returns, in stream order, for this rank's round-robin shard."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_video_matches_per_frame_visualize(tmp_path):
+    from animal_vision_amd.animals import Dog, HoneyBee
+    from animal_vision_amd.dichromat import DichromatOp
+    from animal_vision_amd.pipeline import run_video
+    from animal_vision_amd.renderers import VideoRenderer
+
+    for species, op in ((Dog(), DichromatOp(Dog.SPEC)), (HoneyBee(), HoneyBee()._operator())):
+        for world, rank in ((1, 0), (2, 1)):
+            path = str(tmp_path / f"o_{type(species).__name__}_{world}_{rank}.npy")
+            vr = VideoRenderer(read_path="synthetic:160x96:9:structured", write_path=path)
+            vr.open()
+            stats = run_video(op, vr, rank=rank, world=world, depth=3)
+            vr.close()
+            src = VideoRenderer(read_path="synthetic:160x96:9:structured")
+            src.open()
+            want = []
+            i = 0
+            while True:
+                f = src.get_image()
+                if f is None:
+                    break
+                if i % world == rank:
+                    want.append(species.visualize(f)[1])
+                i += 1
+            got = np.load(path)
+            assert stats.frames == len(want) == got.shape[0]
+            assert np.array_equal(got, np.stack(want))
+
+
+def test_split_compare_stream(tmp_path):
+    from animal_vision_amd.animals import Wolf
+    from animal_vision_amd.dichromat import DichromatOp
+    from animal_vision_amd.pipeline import run_video
+    from animal_vision_amd.renderers import VideoRenderer, split_compose
+    from animal_vision_amd.synthetic import SyntheticVideoSource
+
+    path = str(tmp_path / "split.npy")
+    vr = VideoRenderer(read_path="synthetic:128x64:4", write_path=path)
+    vr.open()
+    run_video(DichromatOp(Wolf.SPEC), vr, split_compare=True)
+    vr.close()
+    got = np.load(path)
+    src = SyntheticVideoSource(64, 128, 4)
+    for k in range(4):
+        f = src.get_image()
+        assert np.array_equal(got[k], split_compose(f, Wolf().visualize(f)[1]))
