@@ -214,6 +214,18 @@ def main():
             else:
                 result["parity_checked"] = bool(np.array_equal(got[0], want))
 
+    if mst is None and rank == 0 and world == 1:
+        # PCIe-inclusive leg (never `value`): the same op through pipeline.FramePipeline, host frames in, host frames out.
+        from animal_vision_amd.pipeline import FramePipeline
+
+        n_e2e = 48 if H <= 1080 else 16
+        pipe = FramePipeline(op, H, W, ctx=ctx, depth=3)
+        sink = []
+        pipe.run(((i, pool[i % len(pool)]) for i in range(4)), lambda i, o: None)  # warm
+        st = pipe.run(((i, pool[i % len(pool)]) for i in range(n_e2e)), lambda i, o: sink.append(i))
+        pipe.close()
+        result["e2e_pcie"] = {"value": round(st.megapixels_per_second, 1), "unit": "MP/s", "frames": n_e2e,
+                              "note": "pageable numpy frame -> pinned -> H2D -> kernels -> D2H -> numpy copy, 3 frames in flight, 1 host thread"}
     if mst is None:
         ctx.stream_destroy(stream)
     if rank == 0:
