@@ -650,9 +650,9 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
         a.one_minus_alpha = d->cat_beta;
         a.enc_thr = ctx->d_enc_thr_f64;
     }
-    // auto: the marching strip kernel for the float32 species; the 2-D tiled kernel for the float64 cat
-    // tail (A/B on MI355X: 50-51 vs 43-51 GP/s); explicit variants are honoured as asked.
-    if (try_march && !(cat && variant == 0)) {
+    // auto: the marching strip kernel wherever an instantiation exists (it beats the 2-D tiled kernel for
+    // every species measured); explicit variants are honoured as asked.
+    if (try_march) {
         const int rc = avx_launch_dichromat_march(ctx, a, d, cat, s);
         if (rc != AVX_ERR_UNSUPPORTED) return rc;
     }

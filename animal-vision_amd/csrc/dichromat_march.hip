@@ -23,8 +23,7 @@ using namespace avxk;
 
 namespace {
 
-constexpr int kMarchThreads = 384;
-constexpr int kGroups = 128;  // column groups per strip
+// Workgroup = NG column groups x 3 channels (NG a multiple of 64 keeps the channel wave-uniform).
 
 struct MarchGeom {
     int nstrips, sw;   // strips per frame row, nominal strip width (multiple of XPT)
@@ -38,8 +37,10 @@ template <> struct VecN<float, 2> { using type = float2; };
 template <> struct VecN<double, 2> { using type = double2; };
 template <> struct VecN<double, 1> { using type = double; };
 
-template <typename T, int R, int SY, int XPT_>
+template <typename T, int R, int SY, int XPT_, int NG>
 struct MarchCfg {
+    static constexpr int kMarchThreads = 3 * NG;
+    static constexpr int kGroups = NG;
     static constexpr int XPT = XPT_;                          // columns per thread = one LDS vector read
     static constexpr int SW = XPT * kGroups;
     static constexpr int AWS = SW + 2 * R;
@@ -57,9 +58,13 @@ struct MarchCfg {
     static constexpr size_t off_coarse = off_lut + 256 * sizeof(float);
     static constexpr size_t off_ktab = off_coarse + 1024;
     static constexpr size_t off_A = off_ktab + 64 * sizeof(T);
-    static constexpr size_t off_raw = off_A + (size_t)SY * 3 * PA * sizeof(T) + 64;
-    static constexpr size_t off_out = off_raw + (size_t)SY * RAWP;
-    static constexpr size_t lds_bytes = ((off_out + (size_t)SY * OUTP + 15) / 16) * 16;
+    // Every row buffer exists twice: one barrier per iteration (see the main loop).
+    static constexpr size_t A_bytes = (size_t)SY * 3 * PA * sizeof(T) + 64;
+    static constexpr size_t raw_bytes = (size_t)SY * RAWP;
+    static constexpr size_t out_bytes = (size_t)SY * OUTP;
+    static constexpr size_t off_raw = off_A + 2 * A_bytes;
+    static constexpr size_t off_out = off_raw + 2 * raw_bytes;
+    static constexpr size_t lds_bytes = ((off_out + 2 * out_bytes + 15) / 16) * 16;
     static_assert(3 * R <= RAW_LEAD, "raw lead-in too small for this radius");
     static_assert(lds_bytes <= 160 * 1024, "does not fit LDS");
 };
@@ -78,9 +83,13 @@ template <> struct Pair<double> { typedef double type __attribute__((ext_vector_
 // scalar instructions.  Each half is the same IEEE operation as the scalar contract.
 template <typename P> __device__ __forceinline__ P pfma(P a, P b, P c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <typename T, int COLOR, bool DARK, int R, int SY, int XPT_, int MINW, int NFIX>
-__global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(DichromatArgs a, Taps<T> taps, QuantCoarse qc, MarchGeom g) {
-    using C = MarchCfg<T, R, SY, XPT_>;
+// STAMP = true is a DIAGNOSTIC instantiation (AVX_STAMPS=1): tid 0 accumulates s_memtime deltas per section
+// into a.stamps (never into an output); its run time is not representative.
+template <typename T, int COLOR, bool DARK, int R, int SY, int XPT_, int NG, int MINW, int NFIX, bool STAMP = false>
+__global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(DichromatArgs a, Taps<T> taps, QuantCoarse qc, MarchGeom g) {
+    using C = MarchCfg<T, R, SY, XPT_, NG>;
+    constexpr int kMarchThreads = C::kMarchThreads;
+    constexpr int kGroups = C::kGroups;
     using P = typename Pair<T>::type;
     constexpr int XPT = C::XPT;
     constexpr int NWAVES = kMarchThreads / 64;
@@ -90,9 +99,10 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
     float* lut = reinterpret_cast<float*>(smem_raw + C::off_lut);
     uint8_t* coarse = smem_raw + C::off_coarse;
     T* ktab = reinterpret_cast<T*>(smem_raw + C::off_ktab);
-    P* A = reinterpret_cast<P*>(smem_raw + C::off_A);      // [SY/2][3][PA] of {row 2k, row 2k+1}
-    uint8_t* RAW = smem_raw + C::off_raw;                   // [SY][RAWP]
-    uint8_t* OUT = smem_raw + C::off_out;                   // [SY][OUTP]
+    // double-buffered by iteration parity: A [SY/2][3][PA] of {row 2k, row 2k+1}; RAW [SY][RAWP]; OUT [SY][OUTP]
+    auto A_of = [&](int t) { return reinterpret_cast<P*>(smem_raw + C::off_A + (size_t)(t & 1) * C::A_bytes); };
+    auto RAW_of = [&](int t) { return smem_raw + C::off_raw + (size_t)(t & 1) * C::raw_bytes; };
+    auto OUT_of = [&](int t) { return smem_raw + C::off_out + (size_t)(t & 1) * C::out_bytes; };
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bookkeeping on the SALU
@@ -137,36 +147,53 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
     // ---- raw row loads: (row, 64-dword segment) units dealt to waves; row math is scalar ---------
     constexpr int NSEG = (C::DPR + 63) / 64;
     constexpr int NLD = (SY * NSEG + NWAVES - 1) / NWAVES;
+    // aligned dwords that contain a valid byte never cross the end of the batch when the batch size is a
+    // multiple of 4 bytes (every standard video size): no tail guard needed then (uniform for the launch)
+    const bool tail_safe = (((frame_bytes * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) == 0;
+    uint8_t* rowshift = smem_raw + C::off_ktab + 48 * sizeof(T);  // [2][SY] raw-row misalignments, by iteration parity
     auto row_base = [&](int t, int s, uint32_t& shift) -> const uint8_t* {
-        const int gy = reflect101(ys - R + t * SY + s, a.H);
+        int y = ys - R + t * SY + s;
+        const int gy = (unsigned)y < (unsigned)a.H ? y : reflect101(y, a.H);
         const uint8_t* rowp = fin + ((size_t)gy * a.W + gx0) * 3;
         shift = (uint32_t)((uintptr_t)rowp & 3u);
         return rowp - shift;
     };
+    // Straight-line issue: no branch between two loads, so all NLD loads are in flight together (a guarded
+    // bytewise path inside the loop made hipcc put s_waitcnt vmcnt(0) after every load and serialise them).
     auto issue_raw_loads = [&](int t, uint32_t (&rv)[NLD]) {
+        const uint8_t* ptr[NLD];
+        bool ok[NLD];
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
             const int u = wave + n * NWAVES;            // uniform
             const int s = u / NSEG, seg = u - s * NSEG; // uniform
-            uint32_t v = 0;
-            if (s < SY) {
+            uint32_t shift;
+            const uint8_t* base = row_base(t, s < SY ? s : 0, shift);
+            const int d = seg * 64 + lane;
+            ptr[n] = base + (size_t)d * 4;
+            ok[n] = s < SY && d * 4 < (int)shift + row_bytes && (tail_safe || ptr[n] + 4 <= in_end);
+        }
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) rv[n] = ok[n] ? *reinterpret_cast<const uint32_t*>(ptr[n]) : 0u;
+        if (!tail_safe) {  // the one dword that straddles the end of the batch: assemble its valid bytes
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) {
+                const int u = wave + n * NWAVES;
+                const int s = u / NSEG, seg = u - s * NSEG;
                 uint32_t shift;
-                const uint8_t* base = row_base(t, s, shift);
+                (void)row_base(t, s < SY ? s : 0, shift);
                 const int d = seg * 64 + lane;
-                if (d * 4 < (int)shift + row_bytes) {
-                    const uint8_t* p = base + (size_t)d * 4;
-                    if (p + 4 <= in_end) {
-                        v = *reinterpret_cast<const uint32_t*>(p);
-                    } else {  // last dword of the whole batch: do not read past the allocation
-                        for (int bb = 0; bb < 4; ++bb)
-                            if (p + bb < in_end) v |= (uint32_t)p[bb] << (8 * bb);
-                    }
+                if (s < SY && d * 4 < (int)shift + row_bytes && ptr[n] + 4 > in_end) {
+                    uint32_t v = 0;
+                    for (int bb = 0; bb < 4; ++bb)
+                        if (ptr[n] + bb < in_end) v |= (uint32_t)ptr[n][bb] << (8 * bb);
+                    rv[n] = v;
                 }
             }
-            rv[n] = v;
         }
     };
     auto write_raw = [&](int t, const uint32_t (&rv)[NLD]) {
+        uint8_t* RAW = RAW_of(t);
         uint32_t seen = 0;
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
@@ -174,15 +201,20 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
             const int s = u / NSEG, seg = u - s * NSEG;
             if (s < SY) {
                 const int d = seg * 64 + lane;
+                uint32_t shift;
+                (void)row_base(t, s, shift);                      // scalar
+                if (seg == 0 && lane == 0) rowshift[(t & 1) * SY + s] = (uint8_t)shift;
                 if (d < C::DPR) {
                     *reinterpret_cast<uint32_t*>(RAW + (size_t)s * C::RAWP + C::RAW_LEAD + d * 4) = rv[n];
                     if (!DARK) {
-                        uint32_t shift;
-                        (void)row_base(t, s, shift);
-                        const int b0 = d * 4 - (int)shift;  // row byte index of this dword's byte 0
-                        uint32_t m = 0xfefefefeu;           // "byte > 1" detector, masked to the row's own bytes
-                        if (b0 < 0) m &= 0xffffffffu << (8 * (-b0));
-                        if (b0 + 4 > row_bytes) m &= b0 >= row_bytes ? 0u : 0xffffffffu >> (8 * (b0 + 4 - row_bytes));
+                        // "byte > 1" detector, masked to the row's own bytes: only the first and the last dword
+                        // of a row hold foreign bytes (<= 3 before / after it)
+                        const int last = ((int)shift + row_bytes - 1) >> 2;                        // scalar
+                        const uint32_t mlo = 0xfefefefeu << (8 * shift);                           // scalar
+                        const uint32_t mhi = 0xfefefefeu >> (8 * (3 - (((int)shift + row_bytes - 1) & 3)));
+                        uint32_t m = d > last ? 0u : 0xfefefefeu;
+                        m = d == 0 ? (m & mlo) : m;
+                        m = d == last ? (m & mhi) : m;
                         seen |= rv[n] & m;
                     }
                 }
@@ -198,6 +230,7 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
     const uintptr_t pitch = (uintptr_t)a.W * 3;
     const int gran = (((o0 | pitch | (uintptr_t)nbytes) & 15u) == 0) ? 16 : ((((o0 | pitch | (uintptr_t)nbytes) & 3u) == 0) ? 4 : 1);
     auto store_out = [&](int t) {
+        const uint8_t* OUT = OUT_of(t);
         const int per_row = nbytes / gran;
 #pragma unroll 1
         for (int v = tid; v < SY * per_row; v += kMarchThreads) {
@@ -221,16 +254,12 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
 
     const int n_iter = (ch + 2 * R + SY - 1) / SY;
     uint32_t rv[NLD];
-    issue_raw_loads(0, rv);
-#pragma unroll 1
-    for (int t = 0; t < n_iter; ++t) {
-        // ---- S1: previous outputs -> HBM, raw rows -> LDS, next raw rows -> registers ------------
-        if (t > 0 && !(a.ablate & 32)) store_out(t - 1);
-        if (!(a.ablate & 16)) write_raw(t, rv);
-        if (t + 1 < n_iter && !(a.ablate & 16)) issue_raw_loads(t + 1, rv);
-        __syncthreads();
-        // ---- S2: decode.  One item = 4 pixels x 2 rows: raw bytes -> decode table -> colour chain on
-        //      {row a, row b} pairs -> A in the row-paired layout the row pass reads. -----------------
+
+    // decode iteration t's raw rows (RAW_of(t)) into A_of(t).  One item = 4 pixels x 2 rows: raw bytes ->
+    // decode table -> colour chain on {row a, row b} pairs -> the row-paired layout the row pass reads.
+    auto decode = [&](int t) {
+        const uint8_t* RAW = RAW_of(t);
+        P* A = A_of(t);
 #pragma unroll 1
         for (int item = (a.ablate & 1) ? (1 << 30) : tid; item < (SY / 2) * C::NG4; item += kMarchThreads) {
             const int sp = item / C::NG4, q4 = item - sp * C::NG4;
@@ -239,8 +268,7 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int s = 2 * sp + h;
-                uint32_t shift;
-                (void)row_base(t, s, shift);
+                const uint32_t shift = rowshift[(t & 1) * SY + s];
                 const int boff = C::RAW_LEAD + (int)shift - 3 * lead + 12 * q4;  // LDS byte offset of pixel lx = 4*q4
                 const uint32_t* dw = reinterpret_cast<const uint32_t*>(RAW + (size_t)s * C::RAWP + (boff & ~3));
                 const uint32_t sh = (uint32_t)boff & 3u;
@@ -302,9 +330,12 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
                 A[(size_t)pl * C::PA + lx] = A[(size_t)pl * C::PA + src];
             }
         }
-        __syncthreads();
-        // ---- S3: row pass for the SY new rows (two rows per packed op), then the column pass and the
-        //      quantiser from the register windows (two columns per packed op). ----------------------
+    };
+    // row pass for the SY new rows of iteration t (two rows per packed op), then the column pass and the
+    // quantiser from the register windows (two columns per packed op) -> OUT_of(t).
+    auto compute = [&](int t) {
+        const P* A = A_of(t);
+        uint8_t* OUT = OUT_of(t);
         if (col_active) {
 #pragma unroll
             for (int xp = 0; xp < XPT / 2; ++xp)
@@ -351,19 +382,67 @@ __global__ __launch_bounds__(kMarchThreads, MINW) void dichromat_march_kernel(Di
                 }
             }
         }
+    };
+
+    // Software pipeline, ONE barrier per iteration.  In interval t the workgroup stores the outputs of t-1,
+    // stages the raw rows of t+2 (already in registers) and fetches those of t+3, decodes t+1 and computes t:
+    // all on different buffers (parity double-buffering), so nothing inside an interval needs ordering.
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (slot >= 0) st_acc[slot] += now - st_t;
+            st_t = now;
+        }
+    };
+    issue_raw_loads(0, rv);
+    write_raw(0, rv);
+    if (n_iter > 1) issue_raw_loads(1, rv);
+    __syncthreads();
+    decode(0);
+    if (n_iter > 1) {
+        write_raw(1, rv);
+        if (n_iter > 2) issue_raw_loads(2, rv);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < n_iter; ++t) {
+        stamp(-1);
+        // raw staging first: its s_waitcnt vmcnt covers only the loads issued one interval ago (vmcnt counts
+        // stores too, in order: behind store_out it would also wait for those stores to retire)
+        if (t + 2 < n_iter) {
+            write_raw(t + 2, rv);
+            stamp(1);
+            if (t + 3 < n_iter) issue_raw_loads(t + 3, rv);
+        }
+        stamp(2);
+        if (t + 1 < n_iter) decode(t + 1);
+        stamp(3);
+        compute(t);
+        stamp(4);
+        if (t > 0 && !(a.ablate & 32)) store_out(t - 1);
+        stamp(0);
         __syncthreads();
+        stamp(5);
     }
     store_out(n_iter - 1);
+    if constexpr (STAMP) {
+        if (tid == 0 && a.stamps) {
+            for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_acc[i]);
+            atomicAdd(a.stamps + 6, (unsigned long long)n_iter);
+        }
+    }
 }
 
-template <typename T, int COLOR, int R, int SY, int XPT, int MINW, int NFIX>
+template <typename T, int COLOR, int R, int SY, int XPT, int NG, int MINW, int NFIX>
 int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, const QuantCoarse& qc, hipStream_t s) {
-    using C = MarchCfg<T, R, SY, XPT>;
+    using C = MarchCfg<T, R, SY, XPT, NG>;
+    constexpr int kMarchThreads = C::kMarchThreads;
     Taps<T> taps;
     for (int i = 0; i < AVX_MAX_KSIZE; ++i) taps.k[i] = (T)0;
     for (int i = 0; i < d->ksize; ++i) taps.k[i] = (T)d->taps_host[i];
-    auto kmain = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, MINW, NFIX>;
-    auto kdark = dichromat_march_kernel<T, COLOR, true, R, SY, XPT, MINW, NFIX>;
+    auto kmain = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, NG, MINW, NFIX>;
+    auto kdark = dichromat_march_kernel<T, COLOR, true, R, SY, XPT, NG, MINW, NFIX>;
     const size_t lds = C::lds_bytes;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kmain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kdark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -388,6 +467,27 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
     const long total = cols * g.nchunks;
     AVX_REQUIRE(ctx, total < (1L << 30), "avx_dichromat_u8: too many workgroups");
     g.xcd_remap = (total % 8 == 0) ? 1 : 0;
+    if (getenv("AVX_STAMPS")) {
+        if constexpr (R == 6 || R == 14) {
+            auto kst = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, NG, MINW, NFIX, true>;
+            AVX_HIP(ctx, hipFuncSetAttribute((const void*)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            avx_ws* wst = avx_workspace(ctx, s);
+            AVX_HIP(ctx, (wst && avx_ensure_scratch(ctx, wst, 64) == AVX_OK) ? hipSuccess : hipErrorOutOfMemory);
+            a.stamps = (unsigned long long*)wst->d_scratch;
+            AVX_HIP(ctx, hipMemsetAsync(a.stamps, 0, 64, s));
+            AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
+            hipLaunchKernelGGL(kst, dim3((unsigned)total), dim3(kMarchThreads), lds, s, a, taps, qc, g);
+            unsigned long long h[8];
+            AVX_HIP(ctx, hipMemcpyAsync(h, a.stamps, 64, hipMemcpyDeviceToHost, s));
+            AVX_HIP(ctx, hipStreamSynchronize(s));
+            double tot = 0;
+            for (int i = 0; i < 6; ++i) tot += (double)h[i];
+            const double per = tot > 0 ? 100.0 / tot : 0, it = (double)h[6] > 0 ? (double)h[6] : 1;
+            fprintf(stderr, "[avx march stamps R=%d XPT=%d blocks=%ld per_cu=%d ch=%d] cycles/iteration (wave 0) %.0f | store %.1f%% raw->LDS %.1f%% issue loads %.1f%% decode %.1f%% row+col+quant %.1f%% barrier %.1f%%\n",
+                    R, XPT, total, per_cu, g.ch, tot / it, h[0] * per, h[1] * per, h[2] * per, h[3] * per, h[4] * per, h[5] * per);
+            a.stamps = nullptr;
+        }
+    }
     AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
     hipLaunchKernelGGL(kmain, dim3((unsigned)total), dim3(kMarchThreads), lds, s, a, taps, qc, g);
     AVX_HIP(ctx, hipGetLastError());
@@ -402,17 +502,25 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
 
 int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, hipStream_t s) {
     constexpr int NF = 2;
+    // 192-thread workgroups (5 per CU) for the float64 cat tail, 384-thread ones for float32 (A/B on MI355X:
+    // cat 70 vs 52-56 GP/s, wolf 94 vs 104); AVX_MARCH_NG=64|128 overrides for tuning.
+    bool ng64 = f64_cat;
+    { const char* e = getenv("AVX_MARCH_NG"); if (e && *e) ng64 = atoi(e) == 64; }
     const int w = f64_cat ? 1 : 0;
     AVX_REQUIRE(ctx, ctx->coarse_n_fix[w] <= NF, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[w], NF);
     QuantCoarse qc{f64_cat ? ctx->d_coarse_f64 : ctx->d_coarse_f32, ctx->coarse_lo_key[w], ctx->coarse_n_keys[w], ctx->coarse_n_fix[w]};
     if (f64_cat) {
-        if (a.r == 4) return launch_march<double, AVX_COLOR_CAT_MERGE, 4, 4, 2, 3, NF>(ctx, a, d, qc, s);
+        if (a.r == 4) return ng64 ? launch_march<double, AVX_COLOR_CAT_MERGE, 4, 4, 2, 64, 3, NF>(ctx, a, d, qc, s)
+                                  : launch_march<double, AVX_COLOR_CAT_MERGE, 4, 4, 2, 128, 3, NF>(ctx, a, d, qc, s);
         return AVX_ERR_UNSUPPORTED;
     }
     switch (a.r) {
         // <R, SY, XPT, min waves/SIMD>, from A/B runs on MI355X: 2 columns per thread keeps the
         // row-window reads conflict-free (16-byte lane stride) and the register windows under 128 VGPRs.
-#define AVX_MARCH_F32(RR, XX, MW) case RR: return launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, MW, NF>(ctx, a, d, qc, s);
+#define AVX_MARCH_F32(RR, XX, MW)                                                                            \
+    case RR:                                                                                                 \
+        return ng64 ? launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, 64, MW, NF>(ctx, a, d, qc, s)          \
+                    : launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, 128, MW, NF>(ctx, a, d, qc, s);
         AVX_MARCH_F32(1, 4, 3) AVX_MARCH_F32(3, 4, 3) AVX_MARCH_F32(4, 2, 3) AVX_MARCH_F32(5, 2, 3) AVX_MARCH_F32(6, 2, 3)
         AVX_MARCH_F32(7, 2, 3) AVX_MARCH_F32(8, 2, 3) AVX_MARCH_F32(9, 2, 3) AVX_MARCH_F32(14, 2, 2)
 #undef AVX_MARCH_F32
