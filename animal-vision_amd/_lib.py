@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libavx.so")
 AVX_OK = 0
 AVX_ERR_INVALID, AVX_ERR_NO_DEVICE, AVX_ERR_HIP, AVX_ERR_UNSUPPORTED, AVX_ERR_NOMEM = -1, -2, -3, -4, -5
 AVX_COLOR_MATRIX, AVX_COLOR_CAT_MERGE = 0, 1
-AVX_POST_NONE, AVX_POST_GAUSS, AVX_POST_ROWGAIN = 0, 1, 2
+AVX_POST_NONE, AVX_POST_GAUSS, AVX_POST_ROWGAIN, AVX_POST_STREAK = 0, 1, 2, 3
 AVX_MAX_KSIZE = 33
 
 
@@ -39,6 +39,8 @@ class DichromatDesc(ctypes.Structure):
         ("chroma_enable", ctypes.c_int32),
         ("chroma_keep", ctypes.c_float),
         ("variant", ctypes.c_int32),
+        ("streak_rows_host", ctypes.POINTER(ctypes.c_float)),
+        ("streak_stride", ctypes.c_int32),
     ]
 
 

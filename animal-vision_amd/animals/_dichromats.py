@@ -49,8 +49,7 @@ Wolf = _mk("Wolf", DichromatSpec("wolf", 0.65, 0.95, sigma=1.4), "animals/wolf.p
 Fox = _mk("Fox", DichromatSpec("fox", 0.65, 0.98, sigma=1.3), "animals/fox.py:29,34")
 Raccoon = _mk("Raccoon", DichromatSpec("raccoon", 0.60, 0.98, sigma=2.0), "animals/raccoon.py:29,34")
 Rat = _mk("Rat", DichromatSpec("rat", 0.05, 0.86, post="scone", scone=(1.3, 0.5, 1.4, 0.25)), "animals/rat.py:29,34")
-# Streak-blur species: colour stage and parameters are in place, the per-row-sigma
-# kernel is the next row to land; constructing them works, visualize raises NotImplementedError.
+# Streak-blur species: apply_anisotropic_acuity_blur_with_streak as coded (quirks Q3/Q4), csrc/dichromat_streak.hip.
 Sheep = _mk("Sheep", DichromatSpec("sheep", 0.74, 1.06, post="streak", streak=(0.48, 0.8, 2.2, 6.0)), "animals/sheep.py:30,35")
 Pig = _mk("Pig", DichromatSpec("pig", 0.89, 1.32, post="streak", streak=(0.5, 1.2, 2.5, 3.0)), "animals/pig.py:30,35,38 (chroma result discarded, Q4)")
 Cow = _mk("Cow", DichromatSpec("cow", 0.84, 1.07, post="streak", streak=(0.5, 0.9, 2.3, 6.5)), "animals/cow.py:29,34")

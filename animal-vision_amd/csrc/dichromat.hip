@@ -579,7 +579,7 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
     AVX_REQUIRE(ctx, (size_t)n_frames * H * W * 3 < ((size_t)1 << 40), "avx_dichromat_u8: batch too large");
     AVX_REQUIRE(ctx, d->color_mode == AVX_COLOR_MATRIX || d->color_mode == AVX_COLOR_CAT_MERGE,
                 "avx_dichromat_u8: unknown color_mode %d", d->color_mode);
-    AVX_REQUIRE(ctx, d->post_mode >= AVX_POST_NONE && d->post_mode <= AVX_POST_ROWGAIN,
+    AVX_REQUIRE(ctx, d->post_mode >= AVX_POST_NONE && d->post_mode <= AVX_POST_STREAK,
                 "avx_dichromat_u8: unknown post_mode %d", d->post_mode);
     if (n_frames == 0) return AVX_OK;
     AVX_HIP(ctx, hipSetDevice(ctx->device));
@@ -652,6 +652,10 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
     }
     // auto: the marching strip kernel wherever an instantiation exists (it beats the 2-D tiled kernel for
     // every species measured); explicit variants are honoured as asked.
+    if (d->post_mode == AVX_POST_STREAK) {
+        AVX_REQUIRE(ctx, !cat, "avx_dichromat_u8: AVX_POST_STREAK needs AVX_COLOR_MATRIX");
+        return avx_launch_dichromat_streak(ctx, ws, a, d, s);
+    }
     if (try_march) {
         const int rc = avx_launch_dichromat_march(ctx, a, d, cat, s);
         if (rc != AVX_ERR_UNSUPPORTED) return rc;

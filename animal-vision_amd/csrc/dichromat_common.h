@@ -89,3 +89,6 @@ template <> struct Vec8<double> { using type = double; };
 
 // variant 2 (dichromat_march.hip): returns AVX_ERR_UNSUPPORTED when no instantiation covers (type, radius).
 int avx_launch_dichromat_march(avx_ctx* ctx, avxk::DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, hipStream_t s);
+
+// AVX_POST_STREAK (dichromat_streak.hip): float32 colour matrix only, like every streak species.
+int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, avxk::DichromatArgs& a, const avx_dichromat_desc* d, hipStream_t s);

@@ -70,6 +70,38 @@ def s_cone_row_gain(H: int, s_top=1.0, s_bottom=0.6, *, power=1.0, extra_boost=0
     return np.ascontiguousarray(w, dtype=np.float32)
 
 
+STREAK_STRIDE = 48
+
+
+def streak_row_tables(H: int, y_center: float, sigma_streak: float, sigma_far: float, falloff: float) -> np.ndarray:
+    """Per-image-row kernels of apply_anisotropic_acuity_blur_with_streak (animals/animal_utils.py:156-171):
+    sigma map :157-162 in float32 exactly as coded, then for each row the two cv2.GaussianBlur kernels
+    (ksize (0,0) -> cvRound(8 sigma + 1)|1, getGaussianKernel taps cast to the image's float32).
+    Layout per row: [k1, k2, 13 x taps(sigmaX), 33 x taps(sigmaY)]."""
+    yy = np.linspace(0, 1, H, dtype=np.float32)[:, None]
+    d = np.abs(yy - y_center)
+    sigma_map = sigma_streak + (sigma_far - sigma_streak) * (1.0 - np.exp(-falloff * d**2))
+    sigmaY = sigma_map
+    sigmaX = np.maximum(0.4, 0.5 * sigma_map)
+    out = np.zeros((H, STREAK_STRIDE), np.float32)
+    cache = {}
+    for y in range(H):
+        sx, sy = float(sigmaX[y, 0]), float(sigmaY[y, 0])
+        key = (sx, sy)
+        row = cache.get(key)
+        if row is None:
+            k1, k2 = cv_auto_ksize(sx), cv_auto_ksize(sy)
+            if k1 > 13 or k2 > 33:
+                raise ValueError(f"streak sigma too large for the device tables (k1={k1}, k2={k2})")
+            row = np.zeros(STREAK_STRIDE, np.float32)
+            row[0], row[1] = k1, k2
+            row[2 : 2 + k1] = gaussian_taps(k1, sx).astype(np.float32)
+            row[15 : 15 + k2] = gaussian_taps(k2, sy).astype(np.float32)
+            cache[key] = row
+        out[y] = row
+    return out
+
+
 @dataclass
 class DichromatSpec:
     """One dichromat species: colour stage + post stage."""
@@ -116,10 +148,16 @@ class DichromatOp:
         elif spec.post == "scone":
             d.post_mode = _lib.AVX_POST_ROWGAIN
             d.row_gain_clamp = 1
+        elif spec.post == "streak":
+            if spec.color != "collapse":
+                raise ValueError("the streak blur runs on the float32 collapse-matrix colour stage")
+            d.post_mode = _lib.AVX_POST_STREAK
+            d.streak_stride = STREAK_STRIDE
         elif spec.post == "none":
             d.post_mode = _lib.AVX_POST_NONE
         else:
-            raise NotImplementedError(f"post stage {spec.post!r} has no device kernel yet (SURVEY 8f row 2)")
+            raise ValueError(f"unknown post stage {spec.post!r}")
+        self._streak = None
         if spec.chroma is not None:
             d.chroma_enable = 1
             d.chroma_keep = float(np.float32(1 - spec.chroma))
@@ -141,6 +179,10 @@ class DichromatOp:
                 s_top, s_bottom, power, boost = self.spec.scone
                 self._gain = s_cone_row_gain(H, s_top, s_bottom, power=power, extra_boost=boost)
             self.desc.row_gain_host = self._gain.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        if self.spec.post == "streak":
+            if self._streak is None or self._streak.shape[0] != H:
+                self._streak = streak_row_tables(H, *self.spec.streak)
+            self.desc.streak_rows_host = self._streak.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
         ctx._check(lib.avx_dichromat_u8(ctx._h, d_in.ptr, d_out.ptr, n_frames, H, W, ctypes.byref(self.desc), ctx._s(stream)))
 
     def __call__(self, image: np.ndarray) -> np.ndarray:

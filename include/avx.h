@@ -72,11 +72,12 @@ int avx_timer_stop(avx_ctx* ctx, void* stream, float* out_ms); /* records, synch
  *     or sRGB_to_LMS / L-M merge / LMS_to_RGB   animals/cat.py:95-101  (f64 tail)   [AVX_COLOR_CAT_MERGE]
  *   apply_acuity_blur      animals/animal_utils.py:121-145 (cv2.GaussianBlur semantics)   [AVX_POST_GAUSS]
  *     or apply_s_cone_vertical_gain  animal_utils.py:206-259 (per-row blue gain)          [AVX_POST_ROWGAIN]
+ *     or apply_anisotropic_acuity_blur_with_streak  animal_utils.py:147-172 (as coded, Q3) [AVX_POST_STREAK]
  *   apply_chroma_compression  animal_utils.py:174-181 (optional)
  *   clip -> linear_to_srgb -> clip -> (x*255+0.5).astype(uint8)   animals/dog.py:54-57
  * Results are bit-identical to the reference executed in the build container (tests/golden). */
 enum { AVX_COLOR_MATRIX = 0, AVX_COLOR_CAT_MERGE = 1 };
-enum { AVX_POST_NONE = 0, AVX_POST_GAUSS = 1, AVX_POST_ROWGAIN = 2 };
+enum { AVX_POST_NONE = 0, AVX_POST_GAUSS = 1, AVX_POST_ROWGAIN = 2, AVX_POST_STREAK = 3 };
 
 typedef struct avx_dichromat_desc {
     uint32_t struct_size;      /* sizeof(avx_dichromat_desc), for ABI growth                         */
@@ -93,6 +94,10 @@ typedef struct avx_dichromat_desc {
     int32_t chroma_enable;     /* apply_chroma_compression after the post stage                      */
     float chroma_keep;         /*   float32(1 - strength), the factor animal_utils.py:181 multiplies by */
     int32_t variant;           /* 0 = auto; A/B only: 1 = reference kernel, 2 = 2-D tiled, 3 = marching strip */
+    const float* streak_rows_host; /* AVX_POST_STREAK: H x streak_stride floats, per image row:
+                                  [0] k1, [1] k2 (odd tap counts of the sigmaX / sigmaY kernels of that row),
+                                  [2..15) k1 float32 taps, [15..48) k2 float32 taps                         */
+    int32_t streak_stride;     /* >= 48                                                                  */
 } avx_dichromat_desc;
 
 #define AVX_MAX_KSIZE 33

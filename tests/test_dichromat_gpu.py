@@ -7,7 +7,8 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-GAUSS = ["dog", "cat", "squirrel", "elephant", "lion", "tiger", "bear", "wolf", "fox", "raccoon", "rat"]
+GAUSS = ["dog", "cat", "squirrel", "elephant", "lion", "tiger", "bear", "wolf", "fox", "raccoon", "rat",
+         "sheep", "pig", "cow", "goat", "horse", "rabbit", "panda", "deer", "kangaroo"]  # all 20 dichromats
 
 
 @pytest.fixture(scope="module")
