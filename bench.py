@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--workload", default="cat_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive pipeline leg (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
 
@@ -176,6 +177,15 @@ def main():
         "roofline": roof,
     }
 
+    # HBM traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_pmc.sh:
+    # separate --pmc runs; FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads, WRITE_SIZE as is).
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+        if pmc and pmc.get("frames_per_launch") == B and mst is None:
+            result["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_note"] = pmc["note"]
+    except (OSError, ValueError):
+        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_ref
 
@@ -214,7 +224,7 @@ def main():
             else:
                 result["parity_checked"] = bool(np.array_equal(got[0], want))
 
-    if mst is None and rank == 0 and world == 1:
+    if mst is None and rank == 0 and world == 1 and not args.no_e2e:
         # PCIe-inclusive leg (never `value`): the same op through pipeline.FramePipeline, host frames in, host frames out.
         from animal_vision_amd.pipeline import FramePipeline
 

@@ -2,7 +2,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_mst
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mst -- python bench.py --workload ${WL:-honeybee_mst_1080p} --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_mst.json 2> gpurun_out/prof_mst.err || { tail -5 gpurun_out/prof_mst.err; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mst -- python bench.py --workload ${WL:-honeybee_mst_1080p} --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/prof_mst.json 2> gpurun_out/prof_mst.err || { tail -5 gpurun_out/prof_mst.err; exit 1; }
 f=$(find gpurun_out/prof_mst -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys

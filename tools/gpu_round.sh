@@ -18,7 +18,7 @@ for wl in ${WORKLOADS:-cat_1080p dog_1080p dog_4k}; do
 done
 echo "== rocprofv3" | tee -a gpurun_out/progress.log
 rm -rf gpurun_out/prof
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { tail -20 gpurun_out/prof.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { tail -20 gpurun_out/prof.err; exit 1; }
 find gpurun_out/prof -name "*stats*" | head
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
 echo "== done" | tee -a gpurun_out/progress.log
