@@ -127,6 +127,9 @@ _SIGS = {
     "avx_planes_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "avx_rgb_to_hsi_lobes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_float, _vp, _vp]),
     "avx_honeybee_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(HoneybeeDesc), _vp, _vp]),
+    "avx_mst_gram": (_i, [_vp, _vp, _i, _sz, _i, _i, _vp, _vp, _vp, _vp]),
+    "avx_dwconv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "avx_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _i, ctypes.c_float, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = stale libavx.so: rebuild

@@ -27,6 +27,76 @@ import torch.nn.functional as F
 DIM = 31
 
 
+class _AvxOps:
+    """Binds the hand-written gfx950 kernels of csrc/mst.hip for CUDA tensors (data_ptr hand-off on torch's
+    current stream).  AVX_MST_TORCH_ONLY=1 keeps every op in torch (A/B and debugging)."""
+
+    def __init__(self):
+        import os
+
+        self.enabled = os.environ.get("AVX_MST_TORCH_ONLY", "") == ""
+        self._ctx = {}
+
+    def ctx(self, device: torch.device):
+        """The process-wide libavx context (one process per GPU); it must sit on the tensor's device."""
+        from ..runtime import get_context
+
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        c = get_context(idx)
+        if c.device != idx:
+            raise RuntimeError(f"libavx context is on device {c.device}, tensor on cuda:{idx} (one process per GPU)")
+        return c
+
+    @staticmethod
+    def _dt(t: torch.Tensor) -> int:
+        if t.dtype == torch.float32:
+            return 0
+        if t.dtype == torch.float16:
+            return 1
+        raise TypeError(f"csrc/mst.hip kernels take float32/float16, got {t.dtype}")
+
+    def gram(self, qkv: torch.Tensor, heads: int):
+        """qkv (b, n, 3c) contiguous -> gram (b, heads, d, d), nq (b, c), nk (b, c), all float32."""
+        from .._lib import lib
+
+        b, n, c3 = qkv.shape
+        c = c3 // 3
+        d = c // heads
+        ctx = self.ctx(qkv.device)
+        g = torch.empty((b, heads, 32, 32), dtype=torch.float32, device=qkv.device)
+        nq = torch.empty((b, c), dtype=torch.float32, device=qkv.device)
+        nk = torch.empty((b, c), dtype=torch.float32, device=qkv.device)
+        st = torch.cuda.current_stream(qkv.device).cuda_stream
+        for i in range(b):
+            ctx._check(lib.avx_mst_gram(ctx._h, qkv[i].data_ptr(), self._dt(qkv), n, c, heads, g[i].data_ptr(), nq[i].data_ptr(), nk[i].data_ptr(), st))
+        return g[:, :, :d, :d], nq, nk
+
+    def dwconv(self, x: torch.Tensor, w_c9: torch.Tensor, gelu: bool) -> torch.Tensor:
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_dwconv3x3_nhwc(ctx._h, x.data_ptr(), w_c9.data_ptr(), y.data_ptr(), self._dt(x), b, h, w, c, 1 if gelu else 0,
+                                          torch.cuda.current_stream(x.device).cuda_stream))
+        return y
+
+    def layernorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+        from .._lib import lib
+
+        c = x.shape[-1]
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_layernorm_rows(ctx._h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), self._dt(x), x.numel() // c, c, eps,
+                                          torch.cuda.current_stream(x.device).cuda_stream))
+        return y
+
+
+_AVX = _AvxOps()
+
+
 def _msab_keys(prefix: str, dim: int) -> Dict[str, tuple]:
     a, f = f"{prefix}.blocks.0.0", f"{prefix}.blocks.0.1"
     return {
@@ -143,11 +213,16 @@ class MSTPlusPlus(torch.nn.Module):
         q, k, v = qkv[..., :c], qkv[..., c : 2 * c], qkv[..., 2 * c :]
         d = c // heads
         # Gram matrix per head over ALL pixels (the global contraction of :129), fp32 accumulate
-        qh = q.reshape(b, n, heads, d).permute(0, 2, 1, 3)  # (b, heads, n, d)
-        kh = k.reshape(b, n, heads, d).permute(0, 2, 1, 3)
-        gram = torch.matmul(kh.transpose(-2, -1), qh).float()  # (b, heads, d, d): [i][j] = k_i . q_j
-        nq = torch.linalg.vector_norm(q.float(), dim=1).reshape(b, heads, 1, d).clamp_min(1e-12)  # F.normalize eps
-        nk = torch.linalg.vector_norm(k.float(), dim=1).reshape(b, heads, d, 1).clamp_min(1e-12)
+        if x.is_cuda and _AVX.enabled:
+            gram, nq, nk = _AVX.gram(qkv, heads)  # one pass over qkv: k^T q and every column norm (csrc/mst.hip)
+            nq = nq.reshape(b, heads, 1, d).clamp_min(1e-12)  # F.normalize eps
+            nk = nk.reshape(b, heads, d, 1).clamp_min(1e-12)
+        else:
+            qh = q.reshape(b, n, heads, d).permute(0, 2, 1, 3)  # (b, heads, n, d)
+            kh = k.reshape(b, n, heads, d).permute(0, 2, 1, 3)
+            gram = torch.matmul(kh.transpose(-2, -1), qh).float()  # (b, heads, d, d): [i][j] = k_i . q_j
+            nq = torch.linalg.vector_norm(q.float(), dim=1).reshape(b, heads, 1, d).clamp_min(1e-12)
+            nk = torch.linalg.vector_norm(k.float(), dim=1).reshape(b, heads, d, 1).clamp_min(1e-12)
         attn = gram / (nk * nq)
         attn = attn * self._p(p + ".rescale").float().reshape(1, heads, 1, 1)
         attn = attn.softmax(dim=-1)  # over j
@@ -157,17 +232,29 @@ class MSTPlusPlus(torch.nn.Module):
         M = torch.matmul(attn.transpose(-2, -1), wp_h.unsqueeze(0)).reshape(b, c, c).to(x.dtype)  # (b, c, c)
         out_c = torch.baddbmm(self._p(p + ".proj.bias").to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
         vi = v.reshape(b, h, w, c)
-        pe = self._conv_nhwc(vi, self._p(p + ".pos_emb.0.weight"), padding=1, groups=c)
-        pe = self._conv_nhwc(F.gelu(pe), self._p(p + ".pos_emb.2.weight"), padding=1, groups=c)
+        pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False)
         return out_c + pe
+
+    def _dw(self, x: torch.Tensor, key: str, gelu: bool) -> torch.Tensor:
+        """Depthwise 3x3 (+ GELU) on an NHWC tensor: csrc/mst.hip on the GPU, torch ops otherwise."""
+        c = x.shape[-1]
+        if x.is_cuda and _AVX.enabled:
+            w9 = self._prep(key + ".c9f32", lambda: self._p(key).reshape(c, 9).float().contiguous())
+            return _AVX.dwconv(x, w9, gelu)
+        y = self._conv_nhwc(x, self._p(key), padding=1, groups=c)
+        return F.gelu(y) if gelu else y
 
     def _ffn(self, x: torch.Tensor, p: str) -> torch.Tensor:
         b, h, w, c = x.shape
-        y = F.layer_norm(x.float(), (c,), self._p(p + ".norm.weight").float(), self._p(p + ".norm.bias").float()).to(x.dtype)
+        if x.is_cuda and _AVX.enabled:
+            y = _AVX.layernorm(x, self._prep(p + ".g32", lambda: self._p(p + ".norm.weight").float().contiguous()),
+                               self._prep(p + ".b32", lambda: self._p(p + ".norm.bias").float().contiguous()))
+        else:
+            y = F.layer_norm(x.float(), (c,), self._p(p + ".norm.weight").float(), self._p(p + ".norm.bias").float()).to(x.dtype)
         w1 = self._prep(p + ".w1", lambda: self._p(p + ".fn.net.0.weight").reshape(4 * c, c).t().contiguous())
         w2 = self._prep(p + ".w2", lambda: self._p(p + ".fn.net.4.weight").reshape(c, 4 * c).t().contiguous())
         y = F.gelu(y.reshape(b, h * w, c) @ w1).reshape(b, h, w, 4 * c)
-        y = F.gelu(self._conv_nhwc(y, self._p(p + ".fn.net.2.weight"), padding=1, groups=4 * c))
+        y = self._dw(y, p + ".fn.net.2.weight", gelu=True)
         return (y.reshape(b, h * w, 4 * c) @ w2).reshape(b, h, w, c)
 
     def _msab(self, x: torch.Tensor, p: str, heads: int) -> torch.Tensor:

@@ -161,6 +161,22 @@ typedef struct avx_honeybee_desc {
 int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W,
                     const avx_honeybee_desc* desc, float* debug_planes, void* stream);
 
+/* ---- MST++ helpers (ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py) ----------------------------
+ * Hand-written kernels for the memory-bound parts of the forward pass; PyTorch-ROCm keeps the dense GEMMs/convs.
+ * Pointers are torch tensors' data_ptr(); dtype 0 = float32, 1 = float16; all on `stream` (torch's current stream). */
+
+/* MS_MSA :127-129 in one pass over qkv (n_pix x 3C, row-major: q | k | v): per head h (d = C/heads <= 32)
+ *   gram[h][i][j] = sum_n k[n][h*d+i] * q[n][h*d+j]   (32x32 padded, float32)
+ *   nq[c] = ||q[:,c]||_2, nk[c] = ||k[:,c]||_2        (what F.normalize(dim=-1) divides by) */
+int avx_mst_gram(avx_ctx* ctx, const void* qkv, int dtype, size_t n_pix, int C, int heads, float* gram, float* nq, float* nk, void* stream);
+
+/* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
+ * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
+int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, void* stream);
+
+/* nn.LayerNorm(C) (PreNorm :57-65) over the last dim of (rows x C): biased variance, float32 statistics. */
+int avx_layernorm_rows(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps, void* stream);
+
 /* The constant tables compiled into the library (reference outputs, see csrc/srgb_tables.h):
  * which = 0: 256 x f32 decode LUT; 1: 255 x f32 encode thresholds; 2: 255 x f64 encode thresholds.
  * Copies min(capacity, size) bytes to dst_host and returns the table's size in bytes. */
