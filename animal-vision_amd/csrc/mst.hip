@@ -105,13 +105,17 @@ __global__ __launch_bounds__(kMT) void k_mst_gram(const T* __restrict__ qkv, siz
     }
 }
 
+// one wave per output element: lanes stride over the block partials, fixed-shape shuffle tree (deterministic)
 __global__ void k_mst_gram_final(const float* __restrict__ partial, int nblocks, int heads, int d, float* gram /*[heads][32][32]*/,
                                  float* nq /*[heads*d]*/, float* nk) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= heads * 34 * 32) return;
     const int h = i / (34 * 32), e = i - h * 34 * 32;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * heads + h) * 34 * 32 + e];
+    for (int b = lane; b < nblocks; b += 64) s += partial[((size_t)b * heads + h) * 34 * 32 + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane != 0) return;
     const int r = e >> 5, c = e & 31;
     if (r < 32) gram[(h * 32 + r) * 32 + c] = s;
     else if (r == 32) { if (c < d) nq[h * d + c] = __fsqrt_rn(s); }
@@ -248,7 +252,7 @@ int avx_mst_gram(avx_ctx* ctx, const void* qkv, int dtype, size_t n_pix, int C, 
         hipLaunchKernelGGL(k_mst_gram<__half>, dim3((unsigned)blocks), dim3(kMT), lds, s, (const __half*)qkv, n_pix, C, heads, per, partial);
     }
     const int tot = heads * 34 * 32;
-    hipLaunchKernelGGL(k_mst_gram_final, dim3((tot + 255) / 256), dim3(256), 0, s, partial, (int)blocks, heads, d, gram, nq, nk);
+    hipLaunchKernelGGL(k_mst_gram_final, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, partial, (int)blocks, heads, d, gram, nq, nk);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

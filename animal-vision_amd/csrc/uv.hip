@@ -169,11 +169,14 @@ __global__ __launch_bounds__(kT) void k_plane_stats(const float* __restrict__ pl
 // next pass divides by: adapt 0: 1 | 1 white_patch: max(max, eps) | 2 gray_world: max(mean, eps)
 // | 3 safe_norm: (max - min), with stats.x = min subtracted first (uv_helpers.py:47-53).
 __global__ void k_finalize_stats(const Stat3* partials, int nblocks, int K, size_t n, int adapt, float eps, float4* stats) {
-    const int k = threadIdx.x;
+    // one wave per plane; lanes stride over the block partials, fixed-shape shuffle tree (deterministic)
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= K) return;
     float a = 3.4e38f, b = -3.4e38f;
     double c = 0.0;
-    for (int i = 0; i < nblocks; ++i) { const Stat3 s = partials[(size_t)i * K + k]; a = fminf(a, s.mn); b = fmaxf(b, s.mx); c += s.sum; }
+    for (int i = lane; i < nblocks; i += 64) { const Stat3 s = partials[(size_t)i * K + k]; a = fminf(a, s.mn); b = fmaxf(b, s.mx); c += s.sum; }
+    a = wave_min(a); b = wave_max(b); c = wave_sum(c);
+    if (lane != 0) return;
     const float mean = (float)(c / (double)n);
     float den = 1.0f;
     if (adapt == 1) den = fmaxf(b, eps);
@@ -288,22 +291,45 @@ __global__ void k_sel_init(SelState* st, unsigned long long rank) {
     st->prefix = 0; st->mask = 0; st->rank = rank; st->key_lo = 0; st->key_hi = 0; st->cnt_in_bin = 0; st->next_key = 0xffffffffu;
 }
 
-__global__ void k_sel_pick(uint32_t* hist, int shift, int bits, SelState* st, int last) {
-    if (threadIdx.x != 0) return;
-    const int nb = 1 << bits;
-    unsigned long long r = st->rank, cum = 0;
-    int b = 0;
-    for (; b < nb; ++b) {
-        const unsigned long long c = hist[b];
-        if (cum + c > r) break;
-        cum += c;
+// One workgroup: 256 threads each own nb/256 consecutive bins; an LDS scan of the 256 chunk sums finds the
+// chunk that holds the rank, its owner finishes inside the chunk.  Also re-zeroes the histogram.
+__global__ __launch_bounds__(kT) void k_sel_pick(uint32_t* hist, int shift, int bits, SelState* st, int last) {
+    __shared__ unsigned long long csum[kT];
+    __shared__ int sel_chunk;
+    const int nb = 1 << bits, per = nb / kT, t = threadIdx.x;  // nb in {1024, 2048}
+    uint32_t loc[8];
+    unsigned long long s = 0;
+    for (int i = 0; i < per; ++i) { loc[i] = hist[t * per + i]; s += loc[i]; }
+    csum[t] = s;
+    __syncthreads();
+    const unsigned long long r = st->rank;
+    if (t == 0) {
+        unsigned long long cum = 0;
+        int c = 0;
+        for (; c < kT; ++c) {
+            if (cum + csum[c] > r) break;
+            cum += csum[c];
+        }
+        if (c == kT) { c = kT - 1; cum -= csum[c]; }  // rank beyond the data (cannot happen for rank < n)
+        sel_chunk = c;
+        csum[0] = cum;  // exclusive prefix of the selected chunk
     }
-    if (b == nb) b = nb - 1;  // rank beyond the data (cannot happen for rank < n)
-    st->prefix |= (uint32_t)b << shift;
-    st->mask |= (uint32_t)(nb - 1) << shift;
-    st->rank = r - cum;
-    if (last) { st->key_lo = st->prefix; st->cnt_in_bin = hist[b]; st->next_key = 0xffffffffu; }
-    for (int i = 0; i < nb; ++i) hist[i] = 0;
+    __syncthreads();
+    if (t == sel_chunk) {
+        unsigned long long cum = csum[0];
+        int i = 0;
+        for (; i < per; ++i) {
+            if (cum + loc[i] > r) break;
+            cum += loc[i];
+        }
+        if (i == per) i = per - 1;
+        const int b = t * per + i;
+        st->prefix |= (uint32_t)b << shift;
+        st->mask |= (uint32_t)(nb - 1) << shift;
+        st->rank = r - cum;
+        if (last) { st->key_lo = st->prefix; st->cnt_in_bin = loc[i]; st->next_key = 0xffffffffu; }
+    }
+    for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
 }
 
 __global__ __launch_bounds__(kT) void k_sel_next(const float* __restrict__ x, size_t n, SelState* st) {
@@ -516,7 +542,7 @@ static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int p = 0; p < 3; ++p) {
         hipLaunchKernelGGL(k_sel_hist, dim3(g), dim3(kT), 0, s, x, n, shifts[p], bits[p], u.sel, u.hist);
-        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(64), 0, s, u.hist, shifts[p], bits[p], u.sel, p == 2 ? 1 : 0);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kT), 0, s, u.hist, shifts[p], bits[p], u.sel, p == 2 ? 1 : 0);
     }
     if (has_next) hipLaunchKernelGGL(k_sel_next, dim3(g), dim3(kT), 0, s, x, n, u.sel);
     hipLaunchKernelGGL(k_sel_lerp, dim3(1), dim3(64), 0, s, u.sel, gamma, has_next, out_dev);
@@ -556,7 +582,7 @@ int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype,
     AVX_HIP(ctx, hipMemcpyAsync(u.mat, weights_host, sizeof(float) * K * B, hipMemcpyHostToDevice, s));
     const int g = grid_for(ctx, n);
     hipLaunchKernelGGL(k_spectral_integrate<16>, dim3(g), dim3(kT), sizeof(float) * K * B, s, hsi, layout, dtype, n, B, u.mat, K, out_planes, u.partials);
-    hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(64), 0, s, u.partials, g, K, n, 0, 0.0f, u.stats);
+    hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(1024), 0, s, u.partials, g, K, n, 0, 0.0f, u.stats);
     AVX_HIP(ctx, hipGetLastError());
     if (stats_host) {
         AVX_HIP(ctx, hipMemcpyAsync(stats_host, u.stats, sizeof(float4) * K, hipMemcpyDeviceToHost, s));
@@ -601,7 +627,7 @@ int avx_plane_stats(avx_ctx* ctx, const float* planes, int K, size_t n, int adap
     if (rc) return rc;
     const int g = grid_for(ctx, n);
     hipLaunchKernelGGL(k_plane_stats<16>, dim3(g), dim3(kT), 0, s, planes, n, K, u.partials);
-    hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(64), 0, s, u.partials, g, K, n, adapt, eps, u.stats);
+    hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(1024), 0, s, u.partials, g, K, n, adapt, eps, u.stats);
     AVX_HIP(ctx, hipGetLastError());
     if (stats_host) {
         AVX_HIP(ctx, hipMemcpyAsync(stats_host, u.stats, sizeof(float4) * K, hipMemcpyDeviceToHost, s));
@@ -665,7 +691,7 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
                                d->bands, u.mat, 3, raw, u.partials);
         }
         // 4) von Kries denominators
-        hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(64), 0, s, u.partials, g, 3, n, d->adaptation, d->eps, u.stats);
+        hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(1024), 0, s, u.partials, g, 3, n, d->adaptation, d->eps, u.stats);
         // 5) (x / white) then Gaussian blur
         {
             BlurArgs a{};
