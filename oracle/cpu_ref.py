@@ -32,10 +32,8 @@ _lib = None
 
 def build_lib() -> str:
     """Compile oracle/avxref.cpp with g++ (idempotent)."""
-    src = os.path.join(_HERE, "avxref.cpp")
-    if not os.path.exists(_LIB_PATH) or (
-        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)
-    ):
+    srcs = [os.path.join(_HERE, f) for f in ("avxref.cpp", "cvref.cpp")]
+    if not os.path.exists(_LIB_PATH) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"])
     return _LIB_PATH
 
@@ -52,6 +50,12 @@ def lib() -> ctypes.CDLL:
             "avxref_matmul3_f32_f64",
             "avxref_quantize_f32",
             "avxref_quantize_f64",
+            "cvref_resize_linear_f32",
+            "cvref_resize_linear_u8",
+            "cvref_resize_cubic_f32",
+            "cvref_resize_area_f32",
+            "cvref_remap_linear_f32",
+            "cvref_sobel3_f32",
         ):
             getattr(_lib, name).restype = None
     return _lib
@@ -809,3 +813,232 @@ def make_split_frame_nolabel(original: np.ndarray, modified: np.ndarray, draw_se
     if draw_seam:
         out[:, mid : mid + 1, :] = 255
     return out
+
+
+# =============================================================================
+# OpenCV resize / remap / Sobel restatements (oracle/cvref.cpp): PARITY UNPINNED
+# =============================================================================
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA = 0, 1, 2, 3  # cv2 constants
+
+
+def cv_resize(img: np.ndarray, dsize: Tuple[int, int], interpolation: int = INTER_LINEAR) -> np.ndarray:
+    """cv2.resize(img, (W_out, H_out), interpolation=...) for HxW[xC] float32 (LINEAR/CUBIC/AREA) or uint8 (LINEAR)."""
+    Wd, Hd = int(dsize[0]), int(dsize[1])
+    squeeze = img.ndim == 2
+    a = np.ascontiguousarray(img[..., None] if squeeze else img)
+    H, W, C = a.shape
+    if a.dtype == np.uint8:
+        assert interpolation == INTER_LINEAR, "uint8: only INTER_LINEAR is restated"
+        out = np.empty((Hd, Wd, C), np.uint8)
+        lib().cvref_resize_linear_u8(_p(a), H, W, C, _p(out), Hd, Wd)
+    else:
+        a = a.astype(np.float32, copy=False)
+        out = np.empty((Hd, Wd, C), np.float32)
+        fn = {INTER_LINEAR: "cvref_resize_linear_f32", INTER_CUBIC: "cvref_resize_cubic_f32", INTER_AREA: "cvref_resize_area_f32"}[interpolation]
+        if interpolation == INTER_AREA and (Wd > W or Hd > H):
+            fn = "cvref_resize_linear_f32"  # cv::resize: INTER_AREA when enlarging behaves like INTER_LINEAR
+        getattr(lib(), fn)(_p(a), H, W, C, _p(out), Hd, Wd)
+    return out[..., 0] if squeeze else out
+
+
+def cv_remap_linear(img: np.ndarray, mapx: np.ndarray, mapy: np.ndarray, border_value: float = 0.0) -> np.ndarray:
+    """cv2.remap(img, mapx, mapy, INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=...) for float32 HxWxC."""
+    a = np.ascontiguousarray(img, np.float32)
+    H, W, C = a.shape
+    mx, my = np.ascontiguousarray(mapx, np.float32), np.ascontiguousarray(mapy, np.float32)
+    Hd, Wd = mx.shape
+    out = np.empty((Hd, Wd, C), np.float32)
+    lib().cvref_remap_linear_f32(_p(a), H, W, C, _p(mx), _p(my), _p(out), Hd, Wd, ctypes.c_float(border_value))
+    return out
+
+
+def cv_sobel3(img: np.ndarray, dx: int, dy: int) -> np.ndarray:
+    """cv2.Sobel(img, CV_32F, dx, dy, ksize=3, borderType=BORDER_REFLECT101) for (dx,dy) in {(1,0),(0,1)}."""
+    assert (dx, dy) in ((1, 0), (0, 1))
+    a = np.ascontiguousarray(img, np.float32)
+    out = np.empty_like(a)
+    lib().cvref_sobel3_f32(_p(a), a.shape[0], a.shape[1], int(dx), _p(out))
+    return out
+
+
+# ---- geometry helpers of the reference on top of them ---------------------------------------------
+def resize_preserve_range(x: np.ndarray, out_hw: Tuple[int, int], *, interp: int) -> np.ndarray:
+    """uv_helpers.py:57-64."""
+    H_out, W_out = out_hw
+    was_float = np.issubdtype(x.dtype, np.floating)
+    y = cv_resize(x.astype(np.float32, copy=False), (W_out, H_out), interp)
+    return y.astype(x.dtype, copy=False) if not was_float else y
+
+
+def panorama_warp(img_lin: np.ndarray, *, scale_x: float) -> np.ndarray:
+    """uv_helpers.py:84-99 (cv2 branch)."""
+    if abs(scale_x - 1.0) < 1e-3:
+        return img_lin
+    H, W = img_lin.shape[:2]
+    newW = max(2, int(round(W * scale_x)))
+    widened = cv_resize(img_lin, (newW, H), INTER_CUBIC)
+    if newW == W:
+        return widened
+    start = (newW - W) // 2
+    return widened[:, start : start + W, :]
+
+
+def classic_rgb_to_hsi_scaled(rgb01: np.ndarray, *, wavelengths: np.ndarray, scale: float) -> np.ndarray:
+    """uv_helpers.py:155-183: INTER_AREA down -> analytic lobes -> INTER_LINEAR up of the B-band cube."""
+    assert 0.0 < scale <= 1.0, "scale must be (0,1]."
+    H, W = rgb01.shape[:2]
+    h_small, w_small = max(1, int(round(H * scale))), max(1, int(round(W * scale)))
+    rgb_small = resize_preserve_range(rgb01, (h_small, w_small), interp=INTER_AREA)
+    hsi_small = classic_rgb_to_hsi_lobes(rgb_small, wavelengths.astype(np.float32))
+    return resize_preserve_range(hsi_small, (H, W), interp=INTER_LINEAR)
+
+
+def center_zoom(image: np.ndarray, scale: float) -> np.ndarray:
+    """animals/cat_widevision_utils.py:11-29 (cv2 branch)."""
+    if scale <= 1.0:
+        return image
+    H, W = image.shape[:2]
+    cw, ch = max(1, int(round(W / scale))), max(1, int(round(H / scale)))
+    x0, y0 = (W - cw) // 2, (H - ch) // 2
+    return cv_resize(image[y0 : y0 + ch, x0 : x0 + cw], (W, H), INTER_LINEAR)
+
+
+def zoom_scale_from_cat_ratio(*, camera_hfov_deg: float, cat_per_eye_half_fov_deg: float, cat_to_human_ratio: float) -> float:
+    """animals/cat_widevision_utils.py:31-44."""
+    import math
+
+    phi = float(cat_per_eye_half_fov_deg)
+    eff = min(float(camera_hfov_deg), 2.0 * phi)
+    ratio = max(1.01, float(cat_to_human_ratio))
+    cam = math.tan(math.radians(camera_hfov_deg) * 0.5)
+    hum = math.tan(math.radians(eff / ratio) * 0.5)
+    return float(cam / max(hum, 1e-6))
+
+
+def binocular_warp_maps(H_in: int, W_in: int, out_w: int, out_h: int, fov_in_deg: float, per_eye_half_fov_deg: float, overlap_deg: float):
+    """Maps and blend weights of animals/cat_widevision_utils.py:66-96 -> (xL, xR, ymap, wL, wR) float32."""
+    phi = np.deg2rad(per_eye_half_fov_deg)
+    psi = np.deg2rad(fov_in_deg * 0.5)
+    O = np.deg2rad(overlap_deg)
+    alpha = max(0.0, phi - 0.5 * O)
+    u = np.linspace(-1.0, 1.0, out_w, dtype=np.float32)
+    v = np.linspace(0.0, float(out_h - 1), out_h, dtype=np.float32)
+    U, _ = np.meshgrid(u, v)
+    thetaL = U * phi
+    thetaR = U * phi
+    gammaL, gammaR = thetaL - alpha, thetaR + alpha
+
+    def yaw_to_xsrc(gamma):
+        return ((gamma / psi) * (W_in * 0.5) + (W_in * 0.5)).astype(np.float32)
+
+    xL, xR = yaw_to_xsrc(gammaL), yaw_to_xsrc(gammaR)
+    ymap = np.repeat(np.linspace(0, H_in - 1, out_h, dtype=np.float32)[:, None], out_w, axis=1)
+    validL = (np.abs(gammaL) <= psi).astype(np.float32)
+    validR = (np.abs(gammaR) <= psi).astype(np.float32)
+    wL = (np.cos(0.5 * np.pi * (thetaL / phi)) ** 2).astype(np.float32) * validL
+    wR = (np.cos(0.5 * np.pi * (thetaR / phi)) ** 2).astype(np.float32) * validR
+    return xL, xR, ymap, wL, wR
+
+
+def animal_fov_binocular_warp(img01: np.ndarray, *, fov_in_deg, per_eye_half_fov_deg, overlap_deg, out_size=None, border_value=0.0):
+    """animals/cat_widevision_utils.py:46-99."""
+    H_in, W_in, _ = img01.shape
+    out_w, out_h = (W_in, H_in) if out_size is None else out_size
+    xL, xR, ymap, wL, wR = binocular_warp_maps(H_in, W_in, out_w, out_h, fov_in_deg, per_eye_half_fov_deg, overlap_deg)
+    left = cv_remap_linear(img01, xL, ymap, border_value)
+    right = cv_remap_linear(img01, xR, ymap, border_value)
+    wsum = (wL + wR + 1e-8)[..., None]
+    out = (left * wL[..., None] + right * wR[..., None]) / wsum
+    return np.clip(out, 0.0, 1.0).astype(np.float32)
+
+
+def cat_visualize(image: np.ndarray, *, enable_fov_warp: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """animals/cat.py:23-28,73-114 (Tina-animals side of the unresolved merge, quirk Q8): human-zoom baseline +
+    wide-FOV cat view with the float64 colour tail."""
+    assert isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] == 3
+    orig_dtype = image.dtype
+    H, W = image.shape[:2]
+    scale = zoom_scale_from_cat_ratio(camera_hfov_deg=100.0, cat_per_eye_half_fov_deg=105.0, cat_to_human_ratio=1.30)
+    human_zoomed = center_zoom(image, scale=scale)
+    cat01 = get_normalized_image(image)
+    if enable_fov_warp:
+        cat01 = animal_fov_binocular_warp(cat01.astype(np.float32), fov_in_deg=100.0, per_eye_half_fov_deg=105.0, overlap_deg=40.0,
+                                          out_size=(W, H), border_value=0.0)
+    lin = srgb_to_linear(cat01)
+    rgb = dichromat_color_stage(DICHROMATS["cat"], lin)
+    rgb = apply_acuity_blur(rgb, sigma=1.0)
+    cat_srgb = np.clip(linear_to_srgb(np.clip(rgb, 0.0, 1.0)), 0.0, 1.0)
+    if np.issubdtype(orig_dtype, np.integer):
+        human_out = human_zoomed if np.issubdtype(human_zoomed.dtype, np.integer) else (np.clip(human_zoomed, 0, 1) * 255.0 + 0.5).astype(orig_dtype)
+        cat_out = (cat_srgb * 255.0 + 0.5).astype(orig_dtype)
+    else:
+        human_out, cat_out = human_zoomed.astype(orig_dtype), cat_srgb.astype(orig_dtype)
+    return human_out, cat_out
+
+
+def mantis_visualize(image: np.ndarray, *, hsi_scale: float = 0.25, panorama_scale: float = 1.12, lambdas=None,
+                     bands=MANTIS_BANDS, red_kill=0.18, haze_strength=0.03, haze_tint=(0.92, 0.98, 1.00), pre_soft_sigma=0.25,
+                     unsharp_sigma=1.0, unsharp_amount=0.32, evec_angle_deg=30.0, pol_linear_strength=0.55, pol_linear_gamma=1.2,
+                     pol_circular_strength=0.35, orientation_mix=0.5, barcode_saturation=0.40, barcode_opacity=0.55,
+                     winner_take_most=0.35, scan_row_freq=26.0, scan_row_gain=0.08, scan_soften=0.8, periph_blur_sigma=0.7,
+                     periph_radius=0.80, periph_softness=7.0):
+    """animals/mantis_shrimp.py:143-279 (cv2 branches), defaults of :42-86."""
+    assert isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] == 3
+    dtype = image.dtype
+    lambdas = np.linspace(300.0, 700.0, 81, dtype=np.float32) if lambdas is None else np.asarray(lambdas, np.float32)
+    haze_tint = np.array(haze_tint, dtype=np.float32)
+    evec_angle = np.deg2rad(float(evec_angle_deg))
+    orientation_mix = float(np.clip(orientation_mix, 0.0, 1.0))
+    barcode_opacity = float(np.clip(barcode_opacity, 0.0, 1.0))
+    winner_take_most = float(np.clip(winner_take_most, 0.0, 1.0))
+    img_lin = uv_srgb_to_linear(to_float01(image))                                                     # :148-149
+    baseline_lin = panorama_warp(img_lin, scale_x=panorama_scale) if panorama_scale != 1.0 else img_lin  # :152
+    baseline_out = from_float01(uv_linear_to_srgb(np.clip(baseline_lin, 0, 1)), dtype)                 # :153
+    if 0.0 < hsi_scale < 1.0:                                                                          # :156-163
+        hsi = classic_rgb_to_hsi_scaled(baseline_lin, wavelengths=lambdas, scale=hsi_scale)
+    else:
+        hsi = classic_rgb_to_hsi_lobes(baseline_lin, lambdas)
+    H, W = baseline_lin.shape[:2]
+    S = mantis_band_stack(hsi, lambdas, bands)                                                         # :167-172
+    barcode_rgb, S_norm = mantis_barcode(S, winner_take_most=winner_take_most, barcode_saturation=barcode_saturation)  # :175-211
+    render = baseline_lin.copy()                                                                       # :214-220
+    render[..., 0] = np.clip(render[..., 0] * (1.0 - red_kill), 0.0, 1.0)
+    if haze_strength > 0.0:
+        a = float(np.clip(haze_strength, 0.0, 1.0))
+        render = (1.0 - a) * render + a * haze_tint[None, None, :]
+    if pre_soft_sigma > 0.0:
+        render = gaussian_blur(render, pre_soft_sigma)
+    broad = np.mean(S_norm, axis=2).astype(np.float32)                                                 # :224-226
+    gx, gy = cv_sobel3(broad, 1, 0), cv_sobel3(broad, 0, 1)
+    theta = np.arctan2(gy, gx).astype(np.float32)
+    cos2_local, sin2_local = np.cos(2.0 * theta), np.sin(2.0 * theta)                                  # :229-242
+    cos2_global, sin2_global = float(np.cos(2.0 * evec_angle)), float(np.sin(2.0 * evec_angle))
+    mix = orientation_mix
+    cos2_mix = (1.0 - mix) * cos2_global + mix * cos2_local
+    sin2_mix = (1.0 - mix) * sin2_global + mix * sin2_local
+    align01 = np.clip(0.5 * (cos2_mix + 1.0), 0.0, 1.0) ** pol_linear_gamma
+    align_circ = np.clip(0.5 * (sin2_mix + 1.0), 0.0, 1.0)
+    pol_gain = 1.0 + pol_linear_strength * align01 + pol_circular_strength * align_circ
+    if unsharp_sigma > 0.0 and unsharp_amount > 0.0:                                                   # :244-247
+        blur = gaussian_blur(render, unsharp_sigma)
+        high = np.clip(render - blur, -1.0, 1.0)
+        render = np.clip(render + (unsharp_amount * pol_gain[..., None]) * high, 0.0, 1.0)
+    render = np.clip((1.0 - barcode_opacity) * render + barcode_opacity * barcode_rgb, 0.0, 1.0)       # :250
+    if scan_row_gain != 0.0:                                                                           # :253-265
+        y = np.linspace(0.0, 1.0, H, dtype=np.float32)[:, None]
+        rows = 0.5 + 0.5 * np.sin(2.0 * np.pi * scan_row_freq * y)
+        rows = rows * np.ones((1, W), dtype=np.float32)
+        if scan_soften > 0.0:
+            rows = gaussian_blur(rows, scan_soften)
+        row_gain = 1.0 + scan_row_gain * (rows - 0.5)
+        render = np.clip(render * row_gain[..., None], 0.0, 1.0)
+    if periph_blur_sigma > 0.0:                                                                        # :268-275
+        periph = gaussian_blur(render, periph_blur_sigma)
+        yy = (np.linspace(-1.0, 1.0, H, dtype=np.float32))[:, None]
+        xx = (np.linspace(-1.0, 1.0, W, dtype=np.float32))[None, :]
+        r = np.sqrt(xx * xx + yy * yy)
+        t = 1.0 / (1.0 + np.exp(-periph_softness * (r - periph_radius)))
+        t = t[..., None]
+        render = (1.0 - t) * render + t * periph
+    out = from_float01(uv_linear_to_srgb(np.clip(render, 0.0, 1.0)), dtype)                            # :278
+    return baseline_out, out

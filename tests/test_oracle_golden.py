@@ -175,3 +175,34 @@ def test_honeybee_end_to_end_bit_exact(oracle):
         base, out = oracle.honeybee_visualize(frame, **kw)
         assert base is frame
         assert np.array_equal(out, g[key]), key
+
+
+def test_geometry_helpers_bit_exact(oracle):
+    """panorama_warp / classic_rgb_to_hsi_scaled / cat FOV helpers of the reference, driven with the shared
+    resize/remap restatements (cv2 itself: parity unpinned), vs the oracle's restatement of the glue."""
+    g = load_golden("geometry")
+    lin = g["lin"]
+    for sname, sc in (("112", 1.12), ("145", 1.45), ("105", 1.05)):
+        assert np.array_equal(oracle.panorama_warp(lin, scale_x=sc), g[f"pano_{sname}"])
+    lam81 = np.linspace(300.0, 700.0, 81, dtype=np.float32)
+    assert np.array_equal(oracle.classic_rgb_to_hsi_scaled(lin, wavelengths=lam81, scale=0.25), g["hsi_scaled_025"])
+    assert np.array_equal(oracle.classic_rgb_to_hsi_scaled(g["lin2"], wavelengths=lam81, scale=0.25), g["hsi_scaled_025_ragged"])
+    assert oracle.zoom_scale_from_cat_ratio(camera_hfov_deg=100.0, cat_per_eye_half_fov_deg=105.0, cat_to_human_ratio=1.30) == float(g["zoom_scale"])
+    for k in ("n48", "s60"):
+        f = g[f"in_{k}"]
+        H, W = f.shape[:2]
+        warp = oracle.animal_fov_binocular_warp(oracle.get_normalized_image(f).astype(np.float32), fov_in_deg=100.0,
+                                                per_eye_half_fov_deg=105.0, overlap_deg=40.0, out_size=(W, H))
+        assert np.array_equal(warp, g[f"cat_warp01_{k}"])
+        human, cat = oracle.cat_visualize(f)
+        assert np.array_equal(human, g[f"cat_human_{k}"])
+        assert np.array_equal(cat, g[f"cat_out_{k}"])
+
+
+def test_mantis_end_to_end_bit_exact(oracle):
+    g = load_golden("mantis")
+    for tag, kw in (("default", {}), ("noresample", dict(hsi_scale=1.0, panorama_scale=1.0))):
+        for k in ("s64", "n50"):
+            base, out = oracle.mantis_visualize(g[f"in_{k}"], **kw)
+            assert np.array_equal(base, g[f"{tag}_base_{k}"]), (tag, k)
+            assert np.array_equal(out, g[f"{tag}_out_{k}"]), (tag, k)

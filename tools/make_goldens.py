@@ -61,6 +61,12 @@ def _GaussianBlur(src, ksize, sigmaX, sigmaY=0.0, borderType=4, dst=None):
 
 
 cv2.GaussianBlur = _GaussianBlur
+# geometry: this repo's OpenCV-semantics restatements, PARITY UNPINNED
+cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC, cv2.INTER_AREA = 0, 1, 2, 3
+cv2.BORDER_CONSTANT = 0
+cv2.resize = lambda src, dsize, interpolation=1, **kw: O.cv_resize(src, dsize, interpolation)
+cv2.remap = lambda src, m1, m2, interpolation=1, borderMode=0, borderValue=0, **kw: O.cv_remap_linear(src, m1, m2, float(borderValue))
+cv2.Sobel = lambda src, ddepth, dx, dy, ksize=3, scale=1.0, delta=0.0, borderType=4: O.cv_sobel3(src, dx, dy)
 sys.modules["cv2"] = cv2
 sys.modules["colour"] = types.ModuleType("colour")
 
@@ -345,8 +351,70 @@ def g_mstpp():
     save("predict_torch_helpers", **o2)
 
 
+def g_geometry():
+    """8f row 1 helpers of the reference (uv_helpers.panorama_warp, classic_rgb_to_hsi_scaled, cat FOV helpers)
+    driven with the injected resize/remap, plus the full Cat (cat.py:73-112 re-enacted: the file does not parse)."""
+    conv = _ref_classic()
+    ref_uvh.cv2 = cv2
+    cw = importlib.import_module("animals.cat_widevision_utils")
+    assert cw._HAS_CV2
+    rng = np.random.default_rng(41)
+    out = {}
+    lin = rng.random((40, 56, 3), dtype=np.float32)
+    out["lin"] = lin
+    for sname, sc in (("112", 1.12), ("145", 1.45), ("105", 1.05)):
+        out[f"pano_{sname}"] = ref_uvh.panorama_warp(lin, scale_x=sc)
+    lam81 = np.linspace(300.0, 700.0, 81, dtype=np.float32)
+    out["hsi_scaled_025"] = ref_uvh.classic_rgb_to_hsi_scaled(lin, wavelengths=lam81, scale=0.25, converter=lambda a, w: conv(a, wavelengths=w))
+    lin2 = rng.random((50, 70, 3), dtype=np.float32)
+    out["lin2"] = lin2
+    out["hsi_scaled_025_ragged"] = ref_uvh.classic_rgb_to_hsi_scaled(lin2, wavelengths=lam81, scale=0.25, converter=lambda a, w: conv(a, wavelengths=w))
+    out["zoom_scale"] = np.array(cw.zoom_scale_from_cat_ratio(camera_hfov_deg=100.0, cat_per_eye_half_fov_deg=105.0, cat_to_human_ratio=1.30))
+    frames = {"n48": noise_frame(0, 48, 64), "s60": structured_frame(2, 60, 84)}
+    for k, f in frames.items():
+        out[f"in_{k}"] = f
+        H, W = f.shape[:2]
+        scale = cw.zoom_scale_from_cat_ratio(camera_hfov_deg=100.0, cat_per_eye_half_fov_deg=105.0, cat_to_human_ratio=1.30)
+        human_zoomed = cw.center_zoom(f, scale=scale)
+        cat01 = ref_au.get_normalized_image(f)
+        cat01 = cw.animal_fov_binocular_warp(cat01.astype(np.float32), fov_in_deg=100.0, per_eye_half_fov_deg=105.0, overlap_deg=40.0,
+                                             out_size=(W, H), border_mode=0, border_value=0.0)
+        out[f"cat_warp01_{k}"] = cat01
+        BLUR_MODE["mode"] = "oracle"
+        lin_c = ref_au.srgb_to_linear(cat01)
+        lms = ref_au.sRGB_to_LMS(lin_c.reshape(-1, 3))
+        LM = 0.5 * lms[:, 0] + (1.0 - 0.5) * lms[:, 1]
+        lin_rgb = ref_au.LMS_to_RGB(np.stack([LM, LM, lms[:, 2]], axis=1)).reshape(H, W, 3)
+        lin_rgb = ref_au.apply_acuity_blur(lin_rgb, sigma=1.0)
+        cat_srgb = np.clip(ref_au.linear_to_srgb(np.clip(lin_rgb, 0.0, 1.0)), 0.0, 1.0)
+        out[f"cat_human_{k}"] = human_zoomed
+        out[f"cat_out_{k}"] = (cat_srgb * 255.0 + 0.5).astype(np.uint8)
+    ref_uvh.cv2 = None
+    save("geometry", **out)
+
+
+def g_mantis():
+    """a22/a23 + geometry: the reference MantisShrimp class end to end (default parameters and a no-resample variant)."""
+    _ref_classic()
+    ref_uvh.cv2 = cv2
+    BLUR_MODE["mode"] = "oracle"
+    ms = importlib.import_module("animals.mantis_shrimp")
+    ms.classic_rgb_to_hsi = sys.modules["ml.classic_rgb_to_hsi.classic_rgb_to_hsi"].classic_rgb_to_hsi
+    ms.cv2 = cv2
+    frames = {"s64": structured_frame(3, 64, 80), "n50": noise_frame(7, 50, 70)}
+    out = {f"in_{k}": v for k, v in frames.items()}
+    for tag, kw in (("default", {}), ("noresample", dict(hsi_scale=1.0, panorama_scale=1.0))):
+        m = ms.MantisShrimp(**kw)
+        for k, f in frames.items():
+            base, res = m.visualize(f)
+            assert base.dtype == np.uint8 and res.dtype == np.uint8
+            out[f"{tag}_base_{k}"], out[f"{tag}_out_{k}"] = base, res
+    ref_uvh.cv2 = None
+    save("mantis", **out)
+
+
 GENERATORS = {"srgb_tables": g_srgb_tables, "matrices": g_matrices, "dichromat": g_dichromat, "uv": g_uv,
-              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp}
+              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp, "geometry": g_geometry, "mantis": g_mantis}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
