@@ -41,6 +41,7 @@ class DichromatDesc(ctypes.Structure):
         ("variant", ctypes.c_int32),
         ("streak_rows_host", ctypes.POINTER(ctypes.c_float)),
         ("streak_stride", ctypes.c_int32),
+        ("in_f32", ctypes.c_int32),
     ]
 
 
@@ -127,6 +128,9 @@ _SIGS = {
     "avx_planes_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "avx_rgb_to_hsi_lobes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_float, _vp, _vp]),
     "avx_honeybee_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(HoneybeeDesc), _vp, _vp]),
+    "avx_resize_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "avx_binocular_warp_u8": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "avx_sobel3_plane": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "avx_mst_gram": (_i, [_vp, _vp, _i, _sz, _i, _i, _vp, _vp, _vp, _vp]),
     "avx_dwconv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "avx_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _i, ctypes.c_float, _vp]),

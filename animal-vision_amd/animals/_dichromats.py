@@ -62,15 +62,46 @@ Kangaroo = _mk("Kangaroo", DichromatSpec("kangaroo", 0.60, 0.98, post="streak", 
 
 
 class Cat(_Dichromat):
-    """animals/cat.py (Tina-animals side of the unresolved merge, quirk Q8): colour core :95-103,109.
+    """animals/cat.py (Tina-animals side of the unresolved merge, quirk Q8): returns (human_zoomed, cat_wide).
 
-    The human-zoom baseline and the binocular FOV warp (cat.py:74-92) are geometric resampling
-    (SURVEY 8f row 1, cv2.resize / cv2.remap): ENABLE_FOV_WARP defaults to False here until those
-    kernels land, and the baseline returned is the input frame."""
+    human_zoomed = centre zoom of the input (cat.py:74-79, uint8 INTER_LINEAR); cat_wide = binocular wide-FOV
+    warp of the ORIGINAL (cat.py:82-92) -> float64 L/M-merge colour tail -> sigma 1.0 blur -> OETF (cat.py:95-109).
+    With ENABLE_FOV_WARP the warp output is float, so its sRGB decode uses the device powf (final bytes within
+    1 code of the reference); with it off the uint8 path is bit-exact."""
 
     SPEC = DichromatSpec("cat", 0.5, 1.0, color="cat_merge", sigma=1.0)
     CAMERA_HFOV_DEG = 100.0
     CAT_PER_EYE_HALF_FOV_DEG = 105.0
     CAT_OVERLAP_DEG = 40.0
     CAT_TO_HUMAN_RATIO = 1.30
-    ENABLE_FOV_WARP = False
+    ENABLE_FOV_WARP = True
+
+    def visualize(self, image: np.ndarray):
+        assert isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] == 3, "HxWx3 RGB"
+        if image.dtype != np.uint8:
+            raise NotImplementedError(f"Cat: device path implemented for uint8 frames, got {image.dtype}")
+        from .. import geometry as G
+
+        H, W = image.shape[:2]
+        scale = G.zoom_scale_from_cat_ratio(camera_hfov_deg=self.CAMERA_HFOV_DEG, cat_per_eye_half_fov_deg=self.CAT_PER_EYE_HALF_FOV_DEG,
+                                            cat_to_human_ratio=self.CAT_TO_HUMAN_RATIO)
+        human_zoomed = G.center_zoom(image, scale=scale)
+        op = self._operator()
+        if not self.ENABLE_FOV_WARP:
+            return human_zoomed, op(image)
+        ctx = op._ctx()
+        tables = G.binocular_warp_tables(H, W, W, H, self.CAMERA_HFOV_DEG, self.CAT_PER_EYE_HALF_FOV_DEG, self.CAT_OVERLAP_DEG)
+        d_in = ctx.upload(image)
+        d_warp = ctx.malloc(H * W * 3 * 4)
+        d_out = ctx.malloc(H * W * 3)
+        try:
+            G.binocular_warp_device(ctx, d_in, H, W, tables, H, W, d_warp)
+            op.desc.in_f32 = 1
+            try:
+                op.run_device(d_warp, d_out, 1, H, W)
+            finally:
+                op.desc.in_f32 = 0
+            cat_out = ctx.download(d_out, image.shape, np.uint8)
+        finally:
+            d_in.free(); d_warp.free(); d_out.free()
+        return human_zoomed, cat_out

@@ -33,6 +33,7 @@ static void avx_ws_release(avx_ws* w) {
     if (w->d_row_gain) (void)hipFree(w->d_row_gain);
     if (w->uv_small) (void)hipFree(w->uv_small);
     if (w->d_scratch) (void)hipFree(w->d_scratch);
+    if (w->d_geom) (void)hipFree(w->d_geom);
     *w = avx_ws();
 }
 

@@ -19,6 +19,8 @@ struct avx_ws {
     void* uv_small = nullptr;        // UV path: partial statistics, histogram, select state, percentiles
     void* d_scratch = nullptr;       // scratch arena (UV path planes)
     size_t scratch_cap = 0;
+    void* d_geom = nullptr;          // resampling coefficient tables (geom.hip)
+    size_t geom_cap = 0;
 };
 
 struct avx_ctx {

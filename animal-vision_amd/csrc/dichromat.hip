@@ -56,14 +56,21 @@ __global__ __launch_bounds__(kThreads) void dichromat_simple_kernel(DichromatArg
         for (int i = tid; i < AH * AW; i += kThreads) {
             const int ly = i / AW, lx = i - ly * AW;
             const int gy = reflect101(y0 - r + ly, a.H), gx = reflect101(x0 - r + lx, a.W);
-            const uint8_t* p = fin + ((size_t)gy * a.W + gx) * 3;
-            const uint32_t b0 = p[0], b1 = p[1], b2 = p[2];
-            seen_gt1 |= (b0 | b1 | b2) >> 1;
             float c0, c1, c2;
-            if (DARK) {  // get_normalized_image skips /255 when max <= 1: codes 0/1 are 0.0/1.0
-                c0 = b0 ? 1.0f : 0.0f; c1 = b1 ? 1.0f : 0.0f; c2 = b2 ? 1.0f : 0.0f;
+            if (a.in_f32) {  // float32 frame already in [0,1]: srgb_to_linear (animal_utils.py:5-11) in float32
+                const float* pf = reinterpret_cast<const float*>(a.in) + ((size_t)f * a.H * a.W + (size_t)gy * a.W + gx) * 3;
+                auto eotf = [](float v) { return v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f); };
+                c0 = eotf(pf[0]); c1 = eotf(pf[1]); c2 = eotf(pf[2]);
+                seen_gt1 = 1;  // the frame is normalised already: never the all-<=1 branch
             } else {
-                c0 = lut[b0]; c1 = lut[b1]; c2 = lut[b2];
+                const uint8_t* p = fin + ((size_t)gy * a.W + gx) * 3;
+                const uint32_t b0 = p[0], b1 = p[1], b2 = p[2];
+                seen_gt1 |= (b0 | b1 | b2) >> 1;
+                if (DARK) {  // get_normalized_image skips /255 when max <= 1: codes 0/1 are 0.0/1.0
+                    c0 = b0 ? 1.0f : 0.0f; c1 = b1 ? 1.0f : 0.0f; c2 = b2 ? 1.0f : 0.0f;
+                } else {
+                    c0 = lut[b0]; c1 = lut[b1]; c2 = lut[b2];
+                }
             }
             T o0, o1, o2;
             if (COLOR == AVX_COLOR_MATRIX) {
@@ -629,7 +636,8 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
     //          2 = 2-D tiled kernel, 3 = marching strip kernel.  All variants share one arithmetic contract.
     int variant = d->variant;
     { const char* e = getenv("AVX_VARIANT"); if (e && variant == 0) variant = atoi(e); }  // tuning only
-    const bool tunable = d->post_mode == AVX_POST_GAUSS && !d->chroma_enable && (((uintptr_t)in_hwc & 3u) == 0);
+    a.in_f32 = d->in_f32 ? 1 : 0;
+    const bool tunable = !d->in_f32 && d->post_mode == AVX_POST_GAUSS && !d->chroma_enable && (((uintptr_t)in_hwc & 3u) == 0);
     const bool try_march = tunable && (variant == 0 || variant == 3);
     const bool use_tiled = tunable && (variant == 0 || variant == 2);
     const bool cat = d->color_mode == AVX_COLOR_CAT_MERGE;
@@ -653,7 +661,7 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
     // auto: the marching strip kernel wherever an instantiation exists (it beats the 2-D tiled kernel for
     // every species measured); explicit variants are honoured as asked.
     if (d->post_mode == AVX_POST_STREAK) {
-        AVX_REQUIRE(ctx, !cat, "avx_dichromat_u8: AVX_POST_STREAK needs AVX_COLOR_MATRIX");
+        AVX_REQUIRE(ctx, !cat && !d->in_f32, "avx_dichromat_u8: AVX_POST_STREAK needs AVX_COLOR_MATRIX and uint8 input");
         return avx_launch_dichromat_streak(ctx, ws, a, d, s);
     }
     if (try_march) {

@@ -32,6 +32,7 @@ struct DichromatArgs {
     uint32_t* flags;      // per frame: set when any byte > 1 was seen
     unsigned long long* stamps;  // diagnostic builds only (8 accumulators), else NULL
     int ablate;                  // AVX_ABLATE (tuning only): bit mask of phases to skip; 0 in production
+    int in_f32;                  // input is a float32 HWC frame in [0,1] (reference kernel only)
 };
 
 __device__ __forceinline__ int reflect101(int p, int len) {

@@ -1,0 +1,365 @@
+// csrc/geom.hip -- geometric resampling for gfx950: the cv2.resize / cv2.remap /
+// cv2.Sobel call sites on either side of the hot path:
+//   uv_helpers.py:57-64 resize_preserve_range, :84-99 panorama_warp (INTER_CUBIC), :155-183
+//   classic_rgb_to_hsi_scaled (INTER_AREA down, INTER_LINEAR up); animals/cat_widevision_utils.py:11-29
+//   center_zoom (uint8 INTER_LINEAR), :46-99 animal_fov_binocular_warp (2x remap INTER_LINEAR BORDER_CONSTANT +
+//   cos^2 blend); animals/mantis_shrimp.py:122-131 Sobel ksize 3.
+// OpenCV semantics restated from its published algorithm (same statement as oracle/cvref.cpp: PARITY
+// UNPINNED); plain float arithmetic in source order (-ffp-contract=off): bit-exact with the oracle.
+// Coefficient tables are O(W + H) and built on the host inside the entry points.
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "dichromat_common.h"
+
+using namespace avxk;
+
+namespace {
+
+constexpr int kGT = 256;
+
+struct AxisLin { int* ofs; float* f; int dmax; };
+struct AxisCub { int* idx; float* a; };                 // [d][4]
+struct AxisArea { int* start; int* cnt; float* alpha; int maxcnt; };  // alpha [d][maxcnt]
+
+__global__ __launch_bounds__(kGT) void k_resize_linear_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd,
+                                                           AxisLin ax, AxisLin ay) {
+    const size_t total = (size_t)Hd * Wd * C;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
+        const int sx = ax.ofs[x], sy0 = ay.ofs[y], sy1 = sy0 + 1 < H ? sy0 + 1 : sy0;
+        const float a1 = ax.f[x], a0 = 1.f - a1, b1 = ay.f[y], b0 = 1.f - b1;
+        const float* S0 = src + ((size_t)sy0 * W + sx) * C + c;
+        const float* S1 = src + ((size_t)sy1 * W + sx) * C + c;
+        float r0, r1;
+        if (x < ax.dmax) { r0 = S0[0] * a0 + S0[C] * a1; r1 = S1[0] * a0 + S1[C] * a1; }
+        else { r0 = S0[0] * 1.f; r1 = S1[0] * 1.f; }
+        dst[i] = r0 * b0 + r1 * b1;
+    }
+}
+
+__global__ __launch_bounds__(kGT) void k_resize_linear_u8(const uint8_t* __restrict__ src, int H, int W, int C, uint8_t* __restrict__ dst, int Hd, int Wd,
+                                                          AxisLin ax, AxisLin ay) {
+    const size_t total = (size_t)Hd * Wd * C;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
+        const int sx = ax.ofs[x], sy0 = ay.ofs[y], sy1 = sy0 + 1 < H ? sy0 + 1 : sy0;
+        const int a0 = __float2int_rn((1.f - ax.f[x]) * 2048.f), a1 = __float2int_rn(ax.f[x] * 2048.f);  // saturate_cast<short>: |v| <= 2048
+        const int b0 = __float2int_rn((1.f - ay.f[y]) * 2048.f), b1 = __float2int_rn(ay.f[y] * 2048.f);
+        const uint8_t* S0 = src + ((size_t)sy0 * W + sx) * C + c;
+        const uint8_t* S1 = src + ((size_t)sy1 * W + sx) * C + c;
+        int r0, r1;
+        if (x < ax.dmax) { r0 = S0[0] * a0 + S0[C] * a1; r1 = S1[0] * a0 + S1[C] * a1; }
+        else { r0 = S0[0] * 2048; r1 = S1[0] * 2048; }
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        dst[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+__global__ __launch_bounds__(kGT) void k_resize_cubic_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd,
+                                                          AxisCub ax, AxisCub ay) {
+    const size_t total = (size_t)Hd * Wd * C;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
+        const int* ix = ax.idx + 4 * x;
+        const float* a = ax.a + 4 * x;
+        const int* iy = ay.idx + 4 * y;
+        const float* b = ay.a + 4 * y;
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* S = src + (size_t)iy[k] * W * C + c;
+            r[k] = S[(size_t)ix[0] * C] * a[0] + S[(size_t)ix[1] * C] * a[1] + S[(size_t)ix[2] * C] * a[2] + S[(size_t)ix[3] * C] * a[3];
+        }
+        dst[i] = r[0] * b[0] + r[1] * b[1] + r[2] * b[2] + r[3] * b[3];
+    }
+}
+
+__global__ __launch_bounds__(kGT) void k_resize_area_fast_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd,
+                                                              int isx, int isy) {
+    const size_t total = (size_t)Hd * Wd * C;
+    const int area = isx * isy;
+    const float scale = 1.f / area;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
+        const float* S = src + ((size_t)(y * isy) * W + (size_t)x * isx) * C + c;
+        auto at = [&](int k) { const int sy = k / isx, sx = k - sy * isx; return S[((size_t)sy * W + sx) * C]; };
+        float sum = 0;
+        int k = 0;
+        for (; k <= area - 4; k += 4) sum += at(k) + at(k + 1) + at(k + 2) + at(k + 3);  // resizeAreaFast_: groups of four
+        for (; k < area; ++k) sum += at(k);
+        dst[i] = sum * scale;
+    }
+}
+
+__global__ __launch_bounds__(kGT) void k_resize_area_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd,
+                                                         AxisArea ax, AxisArea ay) {
+    const size_t total = (size_t)Hd * Wd * C;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
+        const int x0 = ax.start[x], nx = ax.cnt[x], y0 = ay.start[y], ny = ay.cnt[y];
+        const float* al = ax.alpha + (size_t)x * ax.maxcnt;
+        const float* be = ay.alpha + (size_t)y * ay.maxcnt;
+        float sum = 0.f;
+        for (int j = 0; j < ny; ++j) {
+            const float* S = src + ((size_t)(y0 + j) * W + x0) * C + c;
+            float buf = 0.f;
+            for (int k = 0; k < nx; ++k) buf += S[(size_t)k * C] * al[k];  // ResizeArea_Invoker: buf[dx] += S*alpha
+            sum = j == 0 ? be[j] * buf : sum + be[j] * buf;               // first row of a dy starts the sum
+        }
+        dst[i] = sum;
+    }
+}
+
+// "any byte > 1" per frame (a3 quirk, for paths that need the normalised value before their first kernel)
+__global__ __launch_bounds__(kGT) void k_any_gt1(const uint8_t* __restrict__ in, size_t nbytes, uint32_t* flag) {
+    uint32_t seen = 0;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < nbytes; i += (size_t)gridDim.x * kGT) seen |= in[i] >> 1;
+    if (seen) *flag = 1u;
+}
+
+// animal_fov_binocular_warp (cat_widevision_utils.py:46-99) on a uint8 frame: get_normalized_image, two remaps
+// (INTER_LINEAR, BORDER_CONSTANT 0, 1/32-px quantised coordinates) and the cos^2 blend, -> float32 HWC in [0,1].
+struct WarpArgs { const uint8_t* in; float* out; int H, W, Ho, Wo; const float* xL; const float* xR; const float* ymap; const float* wL; const float* wR;
+                  const uint32_t* flag; };
+
+__device__ __forceinline__ void remap_px(const uint8_t* in, int H, int W, float mx, float my, float norm, float (&o)[3]) {
+    const int fx = __float2int_rn(mx * 32.f), fy = __float2int_rn(my * 32.f);
+    int sx = fx >> 5, sy = fy >> 5;
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+    const float tx = (fx & 31) * (1.f / 32), ty = (fy & 31) * (1.f / 32);
+    const float w0 = (1.f - ty) * (1.f - tx), w1 = (1.f - ty) * tx, w2 = ty * (1.f - tx), w3 = ty * tx;
+    if (sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0) { o[0] = o[1] = o[2] = 0.f; return; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        auto at = [&](int yy, int xx) {
+            if ((unsigned)xx >= (unsigned)W || (unsigned)yy >= (unsigned)H) return 0.f;  // BORDER_CONSTANT, value 0
+            const float v = (float)in[((size_t)yy * W + xx) * 3 + c];
+            const float n = norm == 1.f ? v : v / 255.0f;                                // get_normalized_image
+            return n < 0.f ? 0.f : (n > 1.f ? 1.f : n);
+        };
+        o[c] = at(sy, sx) * w0 + at(sy, sx + 1) * w1 + at(sy + 1, sx) * w2 + at(sy + 1, sx + 1) * w3;
+    }
+}
+
+__global__ __launch_bounds__(kGT) void k_binocular_warp(WarpArgs a) {
+    const float norm = *a.flag ? 255.f : 1.f;  // all bytes <= 1: get_normalized_image does not divide
+    const size_t total = (size_t)a.Ho * a.Wo;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int x = (int)(i % a.Wo), y = (int)(i / a.Wo);
+        float l[3], r[3];
+        remap_px(a.in, a.H, a.W, a.xL[x], a.ymap[y], norm, l);
+        remap_px(a.in, a.H, a.W, a.xR[x], a.ymap[y], norm, r);
+        const float wl = a.wL[x], wr = a.wR[x];
+        const float wsum = (wl + wr) + 1e-8f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (l[c] * wl + r[c] * wr) / wsum;
+            a.out[i * 3 + c] = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        }
+    }
+}
+
+// cv2.Sobel(plane, CV_32F, dx, dy, ksize=3, BORDER_REFLECT_101): small-kernel forms, row filter then column filter
+__global__ __launch_bounds__(kGT) void k_sobel3(const float* __restrict__ src, int H, int W, float* __restrict__ gx, float* __restrict__ gy) {
+    const size_t total = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int x = (int)(i % W), y = (int)(i / W);
+        const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+        float d[3], s[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* R = src + (size_t)reflect101(y - 1 + k, H) * W;
+            d[k] = R[xp] - R[xm];
+            s[k] = R[xm] + R[x] * 2 + R[xp];
+        }
+        gx[i] = d[0] + d[1] * 2 + d[2];
+        gy[i] = s[2] - s[0];
+    }
+}
+
+// ---- host-side coefficient tables (same construction as OpenCV's resizeGeneric_ / computeResizeAreaTab) ----
+struct HostLin { std::vector<int> ofs; std::vector<float> f; int dmax; };
+HostLin host_lin(int ssize, int dsize) {
+    HostLin t; t.ofs.resize(dsize); t.f.resize(dsize); t.dmax = dsize;
+    const double scale = 1.0 / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s + 1 >= ssize) { if (t.dmax > d) t.dmax = d; if (s >= ssize - 1) { f = 0; s = ssize - 1; } }
+        t.ofs[d] = s; t.f[d] = f;
+    }
+    return t;
+}
+void host_cubic(int ssize, int dsize, std::vector<int>& idx, std::vector<float>& a) {
+    idx.resize((size_t)dsize * 4); a.resize((size_t)dsize * 4);
+    const double scale = 1.0 / ((double)dsize / ssize);
+    const float A = -0.75f;
+    for (int d = 0; d < dsize; ++d) {
+        float x = (float)((d + 0.5) * scale - 0.5);
+        const int s = (int)std::floor(x);
+        x -= s;
+        float* c = &a[(size_t)d * 4];
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+        for (int k = 0; k < 4; ++k) { int i = s - 1 + k; idx[(size_t)d * 4 + k] = i < 0 ? 0 : (i >= ssize ? ssize - 1 : i); }
+    }
+}
+void host_area(int ssize, int dsize, std::vector<int>& start, std::vector<int>& cnt, std::vector<float>& alpha, int& maxcnt) {
+    const double scale = (double)ssize / dsize;
+    std::vector<std::vector<std::pair<int, float>>> ent(dsize);
+    maxcnt = 1;
+    for (int dx = 0; dx < dsize; ++dx) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::fmin(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+        sx1 = sx1 < sx2 ? sx1 : sx2;
+        if (sx1 - fsx1 > 1e-3) ent[dx].push_back({sx1 - 1, (float)((sx1 - fsx1) / cell)});
+        for (int sx = sx1; sx < sx2; ++sx) ent[dx].push_back({sx, (float)(1.0 / cell)});
+        if (fsx2 - sx2 > 1e-3) ent[dx].push_back({sx2, (float)(std::fmin(std::fmin(fsx2 - sx2, 1.), cell) / cell)});
+        if ((int)ent[dx].size() > maxcnt) maxcnt = (int)ent[dx].size();
+    }
+    start.assign(dsize, 0); cnt.assign(dsize, 0); alpha.assign((size_t)dsize * maxcnt, 0.f);
+    for (int dx = 0; dx < dsize; ++dx) {
+        cnt[dx] = (int)ent[dx].size();
+        start[dx] = cnt[dx] ? ent[dx][0].first : 0;
+        for (int k = 0; k < cnt[dx]; ++k) alpha[(size_t)dx * maxcnt + k] = ent[dx][k].second;  // entries are consecutive source indices
+    }
+}
+
+int grid_for(avx_ctx* ctx, size_t items) {
+    const size_t want = (items + kGT - 1) / kGT, cap = (size_t)ctx->num_cus * 16;
+    return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+// device copy of small host tables inside the stream's scratch arena (synchronous copies: tables are tiny)
+struct TableArena {
+    avx_ctx* ctx; char* base; size_t off, cap; hipStream_t s;
+    template <typename T> int put(const std::vector<T>& v, T** out) {
+        const size_t bytes = (v.size() * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) return avx_fail(ctx, AVX_ERR_NOMEM, "geometry table arena overflow");
+        *out = reinterpret_cast<T*>(base + off);
+        if (!v.empty()) AVX_HIP(ctx, hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        off += bytes;
+        return AVX_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C, void* dst, int Hd, int Wd, int interp, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, src && dst && src != dst && H > 0 && W > 0 && C > 0 && Hd > 0 && Wd > 0, "avx_resize_hwc: bad arguments");
+    AVX_REQUIRE(ctx, dtype == 0 || dtype == 2, "avx_resize_hwc: dtype must be 0 (float32) or 2 (uint8)");
+    AVX_REQUIRE(ctx, interp >= 1 && interp <= 3, "avx_resize_hwc: interpolation must be 1 LINEAR, 2 CUBIC or 3 AREA");
+    AVX_REQUIRE(ctx, dtype == 0 || interp == 1, "avx_resize_hwc: uint8 supports INTER_LINEAR only");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const size_t tab_bytes = ((size_t)(Wd + Hd) * 48 + 4096) * 4;
+    if (ws->geom_cap < tab_bytes) {
+        if (ws->d_geom) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_geom)); }
+        ws->d_geom = nullptr; ws->geom_cap = 0;
+        AVX_HIP(ctx, hipMalloc(&ws->d_geom, tab_bytes));
+        ws->geom_cap = tab_bytes;
+    }
+    AVX_HIP(ctx, hipStreamSynchronize(s));  // the previous launch may still read the table arena; host vectors below are copied before return
+    TableArena ar{ctx, (char*)ws->d_geom, 0, ws->geom_cap, s};
+    const size_t total = (size_t)Hd * Wd * C;
+    const int g = grid_for(ctx, total);
+    int rc = AVX_OK;
+    if (interp == 3 && (Wd > W || Hd > H)) interp = 1;  // cv::resize: INTER_AREA when enlarging is INTER_LINEAR
+    if (interp == 1) {
+        HostLin hx = host_lin(W, Wd), hy = host_lin(H, Hd);
+        AxisLin ax{nullptr, nullptr, hx.dmax}, ay{nullptr, nullptr, hy.dmax};
+        if ((rc = ar.put(hx.ofs, &ax.ofs)) || (rc = ar.put(hx.f, &ax.f)) || (rc = ar.put(hy.ofs, &ay.ofs)) || (rc = ar.put(hy.f, &ay.f))) return rc;
+        AVX_HIP(ctx, hipStreamSynchronize(s));
+        if (dtype == 0) hipLaunchKernelGGL(k_resize_linear_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
+        else hipLaunchKernelGGL(k_resize_linear_u8, dim3(g), dim3(kGT), 0, s, (const uint8_t*)src, H, W, C, (uint8_t*)dst, Hd, Wd, ax, ay);
+    } else if (interp == 2) {
+        std::vector<int> ix, iy; std::vector<float> cx, cy;
+        host_cubic(W, Wd, ix, cx); host_cubic(H, Hd, iy, cy);
+        AxisCub ax{}, ay{};
+        if ((rc = ar.put(ix, &ax.idx)) || (rc = ar.put(cx, &ax.a)) || (rc = ar.put(iy, &ay.idx)) || (rc = ar.put(cy, &ay.a))) return rc;
+        AVX_HIP(ctx, hipStreamSynchronize(s));
+        hipLaunchKernelGGL(k_resize_cubic_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
+    } else {
+        const double sx = (double)W / Wd, sy = (double)H / Hd;
+        const int isx = (int)std::lrint(sx), isy = (int)std::lrint(sy);
+        if (std::fabs(sx - isx) < DBL_EPSILON && std::fabs(sy - isy) < DBL_EPSILON) {
+            hipLaunchKernelGGL(k_resize_area_fast_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, isx, isy);
+        } else {
+            std::vector<int> sxv, cxv, syv, cyv; std::vector<float> axv, ayv; int mx = 1, my = 1;
+            host_area(W, Wd, sxv, cxv, axv, mx); host_area(H, Hd, syv, cyv, ayv, my);
+            AxisArea ax{nullptr, nullptr, nullptr, mx}, ay{nullptr, nullptr, nullptr, my};
+            if ((rc = ar.put(sxv, &ax.start)) || (rc = ar.put(cxv, &ax.cnt)) || (rc = ar.put(axv, &ax.alpha)) || (rc = ar.put(syv, &ay.start)) ||
+                (rc = ar.put(cyv, &ay.cnt)) || (rc = ar.put(ayv, &ay.alpha))) return rc;
+            AVX_HIP(ctx, hipStreamSynchronize(s));
+            hipLaunchKernelGGL(k_resize_area_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
+        }
+    }
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, const float* xL_host, const float* xR_host, const float* ymap_host,
+                          const float* wL_host, const float* wR_host, int Ho, int Wo, float* out_hwc_f32, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, in_hwc && out_hwc_f32 && xL_host && xR_host && ymap_host && wL_host && wR_host && H > 0 && W > 0 && Ho > 0 && Wo > 0,
+                "avx_binocular_warp_u8: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const size_t tab_bytes = ((size_t)(4 * Wo + Ho) + 1024) * 4 + 4096;
+    if (ws->geom_cap < tab_bytes) {
+        if (ws->d_geom) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_geom)); }
+        ws->d_geom = nullptr; ws->geom_cap = 0;
+        AVX_HIP(ctx, hipMalloc(&ws->d_geom, tab_bytes));
+        ws->geom_cap = tab_bytes;
+    }
+    AVX_HIP(ctx, hipStreamSynchronize(s));
+    float* t = (float*)ws->d_geom;
+    WarpArgs a{};
+    a.in = in_hwc; a.out = out_hwc_f32; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+    float* p = t;
+    auto up = [&](const float* h, int n, const float** d) { *d = p; hipError_t e = hipMemcpyAsync(p, h, sizeof(float) * n, hipMemcpyHostToDevice, s); p += (n + 63) & ~63; return e; };
+    AVX_HIP(ctx, up(xL_host, Wo, &a.xL)); AVX_HIP(ctx, up(xR_host, Wo, &a.xR)); AVX_HIP(ctx, up(wL_host, Wo, &a.wL)); AVX_HIP(ctx, up(wR_host, Wo, &a.wR));
+    AVX_HIP(ctx, up(ymap_host, Ho, &a.ymap));
+    uint32_t* flag = (uint32_t*)p;
+    a.flag = flag;
+    AVX_HIP(ctx, hipMemsetAsync(flag, 0, 4, s));
+    AVX_HIP(ctx, hipStreamSynchronize(s));
+    const size_t nbytes = (size_t)H * W * 3;
+    hipLaunchKernelGGL(k_any_gt1, dim3(grid_for(ctx, nbytes)), dim3(kGT), 0, s, in_hwc, nbytes, flag);
+    hipLaunchKernelGGL(k_binocular_warp, dim3(grid_for(ctx, (size_t)Ho * Wo)), dim3(kGT), 0, s, a);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, plane && gx && gy && H > 0 && W > 0, "avx_sobel3_plane: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    hipLaunchKernelGGL(k_sobel3, dim3(grid_for(ctx, (size_t)H * W)), dim3(kGT), 0, s, plane, H, W, gx, gy);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+}  // extern "C"

@@ -172,7 +172,7 @@ class DichromatOp:
         """N uint8 HWC frames resident in HBM -> N uint8 HWC frames; asynchronous on `stream`."""
         ctx = self._ctx()
         need = n_frames * H * W * 3
-        if d_in.nbytes < need or d_out.nbytes < need:
+        if d_in.nbytes < need * (4 if self.desc.in_f32 else 1) or d_out.nbytes < need:
             raise ValueError("device buffers smaller than n_frames*H*W*3")
         if self.spec.post == "scone":
             if self._gain is None or self._gain.size != H:

@@ -98,6 +98,8 @@ typedef struct avx_dichromat_desc {
                                   [0] k1, [1] k2 (odd tap counts of the sigmaX / sigmaY kernels of that row),
                                   [2..15) k1 float32 taps, [15..48) k2 float32 taps                         */
     int32_t streak_stride;     /* >= 48                                                                  */
+    int32_t in_f32;            /* 1: in_hwc is a float32 HWC frame already normalised to [0,1] (e.g. the output of
+                                  avx_binocular_warp_u8); decoded with the sRGB EOTF in float32 (device powf)   */
 } avx_dichromat_desc;
 
 #define AVX_MAX_KSIZE 33
@@ -160,6 +162,23 @@ typedef struct avx_honeybee_desc {
 /* debug_planes (optional, device, N x 3 x H*W floats): receives U,B,G after adaptation + blur. */
 int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W,
                     const avx_honeybee_desc* desc, float* debug_planes, void* stream);
+
+/* ---- geometric resampling: cv2.resize / cv2.remap / cv2.Sobel call sites ----------------
+ * OpenCV semantics restated from its published algorithm (OpenCV is not available to pin against). */
+
+/* cv2.resize(src, (Wd, Hd), interpolation) on an HWC image (uv_helpers.py:57-64,94,172,182;
+ * cat_widevision_utils.py:26).  dtype 0 = float32 (interp 1 LINEAR, 2 CUBIC a=-0.75, 3 AREA), 2 = uint8 (LINEAR,
+ * 11-bit fixed point). */
+int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C, void* dst, int Hd, int Wd, int interp, void* stream);
+
+/* animal_fov_binocular_warp (cat_widevision_utils.py:46-99) on a uint8 frame: get_normalized_image, two
+ * cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) with per-column x maps / per-row y map, cos^2 blend weights, clip:
+ * -> float32 HWC in [0,1].  Host tables: xL, xR, wL, wR (Wo floats each), ymap (Ho floats). */
+int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, const float* xL_host, const float* xR_host, const float* ymap_host,
+                          const float* wL_host, const float* wR_host, int Ho, int Wo, float* out_hwc_f32, void* stream);
+
+/* cv2.Sobel(plane, CV_32F, 1,0 / 0,1, ksize=3, BORDER_REFLECT101) -> gx, gy (mantis_shrimp.py:122-131). */
+int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
 
 /* ---- MST++ helpers (ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py) ----------------------------
  * Hand-written kernels for the memory-bound parts of the forward pass; PyTorch-ROCm keeps the dense GEMMs/convs.
