@@ -67,6 +67,55 @@ class HoneybeeDesc(ctypes.Structure):
     ]
 
 
+_fp, _dp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+
+
+class MantisDesc(ctypes.Structure):
+    """avx_mantis_desc (include/avx.h)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("n_bands", ctypes.c_int32),
+        ("band_matrix_host", _fp),
+        ("band_lut_host", _fp),
+        ("n_wavelengths", ctypes.c_int32),
+        ("lobe_gains_host", _fp),
+        ("lobe_denom", ctypes.c_float),
+        ("band_weights_host", _fp),
+        ("pano_new_w", ctypes.c_int32),
+        ("hsi_small_h", ctypes.c_int32),
+        ("hsi_small_w", ctypes.c_int32),
+        ("red_keep", ctypes.c_float),
+        ("haze", ctypes.c_float),
+        ("haze_keep", ctypes.c_float),
+        ("haze_tint", ctypes.c_float * 3),
+        ("pre_soft_ksize", ctypes.c_int32),
+        ("pre_soft_taps_host", _dp),
+        ("cos2_global", ctypes.c_float),
+        ("sin2_global", ctypes.c_float),
+        ("orientation_mix", ctypes.c_float),
+        ("pol_linear_strength", ctypes.c_float),
+        ("pol_linear_gamma", ctypes.c_float),
+        ("pol_circular_strength", ctypes.c_float),
+        ("unsharp_ksize", ctypes.c_int32),
+        ("unsharp_taps_host", _dp),
+        ("unsharp_amount", ctypes.c_float),
+        ("barcode_saturation", ctypes.c_float),
+        ("barcode_opacity", ctypes.c_float),
+        ("winner_take_most", ctypes.c_float),
+        ("rows_host", _fp),
+        ("scan_row_gain", ctypes.c_float),
+        ("scan_ksize", ctypes.c_int32),
+        ("scan_taps_host", _dp),
+        ("periph_ksize", ctypes.c_int32),
+        ("periph_taps_host", _dp),
+        ("xx_host", _fp),
+        ("yy_host", _fp),
+        ("periph_radius", ctypes.c_float),
+        ("periph_softness", ctypes.c_float),
+    ]
+
+
 AVX_MAP = {"falsecolor": 0, "custom_matrix": 1, "opponent": 2, "uv_purple_yellow": 3, "falsecolor_uv_mixed": 4}
 
 if not os.path.exists(LIB_PATH):
@@ -128,6 +177,7 @@ _SIGS = {
     "avx_planes_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "avx_rgb_to_hsi_lobes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_float, _vp, _vp]),
     "avx_honeybee_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(HoneybeeDesc), _vp, _vp]),
+    "avx_mantis_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, ctypes.POINTER(MantisDesc), _vp]),
     "avx_resize_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "avx_binocular_warp_u8": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "avx_sobel3_plane": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -5,3 +5,4 @@ from ._dichromats import (  # noqa: F401
     Rat, Sheep, Squirrel, Tiger, Wolf,
 )
 from .honeybee import HoneyBee  # noqa: F401
+from .mantis_shrimp import MantisShrimp  # noqa: F401

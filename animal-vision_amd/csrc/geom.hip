@@ -259,6 +259,33 @@ struct TableArena {
 
 }  // namespace
 
+// uv_helpers.panorama_warp (:84-99): INTER_CUBIC widen to newW, then the centre crop [start, start+W): only the
+// cropped columns are computed (the x table is sliced); the height is unchanged (cubic taps 0,1,0,0: identity).
+int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s) {
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const size_t tab_bytes = ((size_t)(newW + H) * 48 + 4096) * 4;
+    if (ws->geom_cap < tab_bytes) {
+        if (ws->d_geom) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_geom)); }
+        ws->d_geom = nullptr; ws->geom_cap = 0;
+        AVX_HIP(ctx, hipMalloc(&ws->d_geom, tab_bytes));
+        ws->geom_cap = tab_bytes;
+    }
+    AVX_HIP(ctx, hipStreamSynchronize(s));
+    TableArena ar{ctx, (char*)ws->d_geom, 0, ws->geom_cap, s};
+    std::vector<int> ix, iy; std::vector<float> cx, cy;
+    host_cubic(W, newW, ix, cx); host_cubic(H, H, iy, cy);
+    AxisCub ax{}, ay{};
+    int rc;
+    if ((rc = ar.put(ix, &ax.idx)) || (rc = ar.put(cx, &ax.a)) || (rc = ar.put(iy, &ay.idx)) || (rc = ar.put(cy, &ay.a))) return rc;
+    AVX_HIP(ctx, hipStreamSynchronize(s));
+    ax.idx += 4 * (size_t)start;
+    ax.a += 4 * (size_t)start;
+    hipLaunchKernelGGL(k_resize_cubic_f32, dim3(grid_for(ctx, (size_t)H * W * 3)), dim3(kGT), 0, s, src, H, W, 3, dst, H, W, ax, ay);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 extern "C" {
 
 int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C, void* dst, int Hd, int Wd, int interp, void* stream) {

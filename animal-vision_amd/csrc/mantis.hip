@@ -1,0 +1,321 @@
+// csrc/mantis.hip -- MantisShrimp.visualize (animals/mantis_shrimp.py:143-279) on the device: the band stack and
+// spectral "barcode" (a17/a22) and the polarisation / unsharp / scanline / periphery finish (a23), chained from
+// the shared building blocks (decode table, cubic panorama warp, area/linear resize, plane blur, Sobel,
+// radix-select percentile, threshold encode).  Float contract: within 1e-4 relative of the reference; the
+// categorical `argmax` of :202 can differ where two band maps tie to within rounding.
+#include <cmath>
+#include <vector>
+
+#include "dichromat_common.h"
+
+using namespace avxk;
+
+// from uv.hip / geom.hip (same library)
+int avx_uv_percentile_device(avx_ctx* ctx, const float* x, size_t n, double q, double* out_dev, hipStream_t s);
+int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize, const double* taps_host, hipStream_t s);
+extern "C" int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C, void* dst, int Hd, int Wd, int interp, void* stream);
+extern "C" int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
+int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s);
+
+namespace {
+
+constexpr int kMT = 256;
+constexpr int KMAX = 16;
+
+__device__ __forceinline__ float s2l(float v) { return v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float clip01f(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+
+__global__ __launch_bounds__(kMT) void k_decode_lin(const uint8_t* __restrict__ in, const float* __restrict__ lut_g, size_t n3, float* __restrict__ out) {
+    __shared__ float lut[256];
+    for (int i = threadIdx.x; i < 256; i += kMT) lut[i] = lut_g[i];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n3; i += (size_t)gridDim.x * kMT) out[i] = lut[in[i]];
+}
+
+// from_float01(linear_to_srgb(clip(x, 0, 1)), uint8) (mantis_shrimp.py:153,278) as the threshold count
+__global__ __launch_bounds__(kMT) void k_encode_hwc(const float* __restrict__ in, size_t n3, const float* __restrict__ thr_g, const uint8_t* __restrict__ coarse_g,
+                                                    uint32_t lo_key, uint8_t* __restrict__ out) {
+    __shared__ float thr[256];
+    __shared__ uint8_t coarse[1024];
+    for (int i = threadIdx.x; i < 256; i += kMT) thr[i] = thr_g[i];
+    for (int i = threadIdx.x; i < 1024; i += kMT) coarse[i] = coarse_g[i];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n3; i += (size_t)gridDim.x * kMT)
+        out[i] = (uint8_t)quantize_coarse<float, 2>(in[i], thr, coarse, lo_key);
+}
+
+// classic_rgb_to_hsi on an ALREADY-LINEAR float frame (quirk Q6: linearised again) folded with the K band-pass
+// windows: stack[p][k] = sum_j M[k][j] * s2l(lin[p][j])   (HxWxK, the reference's S layout before safe_norm).
+// A pixel with a negative channel (cubic overshoot of the panorama warp) takes the band-by-band route, where
+// the per-wavelength clamp_min(0) of classic_rgb_to_hsi.py:81 is applied before the band-pass sum.
+struct StackArgs { const float* lin; size_t n; const float* M; int K; int B; const float* gains; float denom; const float* wts; float* out; };
+__global__ __launch_bounds__(kMT) void k_rgbf_to_stack(StackArgs a) {
+    __shared__ float M[KMAX * 3];
+    for (int i = threadIdx.x; i < a.K * 3; i += kMT) M[i] = a.M[i];
+    __syncthreads();
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
+        const float c0 = s2l(a.lin[3 * p]), c1 = s2l(a.lin[3 * p + 1]), c2 = s2l(a.lin[3 * p + 2]);
+        if (c0 >= 0.f && c1 >= 0.f && c2 >= 0.f) {
+            for (int k = 0; k < a.K; ++k) a.out[p * a.K + k] = fma_t(c2, M[3 * k + 2], fma_t(c1, M[3 * k + 1], c0 * M[3 * k]));
+        } else {
+            for (int k = 0; k < a.K; ++k) {
+                float acc = 0.f;
+                for (int b = 0; b < a.B; ++b) {
+                    const float w = a.wts[(size_t)k * a.B + b];
+                    if (w != 0.f) {
+                        const float spec = ((a.gains[3 * b + 2] * c2 + a.gains[3 * b + 1] * c1) + a.gains[3 * b] * c0) / a.denom;
+                        acc = fma_t(spec > 0.f ? spec : 0.f, w, acc);
+                    }
+                }
+                a.out[p * a.K + k] = acc;
+            }
+        }
+    }
+}
+
+// per-channel min/max of an HxWxK stack -> mm[k] = {min, max} (two-level, deterministic)
+__global__ __launch_bounds__(kMT) void k_stack_minmax(const float* __restrict__ S, size_t n, int K, float2* __restrict__ partial) {
+    __shared__ float smn[kMT / 64][KMAX], smx[kMT / 64][KMAX];
+    float mn[KMAX], mx[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; }
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < n; p += (size_t)gridDim.x * kMT)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) { const float v = S[p * K + k]; mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < K; ++k) {
+        float a = mn[k], b = mx[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+        if (lane == 0) { smn[wave][k] = a; smx[wave][k] = b; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        float a = smn[0][threadIdx.x], b = smx[0][threadIdx.x];
+        for (int w = 1; w < kMT / 64; ++w) { a = fminf(a, smn[w][threadIdx.x]); b = fmaxf(b, smx[w][threadIdx.x]); }
+        partial[(size_t)blockIdx.x * K + threadIdx.x] = make_float2(a, b);
+    }
+}
+__global__ void k_stack_minmax_final(const float2* partial, int nblocks, int K, float2* mm) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (k >= K) return;
+    float a = 3.4e38f, b = -3.4e38f;
+    for (int i = lane; i < nblocks; i += 64) { const float2 v = partial[(size_t)i * K + k]; a = fminf(a, v.x); b = fmaxf(b, v.y); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+    if (lane == 0) mm[k] = make_float2(a, b);
+}
+// safe_norm per band, in place (uv_helpers.py:47-53)
+__global__ __launch_bounds__(kMT) void k_stack_safe_norm(float* __restrict__ S, size_t n, int K, const float2* __restrict__ mm) {
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n * K; i += (size_t)gridDim.x * kMT) {
+        const float2 m = mm[i % K];
+        S[i] = (m.y - m.x) < 1e-9f ? 0.f : (S[i] - m.x) / (m.y - m.x);
+    }
+}
+
+struct BarcodeArgs { const float* S; size_t n; int K; const double* p95; float lut[KMAX * 3]; float wtm, sat; float* bar /*3 planes*/; float* broad; };
+// mantis_shrimp.py:199-211,224: S_norm, argmax, soft/hard tint, saturation; broad = mean(S_norm)
+__global__ __launch_bounds__(kMT) void k_barcode(BarcodeArgs a) {
+    const float den = (float)a.p95[0] + 1e-8f;
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
+        float sn[KMAX];
+        float sum = 0.f, best = -1.f;
+        int arg = 0;
+        for (int k = 0; k < a.K; ++k) {
+            sn[k] = clip01f(a.S[p * a.K + k] / den);
+            sum += sn[k];
+            if (sn[k] > best) { best = sn[k]; arg = k; }  // np.argmax: first maximum
+        }
+        const float wden = sum + 1e-8f;
+        float soft[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < a.K; ++k) {
+            const float w = sn[k] / wden;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) soft[c] = fma_t(w, a.lut[3 * k + c], soft[c]);
+        }
+        float bc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bc[c] = (1.0f - a.wtm) * soft[c] + a.wtm * a.lut[3 * arg + c];
+        const float Yb = (0.2126f * bc[0] + 0.7152f * bc[1]) + 0.0722f * bc[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.bar[(size_t)c * a.n + p] = clip01f(Yb + (bc[c] - Yb) * (1.0f + a.sat));
+        a.broad[p] = sum / (float)a.K;
+    }
+}
+
+// :214-218 render = baseline_lin with red kill and haze, HWC -> 3 planes
+__global__ __launch_bounds__(kMT) void k_prep_render(const float* __restrict__ lin, size_t n, float red_keep, float haze, float haze_keep, float3 tint, float* __restrict__ P) {
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < n; p += (size_t)gridDim.x * kMT) {
+        float v[3] = {clip01f(lin[3 * p] * red_keep), lin[3 * p + 1], lin[3 * p + 2]};
+        const float t[3] = {tint.x, tint.y, tint.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[(size_t)c * n + p] = haze > 0.f ? haze_keep * v[c] + haze * t[c] : v[c];
+    }
+}
+
+struct PolArgs { const float* gx; const float* gy; size_t n; float cos2g, sin2g, mix, lin_s, lin_gamma, circ_s; float* gain; };
+// :226-242
+__global__ __launch_bounds__(kMT) void k_polgain(PolArgs a) {
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
+        const float theta = atan2f(a.gy[p], a.gx[p]);
+        const float c2 = cosf(2.0f * theta), s2 = sinf(2.0f * theta);
+        const float cm = a.cos2g + a.mix * c2, sm = a.sin2g + a.mix * s2;  // cos2g/sin2g arrive as float32((1-mix)*global)
+        const float al = powf(clip01f(0.5f * (cm + 1.0f)), a.lin_gamma);
+        const float ac = clip01f(0.5f * (sm + 1.0f));
+        a.gain[p] = (1.0f + a.lin_s * al) + a.circ_s * ac;
+    }
+}
+
+// :244-250: unsharp guided by pol_gain, then the barcode blend
+__global__ __launch_bounds__(kMT) void k_unsharp_blend(const float* __restrict__ P, const float* __restrict__ Bl, const float* __restrict__ gain, const float* __restrict__ bar,
+                                                       size_t n, float amount, int do_unsharp, float opacity, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < 3 * n; i += (size_t)gridDim.x * kMT) {
+        float r = P[i];
+        if (do_unsharp) {
+            float high = r - Bl[i];
+            high = high < -1.f ? -1.f : (high > 1.f ? 1.f : high);
+            r = clip01f(r + (amount * gain[i % n]) * high);
+        }
+        out[i] = clip01f((1.0f - opacity) * r + opacity * bar[i]);
+    }
+}
+
+__global__ __launch_bounds__(kMT) void k_rows_plane(const float* __restrict__ rows, int H, int W, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < (size_t)H * W; i += (size_t)gridDim.x * kMT) out[i] = rows[i / W] * 1.0f;
+}
+// :264-265
+__global__ __launch_bounds__(kMT) void k_scan_gain(float* __restrict__ P, const float* __restrict__ rows, size_t n, float gain) {
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < 3 * n; i += (size_t)gridDim.x * kMT)
+        P[i] = clip01f(P[i] * (1.0f + gain * (rows[i % n] - 0.5f)));
+}
+
+struct FinishArgs { const float* P; const float* periph; int H, W; const float* xx; const float* yy; float softness, radius; int do_periph;
+                    const float* thr; const uint8_t* coarse; uint32_t lo_key; uint8_t* out; };
+// :268-278: radial sigmoid blend with the blurred copy, then encode
+__global__ __launch_bounds__(kMT) void k_finish(FinishArgs a) {
+    __shared__ float thr[256];
+    __shared__ uint8_t coarse[1024];
+    for (int i = threadIdx.x; i < 256; i += kMT) thr[i] = a.thr[i];
+    for (int i = threadIdx.x; i < 1024; i += kMT) coarse[i] = a.coarse[i];
+    __syncthreads();
+    const size_t n = (size_t)a.H * a.W;
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < n; p += (size_t)gridDim.x * kMT) {
+        float t = 0.f;
+        if (a.do_periph) {
+            const float xx = a.xx[p % a.W], yy = a.yy[p / a.W];
+            const float r = __fsqrt_rn(xx * xx + yy * yy);
+            t = 1.0f / (1.0f + expf(-a.softness * (r - a.radius)));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = a.P[(size_t)c * n + p];
+            if (a.do_periph) v = (1.0f - t) * v + t * a.periph[(size_t)c * n + p];
+            a.out[p * 3 + c] = (uint8_t)quantize_coarse<float, 2>(v, thr, coarse, a.lo_key);
+        }
+    }
+}
+
+int grid_for(avx_ctx* ctx, size_t items) {
+    const size_t want = (items + kMT - 1) / kMT, cap = (size_t)ctx->num_cus * 16;
+    return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_mantis_desc), "avx_mantis_u8: desc is NULL or struct_size mismatch");
+    AVX_REQUIRE(ctx, in_hwc && out_base_hwc && out_hwc && H > 0 && W > 0, "avx_mantis_u8: bad arguments");
+    AVX_REQUIRE(ctx, d->n_bands >= 1 && d->n_bands <= KMAX && d->band_matrix_host && d->band_lut_host, "avx_mantis_u8: bad band tables");
+    AVX_REQUIRE(ctx, d->n_wavelengths >= 1 && d->lobe_gains_host && d->band_weights_host && d->lobe_denom > 0.f, "avx_mantis_u8: per-wavelength tables missing");
+    AVX_REQUIRE(ctx, d->rows_host && d->xx_host && d->yy_host, "avx_mantis_u8: row/column tables missing");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const int K = d->n_bands;
+    const size_t n = (size_t)H * W;
+    const int newW = d->pano_new_w > 0 ? d->pano_new_w : W;
+    const int hs = d->hsi_small_h > 0 ? d->hsi_small_h : H, wsm = d->hsi_small_w > 0 ? d->hsi_small_w : W;
+    const size_t nsmall = (size_t)hs * wsm;
+    // scratch layout (floats)
+    size_t off = 0;
+    auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 63) & ~(size_t)63; return o; };
+    const size_t o_lin0 = take(3 * n), o_wide = take(3 * (size_t)H * newW), o_base = take(3 * n), o_small = take(3 * nsmall), o_sstack = take(nsmall * K),
+                 o_stack = take(n * K), o_bar = take(3 * n), o_broad = take(n), o_gx = take(n), o_gy = take(n), o_gain = take(n), o_P0 = take(3 * n),
+                 o_P1 = take(3 * n), o_P2 = take(3 * n), o_rows = take(n), o_rowsb = take(n), o_tab = take((size_t)K * 3 + H + W + H + (size_t)d->n_wavelengths * (3 + K) + 64),
+                 o_part = take((size_t)ctx->num_cus * 16 * K * 2 + 64), o_mm = take(2 * KMAX + 64), o_pct = take(64);
+    int rc = avx_ensure_scratch(ctx, ws, off * sizeof(float));
+    if (rc) return rc;
+    float* base = (float*)ws->d_scratch;
+    float *lin0 = base + o_lin0, *wide = base + o_wide, *blin = base + o_base, *small = base + o_small, *sstack = base + o_sstack, *stack = base + o_stack,
+          *bar = base + o_bar, *broad = base + o_broad, *gx = base + o_gx, *gy = base + o_gy, *gain = base + o_gain, *P0 = base + o_P0, *P1 = base + o_P1,
+          *P2 = base + o_P2, *rowsp = base + o_rows, *rowsb = base + o_rowsb, *tab = base + o_tab;
+    float2* part = (float2*)(base + o_part);
+    float2* mm = (float2*)(base + o_mm);
+    double* pct = (double*)(base + o_pct);
+    const int B = d->n_wavelengths;
+    float* dM = tab; float* drows = tab + K * 3; float* dxx = drows + H; float* dyy = dxx + W; float* dgains = dyy + H; float* dwts = dgains + 3 * B;
+    AVX_HIP(ctx, hipMemcpyAsync(dgains, d->lobe_gains_host, sizeof(float) * B * 3, hipMemcpyHostToDevice, s));
+    AVX_HIP(ctx, hipMemcpyAsync(dwts, d->band_weights_host, sizeof(float) * B * K, hipMemcpyHostToDevice, s));
+    AVX_HIP(ctx, hipMemcpyAsync(dM, d->band_matrix_host, sizeof(float) * K * 3, hipMemcpyHostToDevice, s));
+    AVX_HIP(ctx, hipMemcpyAsync(drows, d->rows_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
+    AVX_HIP(ctx, hipMemcpyAsync(dxx, d->xx_host, sizeof(float) * W, hipMemcpyHostToDevice, s));
+    AVX_HIP(ctx, hipMemcpyAsync(dyy, d->yy_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
+    const int g = grid_for(ctx, n);
+    // 1) to_float01 + srgb_to_linear (:148-149)
+    hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, lin0);
+    // 2) panorama warp (:152): INTER_CUBIC widen + centre crop
+    const float* baseline = lin0;
+    if (newW != W) {
+        if ((rc = avx_geom_panorama_cubic(ctx, lin0, H, W, newW, (newW - W) / 2, blin, s))) return rc;
+        baseline = blin;
+    }
+    (void)wide;
+    hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, baseline, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_base_hwc);
+    // 3-4) RGB->HSI (optionally at reduced size) folded with the band windows -> HxWxK stack, safe_norm per band
+    if (hs != H || wsm != W) {
+        if ((rc = avx_resize_hwc(ctx, baseline, 0, H, W, 3, small, hs, wsm, 3, s))) return rc;
+        hipLaunchKernelGGL(k_rgbf_to_stack, dim3(grid_for(ctx, nsmall)), dim3(kMT), 0, s, StackArgs{small, nsmall, dM, K, B, dgains, d->lobe_denom, dwts, sstack});
+        if ((rc = avx_resize_hwc(ctx, sstack, 0, hs, wsm, K, stack, H, W, 1, s))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_rgbf_to_stack, dim3(g), dim3(kMT), 0, s, StackArgs{baseline, n, dM, K, B, dgains, d->lobe_denom, dwts, stack});
+    }
+    hipLaunchKernelGGL(k_stack_minmax, dim3(g), dim3(kMT), 0, s, stack, n, K, part);
+    hipLaunchKernelGGL(k_stack_minmax_final, dim3(1), dim3(1024), 0, s, part, g, K, mm);
+    hipLaunchKernelGGL(k_stack_safe_norm, dim3(grid_for(ctx, n * K)), dim3(kMT), 0, s, stack, n, K, mm);
+    // 5-6) barcode
+    if ((rc = avx_uv_percentile_device(ctx, stack, n * K, 95.0, pct, s))) return rc;
+    BarcodeArgs b{};
+    b.S = stack; b.n = n; b.K = K; b.p95 = pct; b.wtm = d->winner_take_most; b.sat = d->barcode_saturation; b.bar = bar; b.broad = broad;
+    for (int i = 0; i < K * 3; ++i) b.lut[i] = d->band_lut_host[i];
+    hipLaunchKernelGGL(k_barcode, dim3(g), dim3(kMT), 0, s, b);
+    // 7) clear-water look
+    hipLaunchKernelGGL(k_prep_render, dim3(g), dim3(kMT), 0, s, baseline, n, d->red_keep, d->haze, d->haze_keep, make_float3(d->haze_tint[0], d->haze_tint[1], d->haze_tint[2]), P0);
+    float* render = P0;
+    if (d->pre_soft_ksize > 0) { if ((rc = avx_uv_plane_blur_device(ctx, P0, P1, 3, H, W, d->pre_soft_ksize, d->pre_soft_taps_host, s))) return rc; render = P1; }
+    // 8) polarisation gain
+    if ((rc = avx_sobel3_plane(ctx, broad, H, W, gx, gy, s))) return rc;
+    PolArgs pa{gx, gy, n, d->cos2_global, d->sin2_global, d->orientation_mix, d->pol_linear_strength, d->pol_linear_gamma, d->pol_circular_strength, gain};
+    hipLaunchKernelGGL(k_polgain, dim3(g), dim3(kMT), 0, s, pa);
+    float* other = render == P0 ? P1 : P0;
+    const int do_unsharp = d->unsharp_ksize > 0 && d->unsharp_amount > 0.f;
+    if (do_unsharp) { if ((rc = avx_uv_plane_blur_device(ctx, render, other, 3, H, W, d->unsharp_ksize, d->unsharp_taps_host, s))) return rc; }
+    // 9) barcode blend
+    hipLaunchKernelGGL(k_unsharp_blend, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, render, other, gain, bar, n, d->unsharp_amount, do_unsharp, d->barcode_opacity, P2);
+    // 10) scanlines
+    if (d->scan_row_gain != 0.f) {
+        hipLaunchKernelGGL(k_rows_plane, dim3(g), dim3(kMT), 0, s, drows, H, W, rowsp);
+        const float* rr = rowsp;
+        if (d->scan_ksize > 0) { if ((rc = avx_uv_plane_blur_device(ctx, rowsp, rowsb, 1, H, W, d->scan_ksize, d->scan_taps_host, s))) return rc; rr = rowsb; }
+        hipLaunchKernelGGL(k_scan_gain, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, P2, rr, n, d->scan_row_gain);
+    }
+    // 11-12) periphery + encode
+    const int do_periph = d->periph_ksize > 0;
+    if (do_periph) { if ((rc = avx_uv_plane_blur_device(ctx, P2, P0, 3, H, W, d->periph_ksize, d->periph_taps_host, s))) return rc; }
+    FinishArgs fa{P2, P0, H, W, dxx, dyy, d->periph_softness, d->periph_radius, do_periph, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_hwc};
+    hipLaunchKernelGGL(k_finish, dim3(g), dim3(kMT), 0, s, fa);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}

@@ -550,6 +550,28 @@ static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size
     return AVX_OK;
 }
 
+// ---- internal entry points for other translation units of the library (mantis.hip) ---------------------
+int avx_uv_percentile_device(avx_ctx* ctx, const float* x, size_t n, double q, double* out_dev, hipStream_t s) {
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, s, &u);
+    if (rc) return rc;
+    return run_percentile(ctx, u, x, n, q, out_dev, s);
+}
+
+int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize, const double* taps_host, hipStream_t s) {
+    BlurArgs a{};
+    a.in = in; a.out = out; a.K = K; a.H = H; a.W = W; a.r = ksize / 2; a.stats = nullptr; a.scale_mode = 0;
+    for (int i = 0; i < ksize && i < AVX_MAX_KSIZE; ++i) a.taps[i] = ksize == 1 ? 1.0f : (float)taps_host[i];
+    const int AW = 64 + 2 * a.r, AH = 32 + 2 * a.r;
+    const size_t lds = sizeof(float) * ((size_t)AH * AW + (size_t)AH * 64);
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_plane_blur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long tiles = (long)((W + 63) / 64) * ((H + 31) / 32) * K;
+    const int g = (int)(tiles < (long)ctx->num_cus * 4 ? tiles : (long)ctx->num_cus * 4);
+    hipLaunchKernelGGL(k_plane_blur, dim3(g), dim3(kT), lds, s, a);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 extern "C" {
 
 int avx_percentile(avx_ctx* ctx, const float* data, size_t n, double q, double* out_host, void* stream) {

@@ -180,6 +180,39 @@ int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, con
 /* cv2.Sobel(plane, CV_32F, 1,0 / 0,1, ksize=3, BORDER_REFLECT101) -> gx, gy (mantis_shrimp.py:122-131). */
 int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
 
+/* MantisShrimp.visualize (animals/mantis_shrimp.py:143-279) for one uint8 frame, all passes on the device:
+ * decode -> panorama warp -> baseline encode; RGB->HSI (optionally at hsi_scale) x band windows -> safe_norm stack
+ * -> P95 -> barcode tint; red kill / haze / pre-soft blur; Sobel polarisation gain; unsharp; barcode blend;
+ * scanlines; peripheral blur blend; encode.  All O(bands), O(H), O(W) tables are built by the host. */
+typedef struct avx_mantis_desc {
+    uint32_t struct_size;
+    int32_t n_bands;                   /* N <= 16 (mantis_shrimp.py:49-60: 10)                                  */
+    const float* band_matrix_host;     /* N x 3: band-pass windows folded with the analytic lobes (input-channel order) */
+    const float* band_lut_host;        /* N x 3: the hue LUT of :175-197                                        */
+    int32_t n_wavelengths;             /* B: the per-wavelength tables below serve pixels with a negative channel (cubic
+                                          overshoot), where clamp_min(0) of classic_rgb_to_hsi.py:81 is not the identity */
+    const float* lobe_gains_host;      /* B x 3 lobe gains (column j multiplies input channel j)                 */
+    float lobe_denom;                  /* the scalar denominator of classic_rgb_to_hsi.py:73-79 (+1e-8)          */
+    const float* band_weights_host;    /* N x B band-pass weights (uv_helpers.py:125-139)                        */
+    int32_t pano_new_w;                /* widened width of panorama_warp (0 / W: no warp)                        */
+    int32_t hsi_small_h, hsi_small_w;  /* classic_rgb_to_hsi_scaled size (0: full resolution)                    */
+    float red_keep;                    /* float32(1 - red_kill)                                                 */
+    float haze, haze_keep, haze_tint[3];
+    int32_t pre_soft_ksize; const double* pre_soft_taps_host;
+    float cos2_global, sin2_global;    /* float32((1 - mix) * cos/sin(2 * evec_angle))                          */
+    float orientation_mix, pol_linear_strength, pol_linear_gamma, pol_circular_strength;
+    int32_t unsharp_ksize; const double* unsharp_taps_host; float unsharp_amount;
+    float barcode_saturation, barcode_opacity, winner_take_most;
+    const float* rows_host;            /* H: 0.5 + 0.5 sin(2 pi f y) (:257-258)                                  */
+    float scan_row_gain; int32_t scan_ksize; const double* scan_taps_host;
+    int32_t periph_ksize; const double* periph_taps_host;
+    const float* xx_host; const float* yy_host; /* W, H: linspace(-1, 1) (:270-271)                              */
+    float periph_radius, periph_softness;
+} avx_mantis_desc;
+
+int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_baseline_hwc, uint8_t* out_hwc, int H, int W,
+                  const avx_mantis_desc* desc, void* stream);
+
 /* ---- MST++ helpers (ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py) ----------------------------
  * Hand-written kernels for the memory-bound parts of the forward pass; PyTorch-ROCm keeps the dense GEMMs/convs.
  * Pointers are torch tensors' data_ptr(); dtype 0 = float32, 1 = float16; all on `stream` (torch's current stream). */

@@ -1,0 +1,61 @@
+"""GPU: MantisShrimp.visualize on the device (csrc/mantis.hip) vs the reference's re-enacted outputs
+(tests/golden/mantis.npz, produced by the imported reference class) and vs the oracle on other shapes/parameters.
+
+Contract: the baseline (decode -> cubic panorama warp -> encode) is bit-exact; the stylised frame is a
+float pipeline held to 1e-4 relative before the uint8 encode, i.e. codes within +-1, except where the categorical
+`argmax` band of mantis_shrimp.py:202 ties to within rounding (hard tint flips: a bounded handful of pixels)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(got, want, what):
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    frac_off = float((diff > 1).mean())
+    assert frac_off <= 2e-3, (what, "fraction beyond +-1:", frac_off, "max", int(diff.max()))
+    assert float((diff > 0).mean()) <= 0.05, (what, "fraction != :", float((diff > 0).mean()))
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("noresample", dict(hsi_scale=1.0, panorama_scale=1.0))])
+def test_mantis_vs_reference_golden(tag, kw):
+    from animal_vision_amd.animals import MantisShrimp
+
+    g = load_golden("mantis")
+    m = MantisShrimp(**kw)
+    for k in ("s64", "n50"):
+        base, out = m.visualize(g[f"in_{k}"])
+        assert base.dtype == np.uint8 and out.dtype == np.uint8 and base.shape == out.shape == g[f"in_{k}"].shape
+        assert np.array_equal(base, g[f"{tag}_base_{k}"]), (tag, k, "baseline")
+        _check(out, g[f"{tag}_out_{k}"], (tag, k))
+
+
+@pytest.mark.parametrize("shape,kw", [
+    ((96, 128, 3), {}),
+    ((90, 121, 3), dict(hsi_scale=0.5, panorama_scale=1.3, winner_take_most=1.0, orientation_mix=1.0)),
+    ((72, 100, 3), dict(pre_soft_sigma=0.0, unsharp_amount=0.0, scan_row_gain=0.0, periph_blur_sigma=0.0, haze_strength=0.0)),
+    ((64, 64, 3), dict(bands=((400.0, 500.0), (500.0, 600.0), (600.0, 700.0)), lambdas=np.linspace(400.0, 700.0, 31), scan_soften=0.0)),
+    ((270, 480, 3), {}),
+])
+def test_mantis_vs_oracle(oracle, shape, kw):
+    from animal_vision_amd.animals import MantisShrimp
+
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    yy, xx = np.mgrid[0 : shape[0], 0 : shape[1]]
+    smooth = (127 + 100 * np.sin(xx / 9.0)[..., None] * np.cos(yy[..., None] / 7.0 + np.arange(3))).clip(0, 255)
+    frame = (0.7 * smooth + 0.3 * rng.integers(0, 256, shape)).astype(np.uint8)
+    base, out = MantisShrimp(**kw).visualize(frame)
+    wbase, wout = oracle.mantis_visualize(frame, **kw)
+    assert np.array_equal(base, wbase)
+    _check(out, wout, (shape, kw))
+
+
+def test_mantis_rejects_non_uint8_and_bad_panorama():
+    from animal_vision_amd.animals import MantisShrimp
+
+    with pytest.raises(NotImplementedError):
+        MantisShrimp().visualize(np.zeros((8, 8, 3), np.float32))
+    with pytest.raises(ValueError):
+        MantisShrimp(panorama_scale=0.8).visualize(np.zeros((16, 16, 3), np.uint8))
