@@ -116,6 +116,55 @@ class MantisDesc(ctypes.Structure):
     ]
 
 
+class BandStackDesc(ctypes.Structure):
+    """avx_band_stack_desc (include/avx.h)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("n_bands", ctypes.c_int32),
+        ("band_matrix_host", _fp),
+        ("n_wavelengths", ctypes.c_int32),
+        ("lobe_gains_host", _fp),
+        ("lobe_denom", ctypes.c_float),
+        ("band_weights_host", _fp),
+        ("small_h", ctypes.c_int32),
+        ("small_w", ctypes.c_int32),
+    ]
+
+
+class EwInsn(ctypes.Structure):
+    _fields_ = [("op", ctypes.c_uint8), ("dst", ctypes.c_uint8), ("a", ctypes.c_uint8), ("b", ctypes.c_uint8), ("imm", ctypes.c_uint32)]
+
+
+class EwPlane(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("stride", ctypes.c_int32), ("kind", ctypes.c_int32)]
+
+
+class EwProgram(ctypes.Structure):
+    """avx_ew_program (include/avx.h)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("H", ctypes.c_int32),
+        ("W", ctypes.c_int32),
+        ("n_insn", ctypes.c_int32),
+        ("insn_host", ctypes.POINTER(EwInsn)),
+        ("n_planes", ctypes.c_int32),
+        ("planes_host", ctypes.POINTER(EwPlane)),
+        ("n_acc", ctypes.c_int32),
+        ("acc_host", ctypes.POINTER(ctypes.c_int32)),
+        ("scalars_dev", ctypes.c_void_p),
+        ("n_scalars", ctypes.c_int32),
+    ]
+
+
+AVX_EW_MAX_INSN, AVX_EW_MAX_PLANES, AVX_EW_MAX_REGS, AVX_EW_MAX_ACC = 384, 24, 32, 16
+_EW_OPS = ("CONST SCALAR LOAD STORE ADD SUB MUL DIV MIN MAX POW ATAN2 NEG ABS SQRT EXP LOG SIN COS FLOOR CEIL CLIP01 TANH "
+           "LT LE GT GE EQ AND OR NOT SELECT ACCMIN ACCMAX ACCSUM").split()
+EW = {name: i + 1 for i, name in enumerate(_EW_OPS)}  # enum in include/avx.h starts at AVX_EW_CONST = 1
+EW_PLANE = {"f32": 0, "u8": 1, "u8_lut": 2, "col": 3, "row": 4, "u8_enc": 5}
+EW_ACC = {"min": 0, "max": 1, "sum": 2, "mean": 3}
+
 AVX_MAP = {"falsecolor": 0, "custom_matrix": 1, "opponent": 2, "uv_purple_yellow": 3, "falsecolor_uv_mixed": 4}
 
 if not os.path.exists(LIB_PATH):
@@ -177,6 +226,10 @@ _SIGS = {
     "avx_planes_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "avx_rgb_to_hsi_lobes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_float, _vp, _vp]),
     "avx_honeybee_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(HoneybeeDesc), _vp, _vp]),
+    "avx_uv_front_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "avx_band_stack": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(BandStackDesc), _vp, _vp]),
+    "avx_percentile_dev": (_i, [_vp, _vp, _sz, ctypes.c_double, _vp, _vp]),
+    "avx_ew_run": (_i, [_vp, ctypes.POINTER(EwProgram), _vp]),
     "avx_mantis_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, ctypes.POINTER(MantisDesc), _vp]),
     "avx_resize_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "avx_binocular_warp_u8": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

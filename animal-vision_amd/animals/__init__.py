@@ -6,3 +6,8 @@ from ._dichromats import (  # noqa: F401
 )
 from .honeybee import HoneyBee  # noqa: F401
 from .mantis_shrimp import MantisShrimp  # noqa: F401
+from .reindeer import Reindeer  # noqa: F401
+from .goldfish import Goldfish  # noqa: F401
+
+# module name -> class name of the UV species written against the plane-program backend (planevm.py)
+UV_CLASS = {"reindeer": "Reindeer", "goldfish": "Goldfish"}

@@ -1,0 +1,65 @@
+"""Common machinery of the UV species written against the plane-program backend vocabulary (planevm.py).
+
+A species implements `render(be, image)` once; `visualize` records it for the frame size on a DeviceBackend the
+first time it sees that size and replays the recorded device calls afterwards (species are stateless between
+frames, SURVEY 8b: only constructor constants and O(bands)/O(H)/O(W) tables enter the recording)."""
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from .animal import Animal
+
+
+class UVSpecies(Animal):
+    """Base class: same `visualize(image) -> (baseline, out)` contract as the reference's species."""
+
+    _MAX_PLANS = 4
+
+    def render(self, be, image: np.ndarray) -> None:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def _plan(self, image: np.ndarray):
+        from ..planevm import DeviceBackend
+
+        plans: Dict[Tuple[int, int], object] = self.__dict__.setdefault("_plans", {})
+        key = (image.shape[0], image.shape[1])
+        be = plans.get(key)
+        if be is None:
+            if len(plans) >= self._MAX_PLANS:
+                plans.pop(next(iter(plans))).close()
+            be = DeviceBackend(*key)
+            self.render(be, image)
+            be.flush()
+            plans[key] = be
+        return be
+
+    def visualize(self, image: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        assert isinstance(image, np.ndarray), "Input must be a numpy ndarray."
+        assert image.ndim == 3 and image.shape[2] == 3, "Input must be HxWx3 RGB."
+        if image.dtype != np.uint8:
+            raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 frames, got {image.dtype}")
+        return self._plan(image).run(image)
+
+
+def default_lambdas(lambdas) -> np.ndarray:
+    """The 300-700 nm / 81-band grid every UV species but HoneyBee defaults to (e.g. reindeer.py:56-58)."""
+    lam = np.asarray(lambdas, dtype=np.float32) if lambdas is not None else np.linspace(300.0, 700.0, 81, dtype=np.float32)
+    assert lam.ndim == 1 and lam.size >= 10, "lambdas must be a 1D vector of wavelengths (nm)."
+    return lam
+
+
+def snow_glare_tone_compress(be, x, *, strength: float, knee: float = 0.8):
+    """uv_helpers.py:111-121 on one plane."""
+    if strength <= 0.0:
+        return x
+    x = be.clip01(x)
+    t = (x - knee) / (1.0 - knee)
+    return be.where(x <= knee, x, knee + (1.0 - knee) * (t / (1.0 + strength * t)))
+
+
+def radial_sigmoid(be, *, radius: float, softness: float):
+    """The peripheral blend weight several species share (e.g. goldfish.py:165-170, mantis_shrimp.py:270-273)."""
+    yy = be.row(np.linspace(-1.0, 1.0, be.H, dtype=np.float32))
+    xx = be.col(np.linspace(-1.0, 1.0, be.W, dtype=np.float32))
+    r = be.sqrt(xx * xx + yy * yy)
+    return 1.0 / (1.0 + be.exp(-softness * (r - radius)))

@@ -34,6 +34,7 @@ static void avx_ws_release(avx_ws* w) {
     if (w->uv_small) (void)hipFree(w->uv_small);
     if (w->d_scratch) (void)hipFree(w->d_scratch);
     if (w->d_geom) (void)hipFree(w->d_geom);
+    if (w->d_ew) (void)hipFree(w->d_ew);
     *w = avx_ws();
 }
 

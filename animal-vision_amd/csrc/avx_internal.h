@@ -21,6 +21,8 @@ struct avx_ws {
     size_t scratch_cap = 0;
     void* d_geom = nullptr;          // resampling coefficient tables (geom.hip)
     size_t geom_cap = 0;
+    void* d_ew = nullptr;            // per-block partial reductions of elementwise programs (ew.hip)
+    size_t ew_cap = 0;
 };
 
 struct avx_ctx {

@@ -223,6 +223,91 @@ int grid_for(avx_ctx* ctx, size_t items) {
 
 }  // namespace
 
+// ---- shared front end and band stack of the UV species (also exported on their own, include/avx.h) ------------
+// to_float01 + srgb_to_linear -> panorama_warp -> baseline encode.  tmp: 3*H*W floats (used when the warp is on).
+static int uv_front(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, int newW, float* tmp, float* lin_out, uint8_t* base_out, hipStream_t s) {
+    const size_t n = (size_t)H * W;
+    int rc;
+    if (newW > W) {
+        hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, tmp);
+        if ((rc = avx_geom_panorama_cubic(ctx, tmp, H, W, newW, (newW - W) / 2, lin_out, s))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, lin_out);
+    }
+    if (base_out)
+        hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, lin_out, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], base_out);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+// classic_rgb_to_hsi(_scaled) x K band windows -> HxWxK stack (raw integrate_band values).
+// tab: (K*3 + B*3 + K*B) floats of device scratch; small / sstack: 3*hs*ws and hs*ws*K floats (reduced-size route).
+static int band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, int K, const float* M_host, int B, const float* gains_host, float denom,
+                      const float* wts_host, int hs, int wsm, float* tab, float* small, float* sstack, float* stack, hipStream_t s) {
+    float* dM = tab; float* dgains = dM + K * 3; float* dwts = dgains + 3 * B;
+    AVX_HIP(ctx, hipMemcpyAsync(dM, M_host, sizeof(float) * K * 3, hipMemcpyHostToDevice, s));
+    AVX_HIP(ctx, hipMemcpyAsync(dgains, gains_host, sizeof(float) * B * 3, hipMemcpyHostToDevice, s));
+    AVX_HIP(ctx, hipMemcpyAsync(dwts, wts_host, sizeof(float) * B * K, hipMemcpyHostToDevice, s));
+    const size_t n = (size_t)H * W, nsmall = (size_t)hs * wsm;
+    int rc;
+    if (hs != H || wsm != W) {
+        if ((rc = avx_resize_hwc(ctx, lin_hwc, 0, H, W, 3, small, hs, wsm, 3, s))) return rc;
+        hipLaunchKernelGGL(k_rgbf_to_stack, dim3(grid_for(ctx, nsmall)), dim3(kMT), 0, s, StackArgs{small, nsmall, dM, K, B, dgains, denom, dwts, sstack});
+        if ((rc = avx_resize_hwc(ctx, sstack, 0, hs, wsm, K, stack, H, W, 1, s))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_rgbf_to_stack, dim3(grid_for(ctx, n)), dim3(kMT), 0, s, StackArgs{lin_hwc, n, dM, K, B, dgains, denom, dwts, stack});
+    }
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+extern "C" int avx_uv_front_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, int pano_new_w, float* lin_hwc_out, uint8_t* baseline_hwc_out, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, in_hwc && lin_hwc_out && H > 0 && W > 0, "avx_uv_front_u8: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const int newW = pano_new_w > W ? pano_new_w : W;
+    float* tmp = nullptr;
+    if (newW > W) {
+        int rc = avx_ensure_scratch(ctx, ws, sizeof(float) * 3 * (size_t)H * W);
+        if (rc) return rc;
+        tmp = (float*)ws->d_scratch;
+    }
+    return uv_front(ctx, in_hwc, H, W, newW, tmp, lin_hwc_out, baseline_hwc_out, s);
+}
+
+extern "C" int avx_band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, const avx_band_stack_desc* d, float* stack_hwk_out, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_band_stack_desc), "avx_band_stack: desc is NULL or struct_size mismatch");
+    AVX_REQUIRE(ctx, lin_hwc && stack_hwk_out && H > 0 && W > 0, "avx_band_stack: bad arguments");
+    AVX_REQUIRE(ctx, d->n_bands >= 1 && d->n_bands <= KMAX && d->band_matrix_host && d->n_wavelengths >= 1 && d->lobe_gains_host && d->band_weights_host && d->lobe_denom > 0.f,
+                "avx_band_stack: bad band tables");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const int K = d->n_bands, B = d->n_wavelengths;
+    const int hs = d->small_h > 0 ? d->small_h : H, wsm = d->small_w > 0 ? d->small_w : W;
+    const size_t nsmall = (hs != H || wsm != W) ? (size_t)hs * wsm : 0;
+    size_t off = 0;
+    auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 63) & ~(size_t)63; return o; };
+    const size_t o_tab = take((size_t)K * 3 + (size_t)B * (3 + K)), o_small = take(3 * nsmall), o_sstack = take(nsmall * K);
+    int rc = avx_ensure_scratch(ctx, ws, off * sizeof(float));
+    if (rc) return rc;
+    float* base = (float*)ws->d_scratch;
+    return band_stack(ctx, lin_hwc, H, W, K, d->band_matrix_host, B, d->lobe_gains_host, d->lobe_denom, d->band_weights_host, hs, wsm, base + o_tab, base + o_small,
+                      base + o_sstack, stack_hwk_out, s);
+}
+
+extern "C" int avx_percentile_dev(avx_ctx* ctx, const float* data_dev, size_t n, double q, double* out_dev, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, data_dev && out_dev && n > 0 && q >= 0.0 && q <= 100.0, "avx_percentile_dev: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    return avx_uv_percentile_device(ctx, data_dev, n, q, out_dev, avx_pick_stream(ctx, stream));
+}
+
 extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_mantis_desc), "avx_mantis_u8: desc is NULL or struct_size mismatch");

@@ -213,6 +213,67 @@ typedef struct avx_mantis_desc {
 int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_baseline_hwc, uint8_t* out_hwc, int H, int W,
                   const avx_mantis_desc* desc, void* stream);
 
+/* ---- stages of the other UV species, each on device pointers so that a species is a sequence of asynchronous
+ * calls on one stream (animal-vision_amd/planevm.py) --------------------------------------------------------- */
+/* Steps 1-2 shared by every UV species but HoneyBee (animals/reindeer.py:83-98, goldfish.py:100-113, ...):
+ * to_float01 + srgb_to_linear, panorama_warp to pano_new_w (<= W: no warp) and the uint8 baseline
+ * (baseline_hwc_out may be NULL).  lin_hwc_out: H x W x 3 float32. */
+int avx_uv_front_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, int pano_new_w, float* lin_hwc_out,
+                    uint8_t* baseline_hwc_out, void* stream);
+/* classic_rgb_to_hsi / classic_rgb_to_hsi_scaled (uv_helpers.py:155-183) followed by N x integrate_band
+ * (:142-146): H x W x 3 linear float32 -> H x W x N float32 (raw band integrals; safe_norm is the caller's). */
+typedef struct avx_band_stack_desc {
+    uint32_t struct_size;
+    int32_t n_bands;                   /* N <= 16                                                              */
+    const float* band_matrix_host;     /* N x 3 (see avx_mantis_desc)                                          */
+    int32_t n_wavelengths;
+    const float* lobe_gains_host;      /* B x 3                                                                */
+    float lobe_denom;
+    const float* band_weights_host;    /* N x B                                                                */
+    int32_t small_h, small_w;          /* reduced size of the hsi_scale route (0: full resolution)             */
+} avx_band_stack_desc;
+int avx_band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, const avx_band_stack_desc* desc,
+                   float* stack_hwk_out, void* stream);
+/* avx_percentile with the result left on the device (one double, the float32 value NumPy would return). */
+int avx_percentile_dev(avx_ctx* ctx, const float* data_dev, size_t n, double q, double* out_dev, void* stream);
+
+/* ---- fused elementwise programs over float32 planes (csrc/ew.hip) --------------------------------------------
+ * The remaining UV species (animals/reindeer.py:83-135, goldfish.py:86-180, ... ) are NumPy expression chains over
+ * HxW planes.  One avx_ew_run = one launch evaluating a whole chain per pixel: a register program (32 float32
+ * registers) whose LOAD/STORE touch only the planes that enter/leave the chain; frame-wide reductions (ndarray.min /
+ * max / sum / mean) accumulate alongside and land in a device-side table of doubles that later programs read with
+ * AVX_EW_SCALAR -- nothing visits the host.  Every instruction is one IEEE float32 operation (no fusing). */
+enum { AVX_EW_MAX_INSN = 384, AVX_EW_MAX_PLANES = 24, AVX_EW_MAX_REGS = 32, AVX_EW_MAX_ACC = 16 };
+enum {  /* opcodes: dst = op(a, b); imm = constant bits / plane index / scalar slot / third register of SELECT */
+    AVX_EW_CONST = 1, AVX_EW_SCALAR, AVX_EW_LOAD, AVX_EW_STORE,
+    AVX_EW_ADD, AVX_EW_SUB, AVX_EW_MUL, AVX_EW_DIV, AVX_EW_MIN, AVX_EW_MAX, AVX_EW_POW, AVX_EW_ATAN2,
+    AVX_EW_NEG, AVX_EW_ABS, AVX_EW_SQRT, AVX_EW_EXP, AVX_EW_LOG, AVX_EW_SIN, AVX_EW_COS, AVX_EW_FLOOR, AVX_EW_CEIL,
+    AVX_EW_CLIP01, AVX_EW_TANH,
+    AVX_EW_LT, AVX_EW_LE, AVX_EW_GT, AVX_EW_GE, AVX_EW_EQ, AVX_EW_AND, AVX_EW_OR, AVX_EW_NOT,
+    AVX_EW_SELECT,                      /* dst = a != 0 ? b : reg[imm & 0xff]  (np.where)                          */
+    AVX_EW_ACCMIN, AVX_EW_ACCMAX, AVX_EW_ACCSUM   /* dst (an accumulator register) op= a                           */
+};
+enum {  /* plane kinds: element i of the frame (i = y*W + x) is at ptr[i*stride] unless stated                    */
+    AVX_EW_PLANE_F32 = 0,               /* float32, load/store (stride 3 + offset pointer = one channel of HWC)      */
+    AVX_EW_PLANE_U8,                    /* uint8 -> float value of the byte, load only                              */
+    AVX_EW_PLANE_U8_LUT,                /* uint8 -> srgb_to_linear(to_float01(byte)) (uv_helpers.py:15-37), load only */
+    AVX_EW_PLANE_COL,                   /* float32 vector of W entries broadcast down the rows: ptr[x]              */
+    AVX_EW_PLANE_ROW,                   /* float32 vector of H entries broadcast along the rows: ptr[y]             */
+    AVX_EW_PLANE_U8_ENC                 /* store only: from_float01(linear_to_srgb(clip(v,0,1)), uint8) (:25-44)    */
+};
+enum { AVX_EW_ACC_MIN = 0, AVX_EW_ACC_MAX, AVX_EW_ACC_SUM, AVX_EW_ACC_MEAN };
+typedef struct avx_ew_insn { uint8_t op, dst, a, b; uint32_t imm; } avx_ew_insn;
+typedef struct avx_ew_plane { void* ptr; int32_t stride; int32_t kind; } avx_ew_plane;
+typedef struct avx_ew_program {
+    uint32_t struct_size;
+    int32_t H, W;
+    int32_t n_insn; const avx_ew_insn* insn_host;
+    int32_t n_planes; const avx_ew_plane* planes_host;   /* device pointers                                          */
+    int32_t n_acc; const int32_t* acc_host;              /* n_acc x {register, AVX_EW_ACC_*, scalar slot}            */
+    double* scalars_dev; int32_t n_scalars;              /* the device-side scalar table                             */
+} avx_ew_program;
+int avx_ew_run(avx_ctx* ctx, const avx_ew_program* program, void* stream);
+
 /* ---- MST++ helpers (ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py) ----------------------------
  * Hand-written kernels for the memory-bound parts of the forward pass; PyTorch-ROCm keeps the dense GEMMs/convs.
  * Pointers are torch tensors' data_ptr(); dtype 0 = float32, 1 = float16; all on `stream` (torch's current stream). */

@@ -1,0 +1,114 @@
+"""oracle/np_backend.py -- TEST INFRASTRUCTURE ONLY (the checker, never the product).
+
+Eager NumPy execution of the backend vocabulary the UV species are written against
+(animal-vision_amd/planevm.py: DeviceBackend is the product; this is the CPU restatement).  Every method is the
+NumPy / oracle call the reference itself makes at that point (uv_helpers.py, uv_mappers.py, and the OpenCV
+restatements of oracle/cvref.cpp: parity with real OpenCV unpinned), so a species' `render(be, image)` run with this
+backend reproduces the reference's arithmetic including NumPy's dtype promotion (np.float64 scalars promote arrays
+to float64 under NumPy >= 2, as they do in the reference).  Pinned by tests/golden/uv_species.npz: outputs of the
+imported reference classes on the same frames (tools/make_goldens.py)."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+from . import cpu_ref as O
+
+
+class NumpyBackend:
+    name = "numpy"
+
+    def __init__(self, H: int, W: int):
+        self.H, self.W = int(H), int(W)
+        self.baseline_out = None
+        self.out = None
+
+    # -- leaves ----------------------------------------------------------------------------------------
+    def col(self, vec):
+        return np.asarray(vec)[None, :]
+
+    def row(self, vec):
+        return np.asarray(vec)[:, None]
+
+    # -- elementwise (bound below: NumPy's own ufuncs) ------------------------------------------------
+    @staticmethod
+    def clip01(x):
+        return np.clip(x, 0.0, 1.0)
+
+    # -- reductions ------------------------------------------------------------------------------------
+    @staticmethod
+    def min(x): return x.min()
+    @staticmethod
+    def max(x): return x.max()
+    @staticmethod
+    def sum(x): return x.sum()
+    @staticmethod
+    def mean(x): return x.mean()
+
+    @staticmethod
+    def safe_norm(x):
+        return O.safe_norm(x)
+
+    @staticmethod
+    def percentile(v, q):
+        if isinstance(v, (list, tuple)):
+            v = np.stack(v, axis=-1)
+        return np.percentile(v, q)
+
+    @staticmethod
+    def mat(v):
+        return v
+
+    # -- stages ----------------------------------------------------------------------------------------
+    @staticmethod
+    def blur(vals: Sequence, sigma: float):
+        """uv_helpers.gaussian_blur on an HxWxC array == per channel (OpenCV filters channels independently)."""
+        return [O.gaussian_blur(np.ascontiguousarray(v), sigma) for v in vals]
+
+    @staticmethod
+    def blur_taps(vals: Sequence, ksize: int, taps):
+        out = []
+        for v in vals:
+            dt = np.float64 if v.dtype == np.float64 else np.float32
+            k = np.asarray(taps, dtype=dt)
+            out.append(O.sepfilter(np.ascontiguousarray(v), k, k))
+        return out
+
+    @staticmethod
+    def sobel(v):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        return O.cv_sobel3(v, 1, 0), O.cv_sobel3(v, 0, 1)
+
+    def front(self, image: np.ndarray, panorama_scale: float):
+        self.dtype = image.dtype
+        img_lin = O.uv_srgb_to_linear(O.to_float01(image))
+        if panorama_scale and panorama_scale != 1.0:
+            self.lin = O.panorama_warp(img_lin, scale_x=panorama_scale)
+        else:
+            self.lin = img_lin
+        self.baseline_out = O.from_float01(O.uv_linear_to_srgb(np.clip(self.lin, 0.0, 1.0)), self.dtype)
+        return [self.lin[..., c] for c in range(3)]
+
+    def bands(self, lambdas, bands, hsi_scale: float):
+        if 0.0 < hsi_scale < 1.0:
+            hsi = O.classic_rgb_to_hsi_scaled(self.lin, wavelengths=lambdas, scale=hsi_scale)
+        else:
+            hsi = O.classic_rgb_to_hsi_lobes(self.lin, lambdas)
+        return [O.integrate_band(hsi, lambdas, lo, hi) for lo, hi in bands]
+
+    def encode(self, rgb: Sequence):
+        render = np.stack([np.broadcast_to(c, (self.H, self.W)) for c in rgb], axis=-1)
+        self.out = O.from_float01(O.uv_linear_to_srgb(np.clip(render, 0.0, 1.0)), self.dtype)
+
+
+for _name, _fn in dict(sqrt=np.sqrt, exp=np.exp, log=np.log, sin=np.sin, cos=np.cos, floor=np.floor, tanh=np.tanh, abs=np.abs,
+                       minimum=np.minimum, maximum=np.maximum, arctan2=np.arctan2, power=np.power, where=np.where, clip=np.clip).items():
+    setattr(NumpyBackend, _name, staticmethod(_fn))
+
+
+def run(species, image: np.ndarray):
+    """(baseline, out) of a backend-generic species evaluated with NumPy."""
+    be = NumpyBackend(image.shape[0], image.shape[1])
+    species.render(be, image)
+    return be.baseline_out, be.out

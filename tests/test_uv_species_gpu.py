@@ -1,0 +1,90 @@
+"""GPU: the UV species on the device (plane programs, csrc/ew.hip + the stage kernels) vs the reference's
+re-enacted outputs (tests/golden/uv_species.npz) and vs the same species run with the oracle's NumPy backend
+on other frame sizes.
+
+Contract: baseline (decode -> cubic panorama warp -> encode) bit-exact; the stylised frame is a float32
+pipeline held to 1e-4 relative before the uint8 encode: codes within +-1, allowing a small fraction of samples
+beyond that where a categorical decision (argmax, threshold masks) sits within rounding of its boundary."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _species():
+    from animal_vision_amd import animals
+
+    return sorted(animals.UV_CLASS)
+
+
+def _check(got, want, what, frac_beyond=2e-3, frac_any=0.05):
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert float((diff > 1).mean()) <= frac_beyond, (what, "fraction beyond +-1:", float((diff > 1).mean()), "max", int(diff.max()))
+    assert float((diff > 0).mean()) <= frac_any, (what, "fraction != :", float((diff > 0).mean()))
+
+
+@pytest.mark.parametrize("mod", ["reindeer", "goldfish"])
+def test_species_vs_reference_golden(mod):
+    from animal_vision_amd import animals
+
+    g = load_golden("uv_species")
+    sp = getattr(animals, animals.UV_CLASS[mod])()
+    for k in ("s64", "n50"):
+        base, out = sp.visualize(g[f"in_{k}"])
+        assert base.dtype == np.uint8 and out.dtype == np.uint8
+        assert np.array_equal(base, g[f"{mod}_base_{k}"]), (mod, k, "baseline")
+        _check(out, g[f"{mod}_out_{k}"], (mod, k))
+
+
+@pytest.mark.parametrize("mod", ["reindeer", "goldfish"])
+def test_species_vs_oracle_other_sizes(mod):
+    from animal_vision_amd import animals
+    from oracle import np_backend
+
+    sp = getattr(animals, animals.UV_CLASS[mod])()
+    for shape in ((96, 128, 3), (135, 241, 3)):
+        rng = np.random.default_rng(shape[0] + shape[1])
+        yy, xx = np.mgrid[0 : shape[0], 0 : shape[1]]
+        smooth = (127 + 100 * np.sin(xx / 9.0)[..., None] * np.cos(yy[..., None] / 7.0 + np.arange(3))).clip(0, 255)
+        frame = (0.75 * smooth + 0.25 * rng.integers(0, 256, shape)).astype(np.uint8)
+        base, out = sp.visualize(frame)
+        wbase, wout = np_backend.run(sp, frame)
+        assert np.array_equal(base, wbase), (mod, shape)
+        _check(out, wout, (mod, shape))
+    # second frame of an already-recorded size replays the plan
+    frame2 = np.ascontiguousarray(frame[::-1])
+    base, out = sp.visualize(frame2)
+    wbase, wout = np_backend.run(sp, frame2)
+    assert np.array_equal(base, wbase)
+    _check(out, wout, (mod, "replay"))
+
+
+def test_ew_program_basic_ops_and_reductions():
+    """The interpreter itself: arithmetic, masks, row/column broadcasts, reductions, vs NumPy float32."""
+    from animal_vision_amd.planevm import DeviceBackend, PlaneRef
+
+    H, W = 37, 53
+    be = DeviceBackend(H, W)
+    rng = np.random.default_rng(5)
+    a, b = rng.random((H, W), dtype=np.float32), rng.random((H, W), dtype=np.float32) + 0.1
+    pa, pb = be.new_planes(2)
+    be.ctx.upload(a, pa.buf.view(pa.offset, a.nbytes))
+    be.ctx.upload(b, pb.buf.view(pb.offset, b.nbytes))
+    A, B = be.load(pa), be.load(pb)
+    col, row = np.linspace(-1, 1, W, dtype=np.float32), np.linspace(0, 2, H, dtype=np.float32)
+    expr = be.where(A > 0.5, be.sqrt(A * B) + be.col(col), be.exp(-A) / B - be.row(row)) ** 2
+    mn, mx, mean = be.min(expr), be.max(expr), be.mean(expr)
+    norm = be.mat((expr - mn) / (mx - mn) + 0.0 * mean)
+    p50 = be.percentile(norm, 50.0)
+    res = be.mat(be.clip(norm - p50, -0.25, 0.25) + be.arctan2(A, B) * be.cos(A) - be.abs(be.sin(B)) + be.power(B, 1.7))
+    be.flush()
+    for fn in be.plan:
+        fn(be.ctx.stream)
+    got = be.ctx.download(res.imm.buf.view(res.imm.offset, 4 * H * W), (H, W), np.float32)
+    e = np.where(a > 0.5, np.sqrt(a * b) + col[None, :], np.exp(-a) / b - row[:, None]) ** 2
+    n = (e - e.min()) / (e.max() - e.min()) + np.float32(0.0) * e.mean()
+    want = np.clip(n - np.percentile(n, 50.0), -0.25, 0.25) + np.arctan2(a, b) * np.cos(a) - np.abs(np.sin(b)) + np.power(b, np.float32(1.7))
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    be.close()

@@ -1,0 +1,25 @@
+"""CPU: the backend-generic UV species (animal-vision_amd/animals/*.py `render`) executed with the NumPy backend
+(oracle/np_backend.py) against the outputs of the imported reference classes (tests/golden/uv_species.npz, made by
+tools/make_goldens.py with cv2 = the oracle's OpenCV restatements).  Bit-exact: the restatement performs the same
+NumPy operations in the same order and dtypes as the reference."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+SPECIES = ["reindeer", "goldfish"]
+
+
+@pytest.mark.parametrize("mod", SPECIES)
+def test_species_restatement_bit_exact_vs_reference(mod):
+    from oracle import np_backend
+
+    g = load_golden("uv_species")
+    from animal_vision_amd import animals
+
+    cls = getattr(animals, animals.UV_CLASS[mod])
+    sp = cls()
+    for k in ("s64", "n50"):
+        base, out = np_backend.run(sp, g[f"in_{k}"])
+        assert np.array_equal(base, g[f"{mod}_base_{k}"]), (mod, k, "baseline")
+        assert np.array_equal(out, g[f"{mod}_out_{k}"]), (mod, k, int(np.abs(out.astype(int) - g[f"{mod}_out_{k}"].astype(int)).max()))

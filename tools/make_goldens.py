@@ -413,8 +413,52 @@ def g_mantis():
     save("mantis", **out)
 
 
+UV_SPECIES = (("reindeer", "Reindeer"), ("rat_uv", "RatUV"), ("goldfish", "Goldfish"), ("damselfish", "Damselfish"), ("anableps", "Anableps"),
+              ("anchovy", "Anchovy"), ("guppy", "Guppy"), ("morpho", "Morpho"), ("heliconius", "Heliconius"), ("pieris", "Pieris"),
+              ("hummingbird", "Hummingbird"), ("kestrel", "Kestrel"), ("jumping_spider", "JumpingSpider"), ("dragonfly", "Dragonfly"))
+
+
+def g_uv_species():
+    """8f row 3: the 14 remaining UV species of the reference, default parameters, end to end on two small frames
+    (cv2 = the oracle's OpenCV restatements, classic_rgb_to_hsi = the reference's analytic branch on CPU)."""
+    conv_mod = None
+    _ref_classic()
+    conv_mod = sys.modules["ml.classic_rgb_to_hsi.classic_rgb_to_hsi"]
+    ref_uvh.cv2 = cv2
+    BLUR_MODE["mode"] = "oracle"
+    frames = {"s64": structured_frame(3, 64, 80), "n50": noise_frame(7, 50, 70)}
+    out = {f"in_{k}": v for k, v in frames.items()}
+    for mod, cls in UV_SPECIES:
+        try:
+            m = importlib.import_module(f"animals.{mod}")
+        except Exception as e:  # noqa: BLE001
+            print(f"   {mod}: import failed: {type(e).__name__}: {e}")
+            continue
+        if hasattr(m, "classic_rgb_to_hsi"):
+            m.classic_rgb_to_hsi = conv_mod.classic_rgb_to_hsi
+        for attr in ("cv2", "cv"):
+            if hasattr(m, attr):
+                setattr(m, attr, cv2)
+        for flag in ("_HAS_CV2", "HAS_CV2", "_HAS_CV"):
+            if hasattr(m, flag):
+                setattr(m, flag, True)
+        try:
+            sp = getattr(m, cls)()
+            for k, f in frames.items():
+                base, res = sp.visualize(f)
+                assert base.dtype == np.uint8 and res.dtype == np.uint8, (mod, base.dtype, res.dtype)
+                out[f"{mod}_base_{k}"], out[f"{mod}_out_{k}"] = base, res
+            print(f"   {mod}: ok")
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            print(f"   {mod}: FAILED {type(e).__name__}: {e}")
+            traceback.print_exc(limit=3)
+    ref_uvh.cv2 = None
+    save("uv_species", **out)
+
+
 GENERATORS = {"srgb_tables": g_srgb_tables, "matrices": g_matrices, "dichromat": g_dichromat, "uv": g_uv,
-              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp, "geometry": g_geometry, "mantis": g_mantis}
+              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp, "geometry": g_geometry, "mantis": g_mantis, "uv_species": g_uv_species}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
