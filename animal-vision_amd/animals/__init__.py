@@ -10,4 +10,12 @@ from .reindeer import Reindeer  # noqa: F401
 from .goldfish import Goldfish  # noqa: F401
 
 # module name -> class name of the UV species written against the plane-program backend (planevm.py)
-UV_CLASS = {"reindeer": "Reindeer", "goldfish": "Goldfish"}
+from .damselfish import Damselfish  # noqa: F401
+from .rat_uv import RatUV  # noqa: F401
+from .anableps import Anableps  # noqa: F401
+from .anchovy import Anchovy  # noqa: F401
+from .guppy import Guppy  # noqa: F401
+from .morpho import Morpho  # noqa: F401
+
+UV_CLASS = {"reindeer": "Reindeer", "goldfish": "Goldfish", "damselfish": "Damselfish", "rat_uv": "RatUV", "anableps": "Anableps",
+            "anchovy": "Anchovy", "guppy": "Guppy", "morpho": "Morpho"}

@@ -16,29 +16,40 @@ class UVSpecies(Animal):
     _MAX_PLANS = 4
 
     def render(self, be, image: np.ndarray) -> None:  # pragma: no cover - abstract
+        """Species with a frame-dependent branch take a third argument: the value `variant()` returned."""
         raise NotImplementedError
 
-    def _plan(self, image: np.ndarray):
+    def variant(self, image: np.ndarray, probes, **kw):
+        """A hashable that selects between recorded plans when the reference branches on frame content
+        (rat_uv.py:100-105); `probes` supplies the frame statistics (device: planevm.DeviceProbes)."""
+        return None
+
+    def _plan(self, image: np.ndarray, variant=None):
         from ..planevm import DeviceBackend
 
-        plans: Dict[Tuple[int, int], object] = self.__dict__.setdefault("_plans", {})
-        key = (image.shape[0], image.shape[1])
+        plans: Dict[tuple, object] = self.__dict__.setdefault("_plans", {})
+        key = (image.shape[0], image.shape[1], variant)
         be = plans.get(key)
         if be is None:
             if len(plans) >= self._MAX_PLANS:
                 plans.pop(next(iter(plans))).close()
-            be = DeviceBackend(*key)
-            self.render(be, image)
+            be = DeviceBackend(image.shape[0], image.shape[1])
+            if variant is None:
+                self.render(be, image)
+            else:
+                self.render(be, image, variant)
             be.flush()
             plans[key] = be
         return be
 
-    def visualize(self, image: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    def visualize(self, image: np.ndarray, **kw) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         assert isinstance(image, np.ndarray), "Input must be a numpy ndarray."
         assert image.ndim == 3 and image.shape[2] == 3, "Input must be HxWx3 RGB."
         if image.dtype != np.uint8:
             raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 frames, got {image.dtype}")
-        return self._plan(image).run(image)
+        from ..planevm import DeviceProbes
+
+        return self._plan(image, self.variant(image, DeviceProbes, **kw)).run(image)
 
 
 def default_lambdas(lambdas) -> np.ndarray:

@@ -167,6 +167,40 @@ __global__ __launch_bounds__(kGT) void k_binocular_warp(WarpArgs a) {
     }
 }
 
+// cv2.remap(float32 planes, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT, borderValue) with per-pixel float32 maps
+// (anableps.py:217-226); K planes share the maps.
+__global__ __launch_bounds__(kGT) void k_remap_planes(const float* __restrict__ src, int K, int H, int W, const float* __restrict__ mapx, const float* __restrict__ mapy,
+                                                      float* __restrict__ dst, float border) {
+    const size_t n = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < n; i += (size_t)gridDim.x * kGT) {
+        const int fx = __float2int_rn(mapx[i] * 32.f), fy = __float2int_rn(mapy[i] * 32.f);
+        int sx = fx >> 5, sy = fy >> 5;
+        sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+        sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+        const float tx = (fx & 31) * (1.f / 32), ty = (fy & 31) * (1.f / 32);
+        const float w0 = (1.f - ty) * (1.f - tx), w1 = (1.f - ty) * tx, w2 = ty * (1.f - tx), w3 = ty * tx;
+        const bool outside = sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0;
+        for (int k = 0; k < K; ++k) {
+            const float* S = src + (size_t)k * n;
+            auto at = [&](int yy, int xx) { return ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) ? S[(size_t)yy * W + xx] : border; };
+            dst[(size_t)k * n + i] = outside ? border : at(sy, sx) * w0 + at(sy, sx + 1) * w1 + at(sy + 1, sx) * w2 + at(sy + 1, sx + 1) * w3;
+        }
+    }
+}
+
+// cv2.resize(..., INTER_NEAREST): sx = min(floor(dx * (W / Wd)), W - 1) with the scale in double (resizeNN)
+__global__ __launch_bounds__(kGT) void k_resize_nearest_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd, double fx, double fy) {
+    const size_t total = (size_t)Hd * Wd * C;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
+        int sx = (int)floor(x * fx), sy = (int)floor(y * fy);
+        sx = sx < W - 1 ? sx : W - 1;
+        sy = sy < H - 1 ? sy : H - 1;
+        dst[i] = src[((size_t)sy * W + sx) * C + c];
+    }
+}
+
 // cv2.Sobel(plane, CV_32F, dx, dy, ksize=3, BORDER_REFLECT_101): small-kernel forms, row filter then column filter
 __global__ __launch_bounds__(kGT) void k_sobel3(const float* __restrict__ src, int H, int W, float* __restrict__ gx, float* __restrict__ gy) {
     const size_t total = (size_t)H * W;
@@ -292,10 +326,16 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, src && dst && src != dst && H > 0 && W > 0 && C > 0 && Hd > 0 && Wd > 0, "avx_resize_hwc: bad arguments");
     AVX_REQUIRE(ctx, dtype == 0 || dtype == 2, "avx_resize_hwc: dtype must be 0 (float32) or 2 (uint8)");
-    AVX_REQUIRE(ctx, interp >= 1 && interp <= 3, "avx_resize_hwc: interpolation must be 1 LINEAR, 2 CUBIC or 3 AREA");
+    AVX_REQUIRE(ctx, interp >= 0 && interp <= 3, "avx_resize_hwc: interpolation must be 0 NEAREST, 1 LINEAR, 2 CUBIC or 3 AREA");
     AVX_REQUIRE(ctx, dtype == 0 || interp == 1, "avx_resize_hwc: uint8 supports INTER_LINEAR only");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
+    if (interp == 0) {  // no tables
+        hipLaunchKernelGGL(k_resize_nearest_f32, dim3(grid_for(ctx, (size_t)Hd * Wd * C)), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd,
+                           1.0 / ((double)Wd / W), 1.0 / ((double)Hd / H));  // resizeNN: ifx = 1 / inv_scale_x
+        AVX_HIP(ctx, hipGetLastError());
+        return AVX_OK;
+    }
     avx_ws* ws = avx_workspace(ctx, s);
     if (!ws) return AVX_ERR_NOMEM;
     const size_t tab_bytes = ((size_t)(Wd + Hd) * 48 + 4096) * 4;
@@ -375,6 +415,18 @@ int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, con
     const size_t nbytes = (size_t)H * W * 3;
     hipLaunchKernelGGL(k_any_gt1, dim3(grid_for(ctx, nbytes)), dim3(kGT), 0, s, in_hwc, nbytes, flag);
     hipLaunchKernelGGL(k_binocular_warp, dim3(grid_for(ctx, (size_t)Ho * Wo)), dim3(kGT), 0, s, a);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+int avx_remap_linear_planes(avx_ctx* ctx, const float* src_planes, int K, int H, int W, const float* mapx, const float* mapy, float* dst_planes,
+                            float border_value, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, src_planes && mapx && mapy && dst_planes && K >= 1 && H > 0 && W > 0, "avx_remap_linear_planes: bad arguments");
+    AVX_REQUIRE(ctx, src_planes != dst_planes, "avx_remap_linear_planes: in-place remap is not possible");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    hipLaunchKernelGGL(k_remap_planes, dim3(grid_for(ctx, (size_t)H * W)), dim3(kGT), 0, s, src_planes, K, H, W, mapx, mapy, dst_planes, border_value);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

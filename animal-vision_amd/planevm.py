@@ -456,6 +456,31 @@ class DeviceBackend:
         self._call(lambda s: ctx._check(lib.avx_sobel3_plane(ctx._h, src, H, W, gx.ptr, gy.ptr, s)))
         return self.load(gx), self.load(gy)
 
+    def remap(self, vals: Sequence, map_x, map_y, border_value: float = 0.0) -> List[Val]:
+        """cv2.remap(stack(vals), map_x, map_y, INTER_LINEAR, BORDER_CONSTANT) with per-pixel float32 maps."""
+        K = len(vals)
+        src, _ = self._contiguous(vals)
+        mx, _ = self._contiguous([map_x])
+        my, _ = self._contiguous([map_y])
+        out = self.new_planes(K)
+        ctx, H, W, dst = self.ctx, self.H, self.W, out[0].ptr
+        self._call(lambda s: ctx._check(lib.avx_remap_linear_planes(ctx._h, src, K, H, W, mx, my, dst, float(border_value), s)))
+        return [self.load(r) for r in out]
+
+    def down_up(self, vals: Sequence, h: int, w: int, interp_down: int, interp_up: int) -> List[Val]:
+        """cv2.resize(cv2.resize(stack(vals), (w, h), interp_down), (W, H), interp_up): the mosaic / coarse-field idiom
+        (morpho.py:84-92).  interp: 0 NEAREST, 1 LINEAR, 2 CUBIC, 3 AREA."""
+        K = len(vals)
+        hwc = self._alloc(4 * self.n * K)
+        for c, v in enumerate(vals):
+            self.store(self._v(v), PlaneRef(hwc, 4 * c, K))
+        small = self._alloc(4 * h * w * K)
+        out = self._alloc(4 * self.n * K)
+        ctx, H, W = self.ctx, self.H, self.W
+        self._call(lambda s: ctx._check(lib.avx_resize_hwc(ctx._h, hwc.ptr, 0, H, W, K, small.ptr, int(h), int(w), int(interp_down), s)))
+        self._call(lambda s: ctx._check(lib.avx_resize_hwc(ctx._h, small.ptr, 0, int(h), int(w), K, out.ptr, H, W, int(interp_up), s)))
+        return [self.load(PlaneRef(out, 4 * c, K)) for c in range(K)]
+
     # -- species skeleton ------------------------------------------------------------------------------
     def front(self, image: np.ndarray, panorama_scale: float) -> List[Val]:
         """to_float01 + srgb_to_linear + panorama_warp; the uint8 baseline goes to d_base.  -> linear [R, G, B]."""
@@ -517,3 +542,30 @@ class DeviceBackend:
         s = self.ctx._s(stream)
         for fn in self.plan:
             fn(s)
+
+
+class DeviceProbes:
+    """Frame statistics a species branches on, computed on the device (8 bytes come back to the host)."""
+
+    _cache: Dict[Tuple[int, int], tuple] = {}
+
+    @classmethod
+    def median_luma(cls, image: np.ndarray) -> float:
+        """float(np.median(0.2126 R + 0.7152 G + 0.0722 B)) of to_float01(image) (rat_uv.py:100-105)."""
+        assert image.dtype == np.uint8
+        H, W = image.shape[:2]
+        hit = cls._cache.get((H, W))
+        if hit is None:
+            if len(cls._cache) >= 4:
+                cls._cache.pop(next(iter(cls._cache)))[0].close()
+            be = DeviceBackend(H, W)
+            ch = [be.load(PlaneRef(be.d_in, c, 3, "u8")) / 255.0 for c in range(3)]
+            slot_val = be.percentile(0.2126 * ch[0] + 0.7152 * ch[1] + 0.0722 * ch[2], 50.0)
+            be.flush()
+            hit = (be, slot_val.imm)
+            cls._cache[(H, W)] = hit
+        be, slot = hit
+        ctx = be.ctx
+        ctx.upload(np.ascontiguousarray(image), be.d_in)
+        be.run_device()
+        return float(ctx.download(be.scalars.view(8 * slot, 8), (1,), np.float64)[0])

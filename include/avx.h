@@ -177,6 +177,11 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
 int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, const float* xL_host, const float* xR_host, const float* ymap_host,
                           const float* wL_host, const float* wR_host, int Ho, int Wo, float* out_hwc_f32, void* stream);
 
+/* cv2.remap(src, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT, borderValue) on K float32 planes that share two
+ * per-pixel float32 maps (anableps.py:217-226): coordinates quantised to 1/32 px like OpenCV. */
+int avx_remap_linear_planes(avx_ctx* ctx, const float* src_planes, int K, int H, int W, const float* mapx_dev,
+                            const float* mapy_dev, float* dst_planes, float border_value, void* stream);
+
 /* cv2.Sobel(plane, CV_32F, 1,0 / 0,1, ksize=3, BORDER_REFLECT101) -> gx, gy (mantis_shrimp.py:122-131). */
 int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
 

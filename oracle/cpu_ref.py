@@ -54,6 +54,7 @@ def lib() -> ctypes.CDLL:
             "cvref_resize_linear_u8",
             "cvref_resize_cubic_f32",
             "cvref_resize_area_f32",
+            "cvref_resize_nearest_f32",
             "cvref_remap_linear_f32",
             "cvref_sobel3_f32",
         ):
@@ -822,7 +823,7 @@ INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA = 0, 1, 2, 3  # cv2 constan
 
 
 def cv_resize(img: np.ndarray, dsize: Tuple[int, int], interpolation: int = INTER_LINEAR) -> np.ndarray:
-    """cv2.resize(img, (W_out, H_out), interpolation=...) for HxW[xC] float32 (LINEAR/CUBIC/AREA) or uint8 (LINEAR)."""
+    """cv2.resize(img, (W_out, H_out), interpolation=...) for HxW[xC] float32 (NEAREST/LINEAR/CUBIC/AREA) or uint8 (LINEAR)."""
     Wd, Hd = int(dsize[0]), int(dsize[1])
     squeeze = img.ndim == 2
     a = np.ascontiguousarray(img[..., None] if squeeze else img)
@@ -834,7 +835,8 @@ def cv_resize(img: np.ndarray, dsize: Tuple[int, int], interpolation: int = INTE
     else:
         a = a.astype(np.float32, copy=False)
         out = np.empty((Hd, Wd, C), np.float32)
-        fn = {INTER_LINEAR: "cvref_resize_linear_f32", INTER_CUBIC: "cvref_resize_cubic_f32", INTER_AREA: "cvref_resize_area_f32"}[interpolation]
+        fn = {INTER_NEAREST: "cvref_resize_nearest_f32", INTER_LINEAR: "cvref_resize_linear_f32", INTER_CUBIC: "cvref_resize_cubic_f32",
+              INTER_AREA: "cvref_resize_area_f32"}[interpolation]
         if interpolation == INTER_AREA and (Wd > W or Hd > H):
             fn = "cvref_resize_linear_f32"  # cv::resize: INTER_AREA when enlarging behaves like INTER_LINEAR
         getattr(lib(), fn)(_p(a), H, W, C, _p(out), Hd, Wd)

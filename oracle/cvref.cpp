@@ -193,6 +193,20 @@ void cvref_resize_area_f32(const float* src, int H, int W, int C, float* dst, in
         for (size_t i = 0; i < sum.size(); ++i) dst[(size_t)prev_dy * Wd * C + i] = sum[i];
 }
 
+// cv::resize(..., INTER_NEAREST) (resizeNN): sx = min(cvFloor(dx * ifx), W - 1), ifx = 1 / ((double)Wd / W).
+void cvref_resize_nearest_f32(const float* src, int H, int W, int C, float* dst, int Hd, int Wd) {
+    const double ifx = 1.0 / ((double)Wd / W), ify = 1.0 / ((double)Hd / H);
+    for (int y = 0; y < Hd; ++y) {
+        int sy = (int)std::floor(y * ify);
+        sy = sy < H - 1 ? sy : H - 1;
+        for (int x = 0; x < Wd; ++x) {
+            int sx = (int)std::floor(x * ifx);
+            sx = sx < W - 1 ? sx : W - 1;
+            for (int c = 0; c < C; ++c) dst[((size_t)y * Wd + x) * C + c] = src[((size_t)sy * W + sx) * C + c];
+        }
+    }
+}
+
 // cv::remap(float HWC, mapx, mapy (CV_32FC1), INTER_LINEAR, BORDER_CONSTANT, borderValue): coordinates are
 // quantised to 1/32 px (cvRound(v*32)), weights come from the float table (1-fx)(1-fy) ... of that grid.
 void cvref_remap_linear_f32(const float* src, int H, int W, int C, const float* mapx, const float* mapy, float* dst, int Hd, int Wd,

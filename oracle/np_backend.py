@@ -80,6 +80,19 @@ class NumpyBackend:
         v = np.ascontiguousarray(v, dtype=np.float32)
         return O.cv_sobel3(v, 1, 0), O.cv_sobel3(v, 0, 1)
 
+    def remap(self, vals: Sequence, map_x, map_y, border_value: float = 0.0):
+        src = np.stack([np.broadcast_to(v, (self.H, self.W)) for v in vals], axis=-1).astype(np.float32)
+        mx = np.ascontiguousarray(np.broadcast_to(map_x, (self.H, self.W)), dtype=np.float32)
+        my = np.ascontiguousarray(np.broadcast_to(map_y, (self.H, self.W)), dtype=np.float32)
+        out = O.cv_remap_linear(src, mx, my, border_value)
+        return [out[..., c] for c in range(out.shape[2])]
+
+    def down_up(self, vals: Sequence, h: int, w: int, interp_down: int, interp_up: int):
+        img = np.stack([np.broadcast_to(v, (self.H, self.W)) for v in vals], axis=-1)
+        small = O.cv_resize(img, (w, h), interp_down)
+        out = O.cv_resize(small, (self.W, self.H), interp_up)
+        return [out[..., c] for c in range(out.shape[2])]
+
     def front(self, image: np.ndarray, panorama_scale: float):
         self.dtype = image.dtype
         img_lin = O.uv_srgb_to_linear(O.to_float01(image))
@@ -107,8 +120,21 @@ for _name, _fn in dict(sqrt=np.sqrt, exp=np.exp, log=np.log, sin=np.sin, cos=np.
     setattr(NumpyBackend, _name, staticmethod(_fn))
 
 
-def run(species, image: np.ndarray):
+class NumpyProbes:
+    @staticmethod
+    def median_luma(image: np.ndarray) -> float:
+        """rat_uv.py:100-105."""
+        img01 = O.to_float01(image)
+        Y = 0.2126 * img01[..., 0] + 0.7152 * img01[..., 1] + 0.0722 * img01[..., 2]
+        return float(np.median(Y))
+
+
+def run(species, image: np.ndarray, **kw):
     """(baseline, out) of a backend-generic species evaluated with NumPy."""
     be = NumpyBackend(image.shape[0], image.shape[1])
-    species.render(be, image)
+    v = species.variant(image, NumpyProbes, **kw)
+    if v is None:
+        species.render(be, image)
+    else:
+        species.render(be, image, v)
     return be.baseline_out, be.out

@@ -13,10 +13,14 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _species():
+# kept in step with animal_vision_amd.animals.UV_CLASS (asserted below): collection must not need the library
+SPECIES = ["anableps", "anchovy", "damselfish", "goldfish", "guppy", "morpho", "rat_uv", "reindeer"]
+
+
+def test_species_list_complete():
     from animal_vision_amd import animals
 
-    return sorted(animals.UV_CLASS)
+    assert sorted(animals.UV_CLASS) == SPECIES
 
 
 def _check(got, want, what, frac_beyond=2e-3, frac_any=0.05):
@@ -25,7 +29,7 @@ def _check(got, want, what, frac_beyond=2e-3, frac_any=0.05):
     assert float((diff > 0).mean()) <= frac_any, (what, "fraction != :", float((diff > 0).mean()))
 
 
-@pytest.mark.parametrize("mod", ["reindeer", "goldfish"])
+@pytest.mark.parametrize("mod", SPECIES)
 def test_species_vs_reference_golden(mod):
     from animal_vision_amd import animals
 
@@ -38,7 +42,7 @@ def test_species_vs_reference_golden(mod):
         _check(out, g[f"{mod}_out_{k}"], (mod, k))
 
 
-@pytest.mark.parametrize("mod", ["reindeer", "goldfish"])
+@pytest.mark.parametrize("mod", SPECIES)
 def test_species_vs_oracle_other_sizes(mod):
     from animal_vision_amd import animals
     from oracle import np_backend
@@ -59,6 +63,25 @@ def test_species_vs_oracle_other_sizes(mod):
     wbase, wout = np_backend.run(sp, frame2)
     assert np.array_equal(base, wbase)
     _check(out, wout, (mod, "replay"))
+
+
+def test_rat_uv_night_branch_and_auto_mode():
+    from animal_vision_amd.animals import RatUV
+    from oracle import np_backend
+
+    g = load_golden("uv_species")
+    sp = RatUV()
+    for k in ("s64", "n50"):
+        _check(sp.visualize(g[f"in_{k}"], mode="night")[1], g[f"rat_uv_night_out_{k}"], ("night", k))
+    dark = (g["in_s64"] // 6).astype(np.uint8)  # median luminance < 0.12: `auto` takes the night branch
+    assert sp.variant(dark, np_backend.NumpyProbes) == "night"
+    from animal_vision_amd.planevm import DeviceProbes
+
+    assert abs(DeviceProbes.median_luma(dark) - np_backend.NumpyProbes.median_luma(dark)) < 1e-6
+    base, out = sp.visualize(dark)
+    wbase, wout = np_backend.run(sp, dark)
+    assert np.array_equal(base, wbase)
+    _check(out, wout, "auto->night")
 
 
 def test_ew_program_basic_ops_and_reductions():

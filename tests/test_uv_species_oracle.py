@@ -7,7 +7,7 @@ import pytest
 
 from conftest import load_golden
 
-SPECIES = ["reindeer", "goldfish"]
+SPECIES = ["reindeer", "goldfish", "damselfish", "rat_uv", "anableps", "anchovy", "guppy", "morpho"]
 
 
 @pytest.mark.parametrize("mod", SPECIES)

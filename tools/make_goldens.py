@@ -448,6 +448,8 @@ def g_uv_species():
                 base, res = sp.visualize(f)
                 assert base.dtype == np.uint8 and res.dtype == np.uint8, (mod, base.dtype, res.dtype)
                 out[f"{mod}_base_{k}"], out[f"{mod}_out_{k}"] = base, res
+                if mod == "rat_uv":  # the branch `mode="auto"` does not take on these frames
+                    out[f"{mod}_night_out_{k}"] = sp.visualize(f, mode="night")[1]
             print(f"   {mod}: ok")
         except Exception as e:  # noqa: BLE001
             import traceback
