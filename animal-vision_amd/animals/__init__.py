@@ -16,6 +16,14 @@ from .anableps import Anableps  # noqa: F401
 from .anchovy import Anchovy  # noqa: F401
 from .guppy import Guppy  # noqa: F401
 from .morpho import Morpho  # noqa: F401
+from .heliconius import Heliconius  # noqa: F401
+from .pieris import Pieris  # noqa: F401
+from .hummingbird import Hummingbird  # noqa: F401
+from .kestrel import Kestrel  # noqa: F401
+from .jumping_spider import JumpingSpider  # noqa: F401
+from .dragonfly import Dragonfly  # noqa: F401
 
 UV_CLASS = {"reindeer": "Reindeer", "goldfish": "Goldfish", "damselfish": "Damselfish", "rat_uv": "RatUV", "anableps": "Anableps",
-            "anchovy": "Anchovy", "guppy": "Guppy", "morpho": "Morpho"}
+            "anchovy": "Anchovy", "guppy": "Guppy", "morpho": "Morpho",
+            "heliconius": "Heliconius", "pieris": "Pieris", "hummingbird": "Hummingbird",
+            "kestrel": "Kestrel", "jumping_spider": "JumpingSpider", "dragonfly": "Dragonfly"}

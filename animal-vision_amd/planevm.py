@@ -380,6 +380,10 @@ class DeviceBackend:
         self.store(v, ref)
         return self.load(ref)
 
+    def mat_all(self, vals: Sequence) -> List[Val]:
+        """mat() of several values, into consecutive planes (a following blur takes them without a copy)."""
+        return self.mat_many(vals)[0]
+
     def mat_many(self, vals: Sequence) -> Tuple[List[Val], DeviceBuffer]:
         """Materialise into CONSECUTIVE planes of one buffer (for multi-plane blurs / percentiles)."""
         refs = self.new_planes(len(vals))

@@ -60,6 +60,10 @@ class NumpyBackend:
     def mat(v):
         return v
 
+    @staticmethod
+    def mat_all(vals):
+        return list(vals)
+
     # -- stages ----------------------------------------------------------------------------------------
     @staticmethod
     def blur(vals: Sequence, sigma: float):

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 # kept in step with animal_vision_amd.animals.UV_CLASS (asserted below): collection must not need the library
-SPECIES = ["anableps", "anchovy", "damselfish", "goldfish", "guppy", "morpho", "rat_uv", "reindeer"]
+SPECIES = ["anableps", "anchovy", "damselfish", "dragonfly", "goldfish", "guppy", "heliconius", "hummingbird", "jumping_spider", "kestrel", "morpho",
+           "pieris", "rat_uv", "reindeer"]
 
 
 def test_species_list_complete():

@@ -7,7 +7,8 @@ import pytest
 
 from conftest import load_golden
 
-SPECIES = ["reindeer", "goldfish", "damselfish", "rat_uv", "anableps", "anchovy", "guppy", "morpho"]
+SPECIES = ["reindeer", "goldfish", "damselfish", "rat_uv", "anableps", "anchovy", "guppy", "morpho", "heliconius", "pieris", "hummingbird", "kestrel",
+           "jumping_spider", "dragonfly"]
 
 
 @pytest.mark.parametrize("mod", SPECIES)
