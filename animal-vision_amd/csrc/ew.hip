@@ -24,6 +24,7 @@ using namespace avxk;
 namespace {
 
 constexpr int kET = 256;
+constexpr int PX = 4;  // pixels per thread: one instruction dispatch serves 4 x 64 pixels per wave
 
 struct EwArgs {
     avx_ew_insn insn[AVX_EW_MAX_INSN];
@@ -35,13 +36,21 @@ struct EwArgs {
     const double* scalars;
     float* partial;  // [block][n_acc]
     const float* lut; const float* thr; const uint8_t* coarse; uint32_t lo_key;
-    int uses_encode;
+    int uses_encode, uses_xy;
 };
 
 __device__ __forceinline__ float acc_init(int kind) { return kind == AVX_EW_ACC_MIN ? INFINITY : (kind == AVX_EW_ACC_MAX ? -INFINITY : 0.f); }
+__device__ __forceinline__ float acc_merge(int kind, float a, float b) { return kind == AVX_EW_ACC_MIN ? fminf(a, b) : (kind == AVX_EW_ACC_MAX ? fmaxf(a, b) : a + b); }
 
+// The per-pixel register files live in VGPRs: four float[NREG] arrays (one per pixel of the thread), indexed by the
+// wave-uniform register numbers of the instruction through s_set_gpr_idx (no LDS, no scratch).  NREG = 16 leaves
+// room for 4 waves/SIMD, NREG = 32 for 2; the host picks the smallest that fits the program.
+#define EW_FOR for (int k = 0; k < PX; ++k)
+#define EW_UN(expr) { _Pragma("unroll") EW_FOR { const float x = xs[k]; r[k] = (expr); } } break
+#define EW_BIN(expr) { _Pragma("unroll") EW_FOR { const float x = xs[k], y = ys[k]; r[k] = (expr); } } break
+
+template <int NREG>
 __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
-    __shared__ float R[AVX_EW_MAX_REGS][kET];
     __shared__ float thr[256];
     __shared__ uint8_t coarse[1024];
     __shared__ float red[kET / 64];
@@ -51,87 +60,117 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
         for (int i = tid; i < 1024; i += kET) coarse[i] = a.coarse[i];
         __syncthreads();
     }
-    for (int k = 0; k < a.n_acc; ++k) R[a.acc_reg[k]][tid] = acc_init(a.acc_kind[k]);
-    for (size_t base = (size_t)blockIdx.x * kET; base < a.n; base += (size_t)gridDim.x * kET) {
-        const size_t i = base + tid;
-        const bool valid = i < a.n;
-        const size_t ii = valid ? i : a.n - 1;  // invalid lanes compute on the last pixel, store / accumulate nothing
+    float R0[NREG], R1[NREG], R2[NREG], R3[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) { R0[i] = 0.f; R1[i] = 0.f; R2[i] = 0.f; R3[i] = 0.f; }
+    for (int k = 0; k < a.n_acc; ++k) {
+        const float v = acc_init(a.acc_kind[k]);
+        const int reg = a.acc_reg[k] & (NREG - 1);
+        R0[reg] = v; R1[reg] = v; R2[reg] = v; R3[reg] = v;
+    }
+    const uint32_t n = (uint32_t)a.n, W = (uint32_t)a.W;  // the host checks H*W < 2^31
+    for (uint32_t base = blockIdx.x * (kET * PX); base < n; base += gridDim.x * (kET * PX)) {
+        uint32_t ii[PX], px[PX], py[PX];
+        bool valid[PX];
+#pragma unroll
+        EW_FOR {
+            const uint32_t i = base + tid + k * kET;
+            valid[k] = i < n;
+            ii[k] = valid[k] ? i : n - 1;  // invalid lanes compute on the last pixel, store / accumulate nothing
+            px[k] = py[k] = 0;
+        }
+        if (a.uses_xy) {
+#pragma unroll
+            EW_FOR { py[k] = ii[k] / W; px[k] = ii[k] - py[k] * W; }
+        }
         for (int pc = 0; pc < a.n_insn; ++pc) {
             const avx_ew_insn in = a.insn[pc];
-            const float x = R[in.a][tid], y = R[in.b][tid];
-            float r;
+            const int ra = in.a & (NREG - 1), rb = in.b & (NREG - 1), rd = in.dst & (NREG - 1);
+            const float xs[PX] = {R0[ra], R1[ra], R2[ra], R3[ra]};
+            const float ys[PX] = {R0[rb], R1[rb], R2[rb], R3[rb]};
+            float r[PX];
             switch (in.op) {
-                case AVX_EW_CONST: r = __uint_as_float(in.imm); break;
-                case AVX_EW_SCALAR: r = (float)a.scalars[in.imm]; break;
+                case AVX_EW_CONST: { const float c = __uint_as_float(in.imm); _Pragma("unroll") EW_FOR r[k] = c; } break;
+                case AVX_EW_SCALAR: { const float c = (float)a.scalars[in.imm]; _Pragma("unroll") EW_FOR r[k] = c; } break;
                 case AVX_EW_LOAD: {
                     const avx_ew_plane p = a.planes[in.imm];
-                    if (p.kind == AVX_EW_PLANE_F32) r = ((const float*)p.ptr)[ii * (size_t)p.stride];
-                    else if (p.kind == AVX_EW_PLANE_U8) r = (float)((const uint8_t*)p.ptr)[ii * (size_t)p.stride];
-                    else if (p.kind == AVX_EW_PLANE_U8_LUT) r = a.lut[((const uint8_t*)p.ptr)[ii * (size_t)p.stride]];
-                    else if (p.kind == AVX_EW_PLANE_COL) r = ((const float*)p.ptr)[ii % (size_t)a.W];
-                    else r = ((const float*)p.ptr)[ii / (size_t)a.W];
+                    if (p.kind == AVX_EW_PLANE_F32) { _Pragma("unroll") EW_FOR r[k] = ((const float*)p.ptr)[(size_t)ii[k] * p.stride]; }
+                    else if (p.kind == AVX_EW_PLANE_U8) { _Pragma("unroll") EW_FOR r[k] = (float)((const uint8_t*)p.ptr)[(size_t)ii[k] * p.stride]; }
+                    else if (p.kind == AVX_EW_PLANE_U8_LUT) { _Pragma("unroll") EW_FOR r[k] = a.lut[((const uint8_t*)p.ptr)[(size_t)ii[k] * p.stride]]; }
+                    else if (p.kind == AVX_EW_PLANE_COL) { _Pragma("unroll") EW_FOR r[k] = ((const float*)p.ptr)[px[k]]; }
+                    else { _Pragma("unroll") EW_FOR r[k] = ((const float*)p.ptr)[py[k]]; }
                     break;
                 }
                 case AVX_EW_STORE: {
                     const avx_ew_plane p = a.planes[in.imm];
-                    if (valid) {
-                        if (p.kind == AVX_EW_PLANE_F32) ((float*)p.ptr)[i * (size_t)p.stride] = x;
-                        else ((uint8_t*)p.ptr)[i * (size_t)p.stride] = (uint8_t)quantize_coarse<float, 2>(x, thr, coarse, a.lo_key);
+                    if (p.kind == AVX_EW_PLANE_F32) {
+#pragma unroll
+                        EW_FOR if (valid[k]) ((float*)p.ptr)[(size_t)ii[k] * p.stride] = xs[k];
+                    } else {
+#pragma unroll
+                        EW_FOR if (valid[k]) ((uint8_t*)p.ptr)[(size_t)ii[k] * p.stride] = (uint8_t)quantize_coarse<float, 2>(xs[k], thr, coarse, a.lo_key);
                     }
                     continue;
                 }
-                case AVX_EW_ADD: r = x + y; break;
-                case AVX_EW_SUB: r = x - y; break;
-                case AVX_EW_MUL: r = x * y; break;
-                case AVX_EW_DIV: r = x / y; break;
-                case AVX_EW_MIN: r = fminf(x, y); break;
-                case AVX_EW_MAX: r = fmaxf(x, y); break;
-                case AVX_EW_POW: r = powf(x, y); break;
-                case AVX_EW_ATAN2: r = atan2f(x, y); break;
-                case AVX_EW_NEG: r = -x; break;
-                case AVX_EW_ABS: r = fabsf(x); break;
-                case AVX_EW_SQRT: r = __fsqrt_rn(x); break;
-                case AVX_EW_EXP: r = expf(x); break;
-                case AVX_EW_LOG: r = logf(x); break;
-                case AVX_EW_SIN: r = sinf(x); break;
-                case AVX_EW_COS: r = cosf(x); break;
-                case AVX_EW_FLOOR: r = floorf(x); break;
-                case AVX_EW_CEIL: r = ceilf(x); break;
-                case AVX_EW_CLIP01: r = x < 0.f ? 0.f : (x > 1.f ? 1.f : x); break;
-                case AVX_EW_TANH: r = tanhf(x); break;
-                case AVX_EW_LT: r = x < y ? 1.f : 0.f; break;
-                case AVX_EW_LE: r = x <= y ? 1.f : 0.f; break;
-                case AVX_EW_GT: r = x > y ? 1.f : 0.f; break;
-                case AVX_EW_GE: r = x >= y ? 1.f : 0.f; break;
-                case AVX_EW_EQ: r = x == y ? 1.f : 0.f; break;
-                case AVX_EW_AND: r = (x != 0.f && y != 0.f) ? 1.f : 0.f; break;
-                case AVX_EW_OR: r = (x != 0.f || y != 0.f) ? 1.f : 0.f; break;
-                case AVX_EW_NOT: r = x != 0.f ? 0.f : 1.f; break;
-                case AVX_EW_SELECT: r = x != 0.f ? y : R[in.imm & 0xff][tid]; break;
-                case AVX_EW_ACCMIN: if (valid) R[in.dst][tid] = fminf(R[in.dst][tid], x); continue;
-                case AVX_EW_ACCMAX: if (valid) R[in.dst][tid] = fmaxf(R[in.dst][tid], x); continue;
-                case AVX_EW_ACCSUM: if (valid) R[in.dst][tid] = R[in.dst][tid] + x; continue;
-                default: r = 0.f; break;
+                case AVX_EW_ADD: EW_BIN(x + y);
+                case AVX_EW_SUB: EW_BIN(x - y);
+                case AVX_EW_MUL: EW_BIN(x * y);
+                case AVX_EW_DIV: EW_BIN(x / y);
+                case AVX_EW_MIN: EW_BIN(fminf(x, y));
+                case AVX_EW_MAX: EW_BIN(fmaxf(x, y));
+                case AVX_EW_POW: EW_BIN(powf(x, y));
+                case AVX_EW_ATAN2: EW_BIN(atan2f(x, y));
+                case AVX_EW_NEG: EW_UN(-x);
+                case AVX_EW_ABS: EW_UN(fabsf(x));
+                case AVX_EW_SQRT: EW_UN(__fsqrt_rn(x));
+                case AVX_EW_EXP: EW_UN(expf(x));
+                case AVX_EW_LOG: EW_UN(logf(x));
+                case AVX_EW_SIN: EW_UN(sinf(x));
+                case AVX_EW_COS: EW_UN(cosf(x));
+                case AVX_EW_FLOOR: EW_UN(floorf(x));
+                case AVX_EW_CEIL: EW_UN(ceilf(x));
+                case AVX_EW_CLIP01: EW_UN(x < 0.f ? 0.f : (x > 1.f ? 1.f : x));
+                case AVX_EW_TANH: EW_UN(tanhf(x));
+                case AVX_EW_LT: EW_BIN(x < y ? 1.f : 0.f);
+                case AVX_EW_LE: EW_BIN(x <= y ? 1.f : 0.f);
+                case AVX_EW_GT: EW_BIN(x > y ? 1.f : 0.f);
+                case AVX_EW_GE: EW_BIN(x >= y ? 1.f : 0.f);
+                case AVX_EW_EQ: EW_BIN(x == y ? 1.f : 0.f);
+                case AVX_EW_AND: EW_BIN((x != 0.f && y != 0.f) ? 1.f : 0.f);
+                case AVX_EW_OR: EW_BIN((x != 0.f || y != 0.f) ? 1.f : 0.f);
+                case AVX_EW_NOT: EW_UN(x != 0.f ? 0.f : 1.f);
+                case AVX_EW_SELECT: {
+                    const int rc = in.imm & (NREG - 1);
+                    const float zs[PX] = {R0[rc], R1[rc], R2[rc], R3[rc]};
+#pragma unroll
+                    EW_FOR r[k] = xs[k] != 0.f ? ys[k] : zs[k];
+                    break;
+                }
+                case AVX_EW_ACCMIN: case AVX_EW_ACCMAX: case AVX_EW_ACCSUM: {
+                    const int kind = in.op == AVX_EW_ACCMIN ? AVX_EW_ACC_MIN : (in.op == AVX_EW_ACCMAX ? AVX_EW_ACC_MAX : AVX_EW_ACC_SUM);
+                    const float cur[PX] = {R0[rd], R1[rd], R2[rd], R3[rd]};
+#pragma unroll
+                    EW_FOR r[k] = valid[k] ? acc_merge(kind, cur[k], xs[k]) : cur[k];
+                    break;
+                }
+                default: { _Pragma("unroll") EW_FOR r[k] = 0.f; } break;
             }
-            R[in.dst][tid] = r;
+            R0[rd] = r[0]; R1[rd] = r[1]; R2[rd] = r[2]; R3[rd] = r[3];
         }
     }
     // block-level reduction of the accumulators -> partial[block][k]
     const int lane = tid & 63, wave = tid >> 6;
     for (int k = 0; k < a.n_acc; ++k) {
-        float v = R[a.acc_reg[k]][tid];
-        const int kind = a.acc_kind[k];
+        const int kind = a.acc_kind[k], reg = a.acc_reg[k] & (NREG - 1);
+        float v = acc_merge(kind, acc_merge(kind, R0[reg], R1[reg]), acc_merge(kind, R2[reg], R3[reg]));
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float w = __shfl_xor(v, o);
-            v = kind == AVX_EW_ACC_MIN ? fminf(v, w) : (kind == AVX_EW_ACC_MAX ? fmaxf(v, w) : v + w);
-        }
+        for (int o = 32; o > 0; o >>= 1) v = acc_merge(kind, v, __shfl_xor(v, o));
         __syncthreads();
         if (lane == 0) red[wave] = v;
         __syncthreads();
         if (tid == 0) {
             float t = red[0];
-            for (int w = 1; w < kET / 64; ++w) t = kind == AVX_EW_ACC_MIN ? fminf(t, red[w]) : (kind == AVX_EW_ACC_MAX ? fmaxf(t, red[w]) : t + red[w]);
+            for (int w = 1; w < kET / 64; ++w) t = acc_merge(kind, t, red[w]);
             a.partial[(size_t)blockIdx.x * a.n_acc + k] = t;
         }
     }
@@ -175,7 +214,9 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
     if (!ws) return AVX_ERR_NOMEM;
     EwArgs a;
     a.n_insn = p->n_insn; a.n_acc = p->n_acc; a.W = p->W; a.n = (size_t)p->H * p->W;
-    a.uses_encode = 0;
+    a.uses_encode = 0; a.uses_xy = 0;
+    AVX_REQUIRE(ctx, (size_t)p->H * p->W < ((size_t)1 << 31), "avx_ew_run: frame too large");
+    int max_reg = 0;
     for (int i = 0; i < p->n_planes; ++i) {
         a.planes[i] = p->planes_host[i];
         AVX_REQUIRE(ctx, a.planes[i].ptr && a.planes[i].stride >= 1 && a.planes[i].kind >= 0 && a.planes[i].kind <= AVX_EW_PLANE_U8_ENC, "avx_ew_run: bad plane entry");
@@ -186,6 +227,7 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
         if (in.op == AVX_EW_LOAD || in.op == AVX_EW_STORE) {
             AVX_REQUIRE(ctx, (int)in.imm < p->n_planes, "avx_ew_run: plane index out of range");
             const int kind = a.planes[in.imm].kind;
+            if (kind == AVX_EW_PLANE_COL || kind == AVX_EW_PLANE_ROW) a.uses_xy = 1;
             if (in.op == AVX_EW_STORE) {
                 AVX_REQUIRE(ctx, kind == AVX_EW_PLANE_F32 || kind == AVX_EW_PLANE_U8_ENC, "avx_ew_run: store to a read-only plane kind");
                 if (kind == AVX_EW_PLANE_U8_ENC) a.uses_encode = 1;
@@ -197,15 +239,20 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
         if (in.op == AVX_EW_SELECT) AVX_REQUIRE(ctx, (in.imm & 0xff) < AVX_EW_MAX_REGS, "avx_ew_run: register index out of range");
         AVX_REQUIRE(ctx, in.op <= AVX_EW_ACCSUM, "avx_ew_run: unknown opcode");
         a.insn[i] = in;
+        max_reg = max_reg > in.dst ? max_reg : in.dst;
+        max_reg = max_reg > in.a ? max_reg : in.a;
+        max_reg = max_reg > in.b ? max_reg : in.b;
+        if (in.op == AVX_EW_SELECT) max_reg = max_reg > (int)(in.imm & 0xff) ? max_reg : (int)(in.imm & 0xff);
     }
     FinalArgs f{};
     for (int k = 0; k < p->n_acc; ++k) {
         const int reg = p->acc_host[3 * k], kind = p->acc_host[3 * k + 1], slot = p->acc_host[3 * k + 2];
         AVX_REQUIRE(ctx, reg >= 0 && reg < AVX_EW_MAX_REGS && kind >= AVX_EW_ACC_MIN && kind <= AVX_EW_ACC_MEAN && slot >= 0 && slot < p->n_scalars, "avx_ew_run: bad accumulator entry");
         a.acc_reg[k] = (uint8_t)reg; a.acc_kind[k] = (uint8_t)kind;
+        max_reg = max_reg > reg ? max_reg : reg;
         f.kind[k] = (uint8_t)kind; f.slot[k] = slot;
     }
-    const size_t want = (a.n + kET - 1) / kET, cap = (size_t)ctx->num_cus * 8;
+    const size_t want = (a.n + kET * PX - 1) / (kET * PX), cap = (size_t)ctx->num_cus * 8;
     const int grid = (int)(want < cap ? want : cap);
     if (p->n_acc) {
         const size_t need = (size_t)grid * p->n_acc * sizeof(float);
@@ -219,7 +266,8 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
     }
     a.scalars = p->scalars_dev; a.partial = (float*)ws->d_ew;
     a.lut = ctx->d_decode_lut; a.thr = ctx->d_enc_thr_f32; a.coarse = ctx->d_coarse_f32; a.lo_key = ctx->coarse_lo_key[0];
-    hipLaunchKernelGGL(k_ew, dim3(grid), dim3(kET), 0, s, a);
+    if (max_reg < 16) hipLaunchKernelGGL(k_ew<16>, dim3(grid), dim3(kET), 0, s, a);
+    else hipLaunchKernelGGL(k_ew<32>, dim3(grid), dim3(kET), 0, s, a);
     if (p->n_acc) {
         f.partial = a.partial; f.nblocks = grid; f.n_acc = p->n_acc; f.scalars = p->scalars_dev; f.n = (double)a.n;
         hipLaunchKernelGGL(k_ew_final, dim3(1), dim3(64 * p->n_acc), 0, s, f);

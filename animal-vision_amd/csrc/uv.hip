@@ -260,6 +260,7 @@ struct SelState {
     uint32_t key_lo, key_hi;    // results: key of x[k] and of x[k+1]
     uint32_t cnt_in_bin;        // size of the finally selected bin (duplicates of x[k])
     uint32_t next_key;          // smallest key > key_lo
+    uint32_t next_above;        // smallest key above the selected 22-bit prefix range (last histogram pass)
 };
 
 __device__ __forceinline__ uint32_t f2key(float f) {
@@ -270,32 +271,49 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-__global__ __launch_bounds__(kT) void k_sel_hist(const float* __restrict__ x, size_t n, int shift, int bits, const SelState* st,
-                                                 uint32_t* hist) {
+// `find_next` (last pass): also the smallest key ABOVE the selected 22-bit prefix range (the successor of x[k] when
+// x[k] is the largest key of its prefix), block-reduced: one atomicMin per workgroup.
+__global__ __launch_bounds__(kT) void k_sel_hist(const float* __restrict__ x, size_t n, int shift, int bits, SelState* st,
+                                                 uint32_t* hist, int find_next) {
     __shared__ uint32_t h[2048];
+    __shared__ uint32_t wmin[kT / 64];
     const int nb = 1 << bits;
     for (int i = threadIdx.x; i < nb; i += kT) h[i] = 0;
     __syncthreads();
     const uint32_t prefix = st->prefix, mask = st->mask;
+    const uint32_t above = prefix | ~mask;  // largest key with this prefix
+    uint32_t best = 0xffffffffu;
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
         const uint32_t k = f2key(x[i]);
         if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & (nb - 1)], 1u);
+        else if (find_next && k > above && k < best) best = k;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += kT)
         if (h[i]) atomicAdd(&hist[i], h[i]);
+    if (find_next) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o); best = t < best ? t : best; }
+        if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kT / 64; ++w) best = wmin[w] < best ? wmin[w] : best;
+            if (best != 0xffffffffu) atomicMin(&st->next_above, best);
+        }
+    }
 }
 
 __global__ void k_sel_init(SelState* st, unsigned long long rank) {
     if (threadIdx.x != 0) return;
     st->prefix = 0; st->mask = 0; st->rank = rank; st->key_lo = 0; st->key_hi = 0; st->cnt_in_bin = 0; st->next_key = 0xffffffffu;
+    st->next_above = 0xffffffffu;
 }
 
 // One workgroup: 256 threads each own nb/256 consecutive bins; an LDS scan of the 256 chunk sums finds the
 // chunk that holds the rank, its owner finishes inside the chunk.  Also re-zeroes the histogram.
 __global__ __launch_bounds__(kT) void k_sel_pick(uint32_t* hist, int shift, int bits, SelState* st, int last) {
     __shared__ unsigned long long csum[kT];
-    __shared__ int sel_chunk;
+    __shared__ int sel_chunk, sel_bin;
     const int nb = 1 << bits, per = nb / kT, t = threadIdx.x;  // nb in {1024, 2048}
     uint32_t loc[8];
     unsigned long long s = 0;
@@ -327,21 +345,23 @@ __global__ __launch_bounds__(kT) void k_sel_pick(uint32_t* hist, int shift, int 
         st->prefix |= (uint32_t)b << shift;
         st->mask |= (uint32_t)(nb - 1) << shift;
         st->rank = r - cum;
-        if (last) { st->key_lo = st->prefix; st->cnt_in_bin = loc[i]; st->next_key = 0xffffffffu; }
+        if (last) { st->key_lo = st->prefix; st->cnt_in_bin = loc[i]; sel_bin = b; }
+    }
+    if (last) {  // successor of x[k] among the distinct keys: next non-empty bin of this prefix, else the smallest key above it
+        __syncthreads();
+        __shared__ int first_after[kT];
+        int f = 0x7fffffff;
+        for (int i = per - 1; i >= 0; --i)
+            if (loc[i] && t * per + i > sel_bin) f = t * per + i;
+        first_after[t] = f;
+        __syncthreads();
+        if (t == 0) {
+            int m = 0x7fffffff;
+            for (int c = 0; c < kT; ++c) m = first_after[c] < m ? first_after[c] : m;
+            st->next_key = m != 0x7fffffff ? ((st->prefix & ~(uint32_t)(nb - 1)) | (uint32_t)m) : st->next_above;
+        }
     }
     for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
-}
-
-__global__ __launch_bounds__(kT) void k_sel_next(const float* __restrict__ x, size_t n, SelState* st) {
-    const uint32_t k0 = st->key_lo;
-    uint32_t best = 0xffffffffu;
-    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
-        const uint32_t k = f2key(x[i]);
-        if (k > k0 && k < best) best = k;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o); best = t < best ? t : best; }
-    if ((threadIdx.x & 63) == 0 && best != 0xffffffffu) atomicMin(&st->next_key, best);
 }
 
 // np.percentile's _lerp for a float32 array: everything in float32 (NumPy matches the virtual index and
@@ -538,13 +558,14 @@ static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size
     const int has_next = (size_t)lo + 1 < n;
     hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, s, u.sel, (unsigned long long)lo);
     AVX_HIP(ctx, hipMemsetAsync(u.hist, 0, 2048 * 4, s));
-    const int g = grid_for(ctx, n);
+    // few, fat workgroups: every workgroup flushes its non-empty LDS bins with global atomics
+    const size_t want = (n + (size_t)kT * 16 - 1) / ((size_t)kT * 16), cap = (size_t)ctx->num_cus * 2;
+    const int g = (int)(want < cap ? (want ? want : 1) : cap);
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int p = 0; p < 3; ++p) {
-        hipLaunchKernelGGL(k_sel_hist, dim3(g), dim3(kT), 0, s, x, n, shifts[p], bits[p], u.sel, u.hist);
+        hipLaunchKernelGGL(k_sel_hist, dim3(g), dim3(kT), 0, s, x, n, shifts[p], bits[p], u.sel, u.hist, (p == 2 && has_next) ? 1 : 0);
         hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kT), 0, s, u.hist, shifts[p], bits[p], u.sel, p == 2 ? 1 : 0);
     }
-    if (has_next) hipLaunchKernelGGL(k_sel_next, dim3(g), dim3(kT), 0, s, x, n, u.sel);
     hipLaunchKernelGGL(k_sel_lerp, dim3(1), dim3(64), 0, s, u.sel, gamma, has_next, out_dev);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;

@@ -191,7 +191,7 @@ class _Compiled:
         if len(accs) > _lib.AVX_EW_MAX_ACC:
             raise ValueError("too many reductions in one plane program")
         free = list(range(_lib.AVX_EW_MAX_REGS - len(accs) - 1, -1, -1))  # pop() hands out r0 first
-        acc_reg = {id(o): _lib.AVX_EW_MAX_REGS - 1 - k for k, o in enumerate(accs)}
+        acc_reg = {id(o): 0x80 + k for k, o in enumerate(accs)}  # placeholders: placed just above the temporaries below
         reg: Dict[int, int] = {}
         insn: List[Tuple[int, int, int, int, int]] = []
         for pos, node in enumerate(order):
@@ -203,6 +203,7 @@ class _Compiled:
                     free.append(reg[id(a)])
             if not free:
                 raise ValueError("plane program needs more than %d live registers: materialise an intermediate with be.mat()" % _lib.AVX_EW_MAX_REGS)
+            free.sort(reverse=True)  # lowest register first: small programs run on the 16-register kernel
             r = free.pop()
             reg[id(node)] = r
             if node.op == "const":
@@ -227,6 +228,11 @@ class _Compiled:
                     insn.append((EW[op], acc_reg[id(o)], r, 0, 0))
             if id(node) not in last:  # nobody reads it later (an output-only node): release at once
                 free.append(r)
+        top = max([t[1] for t in insn if t[1] < 0x80] + [t[2] for t in insn] + [t[3] for t in insn]
+                  + [t[4] for t in insn if t[0] == EW["SELECT"]] + [0]) + 1
+        acc_reg = {k: top + (v - 0x80) for k, v in acc_reg.items()}
+        insn = [(op, top + (d - 0x80) if d >= 0x80 else d, a_, b_, imm) for (op, d, a_, b_, imm) in insn]
+        self.n_regs = top + len(accs)
         if len(insn) > _lib.AVX_EW_MAX_INSN:
             raise ValueError(f"plane program has {len(insn)} instructions (> {_lib.AVX_EW_MAX_INSN}): materialise an intermediate with be.mat()")
         self.n_insn = len(insn)
@@ -270,6 +276,8 @@ class DeviceBackend:
         self._bufs += [self.d_in, self.d_base, self.d_out]
         self.n_programs = 0
         self.n_insn = 0
+        self._memo: Dict = {}         # id(Val) / tuple of ids -> materialised loads (keeps the Vals alive)
+        self.stages: List[str] = []   # human-readable trace of the recorded plan (tools/dbg_plan.py)
 
     # -- memory ------------------------------------------------------------------------------------
     def _alloc(self, nbytes: int) -> DeviceBuffer:
@@ -357,6 +365,7 @@ class DeviceBackend:
         self.n_insn += comp.n_insn
         ctx = self.ctx
         self.plan.append(lambda s, c=comp: ctx._check(lib.avx_ew_run(ctx._h, ctypes.byref(c.program), s)))
+        self.stages.append(f"ew[{comp.n_insn} insn, {comp.n_regs} regs, {comp.program.n_planes} planes, {comp.program.n_acc} acc]")
         self.pending, self._pend_planes, self._pend_slots = [], set(), set()
 
     def _push(self, out):
@@ -372,13 +381,18 @@ class DeviceBackend:
         self._push(("store", self._v(v), ref))
 
     def mat(self, v) -> Val:
-        """Force a value into a plane in HBM (a leaf for later programs)."""
+        """Force a value into a plane in HBM (a leaf for later programs); a value is materialised at most once."""
         v = self._v(v)
         if v.op == "load" and v.imm.kind == "f32":
             return v
+        hit = self._memo.get(id(v))
+        if hit is not None:
+            return hit[1]
         ref = self.new_planes(1)[0]
         self.store(v, ref)
-        return self.load(ref)
+        out = self.load(ref)
+        self._memo[id(v)] = (v, out)  # holds v: ids stay unique
+        return out
 
     def mat_all(self, vals: Sequence) -> List[Val]:
         """mat() of several values, into consecutive planes (a following blur takes them without a copy)."""
@@ -386,10 +400,17 @@ class DeviceBackend:
 
     def mat_many(self, vals: Sequence) -> Tuple[List[Val], DeviceBuffer]:
         """Materialise into CONSECUTIVE planes of one buffer (for multi-plane blurs / percentiles)."""
+        vals = [self._v(v) for v in vals]
+        key = tuple(id(v) for v in vals)
+        hit = self._memo.get(key)
+        if hit is not None:
+            return hit[1], hit[2]
         refs = self.new_planes(len(vals))
         for v, r in zip(vals, refs):
             self.store(v, r)
-        return [self.load(r) for r in refs], refs[0].buf
+        out = [self.load(r) for r in refs]
+        self._memo[key] = (vals, out, refs[0].buf)
+        return out, refs[0].buf
 
     def _reduce(self, v, kind: str) -> Val:
         slot = self.new_slot()
@@ -408,9 +429,12 @@ class DeviceBackend:
         return self.where(rng < 1e-9, 0.0, (x - mn) / rng)
 
     # -- non-elementwise stages ------------------------------------------------------------------------
-    def _call(self, fn):
+    def _call(self, fn, name: str = ""):
         self.flush()
         self.plan.append(fn)
+        import inspect
+
+        self.stages.append(name or inspect.stack()[1].function)
 
     def percentile(self, v, q: float) -> Val:
         """np.percentile over one value or over a list of values taken together (e.g. an HxWx3 array)."""

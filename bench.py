@@ -33,6 +33,13 @@ WORKLOADS = {
     "honeybee_4k": ("honeybee", 2160, 3840, 4),
     "honeybee_mst_1080p": ("honeybee_mst", 1080, 1920, 2),
     "honeybee_mst_4k": ("honeybee_mst", 2160, 3840, 1),
+    # the other UV species: "uv:<module>" = plane-program species, "mantis" = the fused mantis stack
+    "mantis_1080p": ("mantis", 1080, 1920, 4),
+    "mantis_4k": ("mantis", 2160, 3840, 2),
+    **{f"{m}_{r}": (f"uv:{m}", h, w, 4 if r == "1080p" else 2)
+       for m in ("reindeer", "rat_uv", "goldfish", "damselfish", "anableps", "anchovy", "guppy", "morpho", "heliconius", "pieris", "hummingbird",
+                 "kestrel", "jumping_spider", "dragonfly")
+       for r, h, w in (("1080p", 1080, 1920), ("4k", 2160, 3840))},
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
 MFMA_FP16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, same guide
@@ -76,17 +83,38 @@ def main():
         B = args.batch
     ctx = av.get_context(local_rank)
     bee = species.startswith("honeybee")
+    uvsp = species.startswith("uv:") or species == "mantis"
     from animal_vision_amd.synthetic import structured_frame
 
     # This rank's shard of the synthetic stream: global frame index i = rank + j*world (round-robin).
-    gen = structured_frame if bee else noise_frame  # percentile-driven stages need non-degenerate statistics
+    gen = structured_frame if (bee or uvsp) else noise_frame  # percentile-driven stages need non-degenerate statistics
     pool = [gen(rank + j * world, H, W) for j in range(min(B, 4))]
     batch = np.stack([pool[j % len(pool)] for j in range(B)])
     d_in = ctx.upload(batch)
     d_out = ctx.malloc(batch.nbytes)
     stream = ctx.stream_create()
     mst = None
-    if bee:
+    uv_obj = None
+    if uvsp:
+        d_base = ctx.malloc(pool[0].nbytes)
+        if species == "mantis":
+            uv_obj = animals.MantisShrimp()
+            uv_obj.ctx = ctx
+            frame_bytes = pool[0].nbytes
+
+            def run_step():
+                for j in range(B):
+                    uv_obj.run_device(d_in.view(j * frame_bytes, frame_bytes), d_base, d_out.view(j * frame_bytes, frame_bytes), H, W, stream)
+        else:
+            uv_obj = getattr(animals, animals.UV_CLASS[species[3:]])()
+            variant = "day" if species == "uv:rat_uv" else None
+            plan = uv_obj._plan(pool[0], variant)  # records the device call sequence for this frame size
+            ctx.upload(pool[0], plan.d_in)
+
+            def run_step():
+                for j in range(B):
+                    plan.run_device(stream)
+    elif bee:
         op = animals.HoneyBee()._operator()
         op.ctx = ctx
         if species == "honeybee_mst":
@@ -146,7 +174,9 @@ def main():
     mp_per_step = B * H * W / 1e6
     value = world * mp_per_step * args.steps / elapsed
     launch_s = ev_ms / 1e3 / args.steps
-    alg_bytes = 6.0 * B * H * W  # 3 B/px read + 3 B/px written (dichromat, and the fused analytic bee route)
+    # 3 B/px read + 3 B/px written (dichromat, and the fused analytic bee route); the other UV species
+    # also write the warped uint8 baseline: 9 B/px
+    alg_bytes = (9.0 if uvsp else 6.0) * B * H * W
     achieved = alg_bytes / launch_s / 1e9
     if mst is not None:
         roof = {"bound": "mfma", "achieved": round(MSTPP_FLOP_PER_PX * B * H * W / launch_s / 1e12, 2), "peak": MFMA_FP16_PEAK_TFLOPS,
@@ -156,7 +186,9 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": ("honeybee passes (catches, blur, 2x radix select, map+encode)" if bee else "dichromat fused launch (main + all<=1 fix-up)"),
+                "kernel": ("honeybee passes (catches, blur, 2x radix select, map+encode)" if bee else
+                           ("whole species plan per step (front, band stack, blurs, fused elementwise programs, encode)" if uvsp else
+                            "dichromat fused launch (main + all<=1 fix-up)")),
                 "us_per_launch": round(launch_s * 1e6, 2)}
 
     result = {
@@ -170,9 +202,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64" if species == "cat" else ("f16" if mst is not None else "f32"),
+        "dtype": "f32" if uvsp else "f64" if species == "cat" else ("f16" if mst is not None else "f32"),
         "data": "synthetic",
-        "config": {"workload": (f"{species} dichromat core" if not bee else ("honeybee UV path, MST++ HSI (seeded weights) + spectral remap" if mst is not None else "honeybee UV path as coded (analytic lobes), opponent map")) + f", {W}x{H} uint8 frames, {B} frames/step per GPU, device-resident",
+        "config": {"workload": (f"{species} species, full visualize" if uvsp else f"{species} dichromat core" if not bee else ("honeybee UV path, MST++ HSI (seeded weights) + spectral remap" if mst is not None else "honeybee UV path as coded (analytic lobes), opponent map")) + f", {W}x{H} uint8 frames, {B} frames/step per GPU, device-resident",
                    "frames_per_step_per_gpu": B, "fps": round(value * 1e6 / (H * W), 1), "sharding": f"round-robin x{world}"},
         "roofline": roof,
     }
@@ -189,7 +221,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_ref
 
-        if bee:
+        if uvsp:
+            if species == "mantis":
+                def cpu_fn(f):
+                    return cpu_ref.mantis_visualize(f)
+
+                name = "oracle/cpu_ref.mantis_visualize"
+            else:
+                from oracle import np_backend
+
+                def cpu_fn(f):
+                    return np_backend.run(uv_obj, f)
+
+                name = f"oracle/np_backend.run({type(uv_obj).__name__}) (NumPy + C++ OpenCV restatements)"
+        elif bee:
             # CPU leg = the route the reference runs without a GPU-less torch: oracle honeybee (analytic lobes via
             # torch-CPU + NumPy tail).  The MST++ CPU forward is not timed here (minutes per 1080p frame).
             def cpu_fn(f):
@@ -216,15 +261,22 @@ def main():
             "sample": f"{n} frames {W}x{H} through {name}, 1 thread of {len(os.sched_getaffinity(0))} available",
         }
         if mst is None:
-            got = ctx.download(d_out, batch.shape, np.uint8)
+            if uvsp and species != "mantis":
+                got = ctx.download(plan.d_out, pool[0].shape, np.uint8)[None]
+            else:
+                got = ctx.download(d_out, batch.shape, np.uint8)
             _, want = cpu_fn(pool[0])
-            if bee:
+            if uvsp:  # float pipeline + categorical stages: the tests' criterion (tests/test_uv_species_gpu.py::_check)
+                dd = np.abs(got[0].astype(np.int16) - want.astype(np.int16))
+                result["parity_checked"] = bool((dd > 1).mean() <= 2e-3 and (dd > 0).mean() <= 0.05)
+                result["parity_stats"] = {"max": int(dd.max()), "frac_gt1": float((dd > 1).mean()), "frac_ne": float((dd > 0).mean())}
+            elif bee:
                 dd = np.abs(got[0].astype(np.int16) - want.astype(np.int16))
                 result["parity_checked"] = bool(dd.max() <= 1 and (dd > 0).mean() < 2e-3)
             else:
                 result["parity_checked"] = bool(np.array_equal(got[0], want))
 
-    if mst is None and rank == 0 and world == 1 and not args.no_e2e:
+    if mst is None and not uvsp and rank == 0 and world == 1 and not args.no_e2e:
         # PCIe-inclusive leg (never `value`): the same op through pipeline.FramePipeline, host frames in, host frames out.
         from animal_vision_amd.pipeline import FramePipeline
 

@@ -7,6 +7,6 @@ for wl in ${WORKLOADS:-cat_1080p dog_4k wolf_1080p}; do
   python - <<PY
 import json
 r=json.load(open("gpurun_out/bench_$wl.json"))
-print("$wl", r["value"], "MP/s", r["roofline"]["achieved"], "GB/s frac", r["roofline"]["frac"], "us/launch", r["roofline"]["us_per_launch"], "parity", r.get("parity_checked"))
+print("$wl", r["value"], "MP/s", r["roofline"]["achieved"], "GB/s frac", r["roofline"]["frac"], "us/launch", r["roofline"]["us_per_launch"], "parity", r.get("parity_checked"), r.get("parity_stats", ""), "cpu", r.get("cpu_baseline", {}).get("value"))
 PY
 done
