@@ -21,6 +21,9 @@ struct avx_ws {
     size_t scratch_cap = 0;
     void* d_geom = nullptr;          // resampling coefficient tables (geom.hip)
     size_t geom_cap = 0;
+    struct tab { uint64_t key; void* dev; };
+    tab geom_tabs[64] = {};          // immutable resampling tables cached by (kind, component, source size, target size)
+    int n_geom_tabs = 0;
     void* d_ew = nullptr;            // per-block partial reductions of elementwise programs (ew.hip)
     size_t ew_cap = 0;
 };

@@ -37,6 +37,7 @@ struct EwArgs {
     float* partial;  // [block][n_acc]
     const float* lut; const float* thr; const uint8_t* coarse; uint32_t lo_key;
     int uses_encode, uses_xy;
+    uint32_t* ticket; double* scalars_out; uint8_t acc_out_kind[AVX_EW_MAX_ACC]; int acc_slot[AVX_EW_MAX_ACC];
 };
 
 __device__ __forceinline__ float acc_init(int kind) { return kind == AVX_EW_ACC_MIN ? INFINITY : (kind == AVX_EW_ACC_MAX ? -INFINITY : 0.f); }
@@ -86,10 +87,12 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
         for (int pc = 0; pc < a.n_insn; ++pc) {
             const avx_ew_insn in = a.insn[pc];
             const int ra = in.a & (NREG - 1), rb = in.b & (NREG - 1), rd = in.dst & (NREG - 1);
-            const float xs[PX] = {R0[ra], R1[ra], R2[ra], R3[ra]};
-            const float ys[PX] = {R0[rb], R1[rb], R2[rb], R3[rb]};
+            const float imm = __uint_as_float(in.imm);
+            const bool ia = in.op & AVX_EW_IMM_A, ib = in.op & AVX_EW_IMM_B;  // an operand is the immediate constant
+            const float xs[PX] = {ia ? imm : R0[ra], ia ? imm : R1[ra], ia ? imm : R2[ra], ia ? imm : R3[ra]};
+            const float ys[PX] = {ib ? imm : R0[rb], ib ? imm : R1[rb], ib ? imm : R2[rb], ib ? imm : R3[rb]};
             float r[PX];
-            switch (in.op) {
+            switch (in.op & AVX_EW_OPCODE_MASK) {
                 case AVX_EW_CONST: { const float c = __uint_as_float(in.imm); _Pragma("unroll") EW_FOR r[k] = c; } break;
                 case AVX_EW_SCALAR: { const float c = (float)a.scalars[in.imm]; _Pragma("unroll") EW_FOR r[k] = c; } break;
                 case AVX_EW_LOAD: {
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
                     break;
                 }
                 case AVX_EW_ACCMIN: case AVX_EW_ACCMAX: case AVX_EW_ACCSUM: {
-                    const int kind = in.op == AVX_EW_ACCMIN ? AVX_EW_ACC_MIN : (in.op == AVX_EW_ACCMAX ? AVX_EW_ACC_MAX : AVX_EW_ACC_SUM);
+                    const int opc = in.op & AVX_EW_OPCODE_MASK;
+                    const int kind = opc == AVX_EW_ACCMIN ? AVX_EW_ACC_MIN : (opc == AVX_EW_ACCMAX ? AVX_EW_ACC_MAX : AVX_EW_ACC_SUM);
                     const float cur[PX] = {R0[rd], R1[rd], R2[rd], R3[rd]};
 #pragma unroll
                     EW_FOR r[k] = valid[k] ? acc_merge(kind, cur[k], xs[k]) : cur[k];
@@ -158,8 +162,13 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
             R0[rd] = r[0]; R1[rd] = r[1]; R2[rd] = r[2]; R3[rd] = r[3];
         }
     }
-    // block-level reduction of the accumulators -> partial[block][k]
+    // block-level reduction of the accumulators -> partial[block][k]; the last workgroup to finish (ticket) folds the
+    // per-block partials into the scalar table: min / max, or the sum in double over the float32 partial sums
+    // (AVX_EW_ACC_MEAN = float32(sum) / n like ndarray.mean() of a float32 array).  Partials travel in agent-scope
+    // atomic stores / loads: no cache write-back or invalidate is needed (see k_sel_pass in uv.hip).
+    if (a.n_acc == 0) return;
     const int lane = tid & 63, wave = tid >> 6;
+    __shared__ int is_last;
     for (int k = 0; k < a.n_acc; ++k) {
         const int kind = a.acc_kind[k], reg = a.acc_reg[k] & (NREG - 1);
         float v = acc_merge(kind, acc_merge(kind, R0[reg], R1[reg]), acc_merge(kind, R2[reg], R3[reg]));
@@ -171,31 +180,34 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
         if (tid == 0) {
             float t = red[0];
             for (int w = 1; w < kET / 64; ++w) t = acc_merge(kind, t, red[w]);
-            a.partial[(size_t)blockIdx.x * a.n_acc + k] = t;
+            __hip_atomic_store(&a.partial[(size_t)blockIdx.x * a.n_acc + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-}
-
-struct FinalArgs { const float* partial; int nblocks, n_acc; uint8_t kind[AVX_EW_MAX_ACC]; int slot[AVX_EW_MAX_ACC]; double* scalars; double n; };
-// one wave per accumulator: min / max, or the sum in double over the per-block float32 partial sums;
-// AVX_EW_ACC_MEAN = float32(sum) / n like ndarray.mean() of a float32 array
-__global__ void k_ew_final(const FinalArgs a) {
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (k >= a.n_acc) return;
-    const int kind = a.kind[k];
-    if (kind == AVX_EW_ACC_MIN || kind == AVX_EW_ACC_MAX) {
-        float v = kind == AVX_EW_ACC_MIN ? INFINITY : -INFINITY;
-        for (int i = lane; i < a.nblocks; i += 64) { const float w = a.partial[(size_t)i * a.n_acc + k]; v = kind == AVX_EW_ACC_MIN ? fminf(v, w) : fmaxf(v, w); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const float w = __shfl_xor(v, o); v = kind == AVX_EW_ACC_MIN ? fminf(v, w) : fmaxf(v, w); }
-        if (lane == 0) a.scalars[a.slot[k]] = (double)v;
-    } else {
-        double v = 0.0;
-        for (int i = lane; i < a.nblocks; i += 64) v += (double)a.partial[(size_t)i * a.n_acc + k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) a.scalars[a.slot[k]] = kind == AVX_EW_ACC_MEAN ? (double)((float)v / (float)a.n) : (double)(float)v;
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
     }
+    __syncthreads();
+    if (!is_last) return;
+    for (int k = wave; k < a.n_acc; k += kET / 64) {  // one wave per accumulator
+        const int kind = a.acc_out_kind[k];
+        if (kind == AVX_EW_ACC_MIN || kind == AVX_EW_ACC_MAX) {
+            float v = kind == AVX_EW_ACC_MIN ? INFINITY : -INFINITY;
+            for (int i = lane; i < (int)gridDim.x; i += 64)
+                v = acc_merge(kind, v, __hip_atomic_load(&a.partial[(size_t)i * a.n_acc + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = acc_merge(kind, v, __shfl_xor(v, o));
+            if (lane == 0) a.scalars_out[a.acc_slot[k]] = (double)v;
+        } else {
+            double v = 0.0;
+            for (int i = lane; i < (int)gridDim.x; i += 64)
+                v += (double)__hip_atomic_load(&a.partial[(size_t)i * a.n_acc + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) a.scalars_out[a.acc_slot[k]] = kind == AVX_EW_ACC_MEAN ? (double)((float)v / (float)a.n) : (double)(float)v;
+        }
+    }
+    if (tid == 0) *a.ticket = 0;
 }
 
 }  // namespace
@@ -224,54 +236,49 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
     for (int i = 0; i < p->n_insn; ++i) {
         const avx_ew_insn in = p->insn_host[i];
         AVX_REQUIRE(ctx, in.dst < AVX_EW_MAX_REGS && in.a < AVX_EW_MAX_REGS && in.b < AVX_EW_MAX_REGS, "avx_ew_run: register index out of range");
-        if (in.op == AVX_EW_LOAD || in.op == AVX_EW_STORE) {
+        const int opc = in.op & AVX_EW_OPCODE_MASK;
+        if ((in.op & (AVX_EW_IMM_A | AVX_EW_IMM_B)) != 0)
+            AVX_REQUIRE(ctx, opc >= AVX_EW_ADD && opc <= AVX_EW_OR && opc != AVX_EW_NOT && (in.op & (AVX_EW_IMM_A | AVX_EW_IMM_B)) != (AVX_EW_IMM_A | AVX_EW_IMM_B),
+                        "avx_ew_run: immediate operand on an opcode that takes none");
+        if (opc == AVX_EW_LOAD || opc == AVX_EW_STORE) {
             AVX_REQUIRE(ctx, (int)in.imm < p->n_planes, "avx_ew_run: plane index out of range");
             const int kind = a.planes[in.imm].kind;
             if (kind == AVX_EW_PLANE_COL || kind == AVX_EW_PLANE_ROW) a.uses_xy = 1;
-            if (in.op == AVX_EW_STORE) {
+            if (opc == AVX_EW_STORE) {
                 AVX_REQUIRE(ctx, kind == AVX_EW_PLANE_F32 || kind == AVX_EW_PLANE_U8_ENC, "avx_ew_run: store to a read-only plane kind");
                 if (kind == AVX_EW_PLANE_U8_ENC) a.uses_encode = 1;
             } else {
                 AVX_REQUIRE(ctx, kind != AVX_EW_PLANE_U8_ENC, "avx_ew_run: load from an encode-only plane");
             }
         }
-        if (in.op == AVX_EW_SCALAR) AVX_REQUIRE(ctx, p->scalars_dev && (int)in.imm < p->n_scalars, "avx_ew_run: scalar slot out of range");
-        if (in.op == AVX_EW_SELECT) AVX_REQUIRE(ctx, (in.imm & 0xff) < AVX_EW_MAX_REGS, "avx_ew_run: register index out of range");
-        AVX_REQUIRE(ctx, in.op <= AVX_EW_ACCSUM, "avx_ew_run: unknown opcode");
+        if (opc == AVX_EW_SCALAR) AVX_REQUIRE(ctx, p->scalars_dev && (int)in.imm < p->n_scalars, "avx_ew_run: scalar slot out of range");
+        if (opc == AVX_EW_SELECT) AVX_REQUIRE(ctx, (in.imm & 0xff) < AVX_EW_MAX_REGS, "avx_ew_run: register index out of range");
+        AVX_REQUIRE(ctx, opc >= AVX_EW_CONST && opc <= AVX_EW_ACCSUM, "avx_ew_run: unknown opcode");
         a.insn[i] = in;
         max_reg = max_reg > in.dst ? max_reg : in.dst;
         max_reg = max_reg > in.a ? max_reg : in.a;
         max_reg = max_reg > in.b ? max_reg : in.b;
-        if (in.op == AVX_EW_SELECT) max_reg = max_reg > (int)(in.imm & 0xff) ? max_reg : (int)(in.imm & 0xff);
+        if (opc == AVX_EW_SELECT) max_reg = max_reg > (int)(in.imm & 0xff) ? max_reg : (int)(in.imm & 0xff);
     }
-    FinalArgs f{};
     for (int k = 0; k < p->n_acc; ++k) {
         const int reg = p->acc_host[3 * k], kind = p->acc_host[3 * k + 1], slot = p->acc_host[3 * k + 2];
         AVX_REQUIRE(ctx, reg >= 0 && reg < AVX_EW_MAX_REGS && kind >= AVX_EW_ACC_MIN && kind <= AVX_EW_ACC_MEAN && slot >= 0 && slot < p->n_scalars, "avx_ew_run: bad accumulator entry");
         a.acc_reg[k] = (uint8_t)reg; a.acc_kind[k] = (uint8_t)kind;
         max_reg = max_reg > reg ? max_reg : reg;
-        f.kind[k] = (uint8_t)kind; f.slot[k] = slot;
+        a.acc_out_kind[k] = (uint8_t)kind; a.acc_slot[k] = slot;
     }
     const size_t want = (a.n + kET * PX - 1) / (kET * PX), cap = (size_t)ctx->num_cus * 8;
     const int grid = (int)(want < cap ? want : cap);
-    if (p->n_acc) {
-        const size_t need = (size_t)grid * p->n_acc * sizeof(float);
-        if (ws->ew_cap < need) {
-            if (ws->d_ew) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_ew)); }
-            ws->d_ew = nullptr; ws->ew_cap = 0;
-            const size_t full = (size_t)ctx->num_cus * 8 * AVX_EW_MAX_ACC * sizeof(float);
-            AVX_HIP(ctx, hipMalloc(&ws->d_ew, full));
-            ws->ew_cap = full;
-        }
+    if (p->n_acc && ws->d_ew == nullptr) {  // per-block partials + the ticket (zero at rest)
+        const size_t full = (size_t)ctx->num_cus * 8 * AVX_EW_MAX_ACC * sizeof(float) + 256;
+        AVX_HIP(ctx, hipMalloc(&ws->d_ew, full));
+        AVX_HIP(ctx, hipMemsetAsync(ws->d_ew, 0, full, s));
+        ws->ew_cap = full;
     }
-    a.scalars = p->scalars_dev; a.partial = (float*)ws->d_ew;
+    a.scalars = p->scalars_dev; a.partial = (float*)ws->d_ew + 64; a.ticket = (uint32_t*)ws->d_ew; a.scalars_out = p->scalars_dev;
     a.lut = ctx->d_decode_lut; a.thr = ctx->d_enc_thr_f32; a.coarse = ctx->d_coarse_f32; a.lo_key = ctx->coarse_lo_key[0];
     if (max_reg < 16) hipLaunchKernelGGL(k_ew<16>, dim3(grid), dim3(kET), 0, s, a);
     else hipLaunchKernelGGL(k_ew<32>, dim3(grid), dim3(kET), 0, s, a);
-    if (p->n_acc) {
-        f.partial = a.partial; f.nblocks = grid; f.n_acc = p->n_acc; f.scalars = p->scalars_dev; f.n = (double)a.n;
-        hipLaunchKernelGGL(k_ew_final, dim3(1), dim3(64 * p->n_acc), 0, s, f);
-    }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -278,15 +278,72 @@ int grid_for(avx_ctx* ctx, size_t items) {
     return (int)(want < cap ? (want ? want : 1) : cap);
 }
 
-// device copy of small host tables inside the stream's scratch arena (synchronous copies: tables are tiny)
-struct TableArena {
-    avx_ctx* ctx; char* base; size_t off, cap; hipStream_t s;
-    template <typename T> int put(const std::vector<T>& v, T** out) {
-        const size_t bytes = (v.size() * sizeof(T) + 255) & ~(size_t)255;
-        if (off + bytes > cap) return avx_fail(ctx, AVX_ERR_NOMEM, "geometry table arena overflow");
-        *out = reinterpret_cast<T*>(base + off);
-        if (!v.empty()) AVX_HIP(ctx, hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-        off += bytes;
+// Device copies of the O(W + H) coefficient tables, cached per stream workspace under (kind, component, source size,
+// target size): built and uploaded (blocking) the first time a geometry is seen, immutable afterwards, so replaying a
+// resize costs no host work and no stream synchronisation.
+enum { TK_LIN = 1, TK_CUB = 2, TK_AREA = 3 };
+struct TableCache {
+    avx_ctx* ctx; avx_ws* ws; hipStream_t s;
+    static uint64_t key(int kind, int comp, int ssize, int dsize) { return ((uint64_t)kind << 58) | ((uint64_t)comp << 54) | ((uint64_t)ssize << 27) | (uint64_t)dsize; }
+    void* find(uint64_t k) const {
+        for (int i = 0; i < ws->n_geom_tabs; ++i)
+            if (ws->geom_tabs[i].key == k) return ws->geom_tabs[i].dev;
+        return nullptr;
+    }
+    int room() {  // once per entry point, before any lookup: nearly full -> drop everything (launches may still read the tables)
+        if (ws->n_geom_tabs <= 48) return AVX_OK;
+        AVX_HIP(ctx, hipStreamSynchronize(s));
+        for (int i = 0; i < ws->n_geom_tabs; ++i)
+            if (((ws->geom_tabs[i].key >> 54) & 0xf) < 8) (void)hipFree(ws->geom_tabs[i].dev);
+        ws->n_geom_tabs = 0;
+        return AVX_OK;
+    }
+    template <typename T> int put(uint64_t k, const std::vector<T>& v, T** out) {
+        if (ws->n_geom_tabs >= 64) return avx_fail(ctx, AVX_ERR_NOMEM, "geometry table cache overflow");
+        void* d = nullptr;
+        AVX_HIP(ctx, hipMalloc(&d, v.size() * sizeof(T) + 256));
+        if (!v.empty()) AVX_HIP(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        ws->geom_tabs[ws->n_geom_tabs++] = {k, d};
+        *out = (T*)d;
+        return AVX_OK;
+    }
+    int lin(int ssize, int dsize, AxisLin* ax) {
+        const uint64_t k0 = key(TK_LIN, 0, ssize, dsize), k1 = key(TK_LIN, 1, ssize, dsize), k2 = key(TK_LIN, 8, ssize, dsize);  // component >= 8: a scalar in the pointer slot
+        if (void* d = find(k0)) {
+            ax->ofs = (int*)d; ax->f = (float*)find(k1);
+            ax->dmax = (int)(intptr_t)find(k2) - 1;
+            return AVX_OK;
+        }
+        HostLin h = host_lin(ssize, dsize);
+        int rc;
+        if ((rc = put(k0, h.ofs, &ax->ofs)) || (rc = put(k1, h.f, &ax->f))) return rc;
+        ax->dmax = h.dmax;
+        if (ws->n_geom_tabs < 64) ws->geom_tabs[ws->n_geom_tabs++] = {k2, (void*)(intptr_t)(h.dmax + 1)};  // a scalar rides in the pointer slot
+        else return avx_fail(ctx, AVX_ERR_NOMEM, "geometry table cache overflow");
+        return AVX_OK;
+    }
+    int cub(int ssize, int dsize, AxisCub* ax) {
+        const uint64_t k0 = key(TK_CUB, 0, ssize, dsize), k1 = key(TK_CUB, 1, ssize, dsize);
+        if (void* d = find(k0)) { ax->idx = (int*)d; ax->a = (float*)find(k1); return AVX_OK; }
+        std::vector<int> ix; std::vector<float> cx;
+        host_cubic(ssize, dsize, ix, cx);
+        int rc;
+        if ((rc = put(k0, ix, &ax->idx)) || (rc = put(k1, cx, &ax->a))) return rc;
+        return AVX_OK;
+    }
+    int area(int ssize, int dsize, AxisArea* ax) {
+        const uint64_t k0 = key(TK_AREA, 0, ssize, dsize), k1 = key(TK_AREA, 1, ssize, dsize), k2 = key(TK_AREA, 2, ssize, dsize), k3 = key(TK_AREA, 8, ssize, dsize);
+        if (void* d = find(k0)) {
+            ax->start = (int*)d; ax->cnt = (int*)find(k1); ax->alpha = (float*)find(k2); ax->maxcnt = (int)(intptr_t)find(k3);
+            return AVX_OK;
+        }
+        std::vector<int> sv, cv; std::vector<float> av; int m = 1;
+        host_area(ssize, dsize, sv, cv, av, m);
+        int rc;
+        if ((rc = put(k0, sv, &ax->start)) || (rc = put(k1, cv, &ax->cnt)) || (rc = put(k2, av, &ax->alpha))) return rc;
+        ax->maxcnt = m;
+        if (ws->n_geom_tabs < 64) ws->geom_tabs[ws->n_geom_tabs++] = {k3, (void*)(intptr_t)m};
+        else return avx_fail(ctx, AVX_ERR_NOMEM, "geometry table cache overflow");
         return AVX_OK;
     }
 };
@@ -298,21 +355,11 @@ struct TableArena {
 int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s) {
     avx_ws* ws = avx_workspace(ctx, s);
     if (!ws) return AVX_ERR_NOMEM;
-    const size_t tab_bytes = ((size_t)(newW + H) * 48 + 4096) * 4;
-    if (ws->geom_cap < tab_bytes) {
-        if (ws->d_geom) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_geom)); }
-        ws->d_geom = nullptr; ws->geom_cap = 0;
-        AVX_HIP(ctx, hipMalloc(&ws->d_geom, tab_bytes));
-        ws->geom_cap = tab_bytes;
-    }
-    AVX_HIP(ctx, hipStreamSynchronize(s));
-    TableArena ar{ctx, (char*)ws->d_geom, 0, ws->geom_cap, s};
-    std::vector<int> ix, iy; std::vector<float> cx, cy;
-    host_cubic(W, newW, ix, cx); host_cubic(H, H, iy, cy);
+    TableCache tc{ctx, ws, s};
     AxisCub ax{}, ay{};
     int rc;
-    if ((rc = ar.put(ix, &ax.idx)) || (rc = ar.put(cx, &ax.a)) || (rc = ar.put(iy, &ay.idx)) || (rc = ar.put(cy, &ay.a))) return rc;
-    AVX_HIP(ctx, hipStreamSynchronize(s));
+    if ((rc = tc.room())) return rc;
+    if ((rc = tc.cub(W, newW, &ax)) || (rc = tc.cub(H, H, &ay))) return rc;
     ax.idx += 4 * (size_t)start;
     ax.a += 4 * (size_t)start;
     hipLaunchKernelGGL(k_resize_cubic_f32, dim3(grid_for(ctx, (size_t)H * W * 3)), dim3(kGT), 0, s, src, H, W, 3, dst, H, W, ax, ay);
@@ -338,32 +385,20 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
     }
     avx_ws* ws = avx_workspace(ctx, s);
     if (!ws) return AVX_ERR_NOMEM;
-    const size_t tab_bytes = ((size_t)(Wd + Hd) * 48 + 4096) * 4;
-    if (ws->geom_cap < tab_bytes) {
-        if (ws->d_geom) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_geom)); }
-        ws->d_geom = nullptr; ws->geom_cap = 0;
-        AVX_HIP(ctx, hipMalloc(&ws->d_geom, tab_bytes));
-        ws->geom_cap = tab_bytes;
-    }
-    AVX_HIP(ctx, hipStreamSynchronize(s));  // the previous launch may still read the table arena; host vectors below are copied before return
-    TableArena ar{ctx, (char*)ws->d_geom, 0, ws->geom_cap, s};
+    TableCache tc{ctx, ws, s};
     const size_t total = (size_t)Hd * Wd * C;
     const int g = grid_for(ctx, total);
-    int rc = AVX_OK;
+    int rc = tc.room();
+    if (rc) return rc;
     if (interp == 3 && (Wd > W || Hd > H)) interp = 1;  // cv::resize: INTER_AREA when enlarging is INTER_LINEAR
     if (interp == 1) {
-        HostLin hx = host_lin(W, Wd), hy = host_lin(H, Hd);
-        AxisLin ax{nullptr, nullptr, hx.dmax}, ay{nullptr, nullptr, hy.dmax};
-        if ((rc = ar.put(hx.ofs, &ax.ofs)) || (rc = ar.put(hx.f, &ax.f)) || (rc = ar.put(hy.ofs, &ay.ofs)) || (rc = ar.put(hy.f, &ay.f))) return rc;
-        AVX_HIP(ctx, hipStreamSynchronize(s));
+        AxisLin ax{}, ay{};
+        if ((rc = tc.lin(W, Wd, &ax)) || (rc = tc.lin(H, Hd, &ay))) return rc;
         if (dtype == 0) hipLaunchKernelGGL(k_resize_linear_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
         else hipLaunchKernelGGL(k_resize_linear_u8, dim3(g), dim3(kGT), 0, s, (const uint8_t*)src, H, W, C, (uint8_t*)dst, Hd, Wd, ax, ay);
     } else if (interp == 2) {
-        std::vector<int> ix, iy; std::vector<float> cx, cy;
-        host_cubic(W, Wd, ix, cx); host_cubic(H, Hd, iy, cy);
         AxisCub ax{}, ay{};
-        if ((rc = ar.put(ix, &ax.idx)) || (rc = ar.put(cx, &ax.a)) || (rc = ar.put(iy, &ay.idx)) || (rc = ar.put(cy, &ay.a))) return rc;
-        AVX_HIP(ctx, hipStreamSynchronize(s));
+        if ((rc = tc.cub(W, Wd, &ax)) || (rc = tc.cub(H, Hd, &ay))) return rc;
         hipLaunchKernelGGL(k_resize_cubic_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
     } else {
         const double sx = (double)W / Wd, sy = (double)H / Hd;
@@ -371,12 +406,8 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
         if (std::fabs(sx - isx) < DBL_EPSILON && std::fabs(sy - isy) < DBL_EPSILON) {
             hipLaunchKernelGGL(k_resize_area_fast_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, isx, isy);
         } else {
-            std::vector<int> sxv, cxv, syv, cyv; std::vector<float> axv, ayv; int mx = 1, my = 1;
-            host_area(W, Wd, sxv, cxv, axv, mx); host_area(H, Hd, syv, cyv, ayv, my);
-            AxisArea ax{nullptr, nullptr, nullptr, mx}, ay{nullptr, nullptr, nullptr, my};
-            if ((rc = ar.put(sxv, &ax.start)) || (rc = ar.put(cxv, &ax.cnt)) || (rc = ar.put(axv, &ax.alpha)) || (rc = ar.put(syv, &ay.start)) ||
-                (rc = ar.put(cyv, &ay.cnt)) || (rc = ar.put(ayv, &ay.alpha))) return rc;
-            AVX_HIP(ctx, hipStreamSynchronize(s));
+            AxisArea ax{}, ay{};
+            if ((rc = tc.area(W, Wd, &ax)) || (rc = tc.area(H, Hd, &ay))) return rc;
             hipLaunchKernelGGL(k_resize_area_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
         }
     }

@@ -271,70 +271,79 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// `find_next` (last pass): also the smallest key ABOVE the selected 22-bit prefix range (the successor of x[k] when
-// x[k] is the largest key of its prefix), block-reduced: one atomicMin per workgroup.
-__global__ __launch_bounds__(kT) void k_sel_hist(const float* __restrict__ x, size_t n, int shift, int bits, SelState* st,
-                                                 uint32_t* hist, int find_next) {
+// One launch per radix pass.  Every workgroup histograms its share in LDS and flushes the non-empty bins with global
+// atomics; the LAST workgroup to finish (ticket counter behind an agent-scope fence) picks the bin that holds the rank,
+// narrows the prefix, re-zeroes the histogram and the ticket, and -- on the last pass -- resolves the successor key
+// and performs NumPy's float32 lerp.  Pass 0 takes its state from the arguments: no init launch, no memset.
+struct SelPass {
+    const float* x; size_t n; int pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket;
+    unsigned long long rank0; float gamma; int has_next; double* out;
+};
+
+__global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a) {
     __shared__ uint32_t h[2048];
     __shared__ uint32_t wmin[kT / 64];
-    const int nb = 1 << bits;
-    for (int i = threadIdx.x; i < nb; i += kT) h[i] = 0;
+    __shared__ unsigned long long csum[kT];
+    __shared__ int first_after[kT];
+    __shared__ int sel_chunk, sel_bin, is_last;
+    __shared__ unsigned long long sel_rank;
+    __shared__ uint32_t sel_cnt;
+    const int nb = 1 << a.bits, t = threadIdx.x;
+    const bool last_pass = a.pass == 2, find_next = last_pass && a.has_next;
+    for (int i = t; i < nb; i += kT) h[i] = 0;
     __syncthreads();
-    const uint32_t prefix = st->prefix, mask = st->mask;
+    const uint32_t prefix = a.pass == 0 ? 0u : a.st->prefix, mask = a.pass == 0 ? 0u : a.st->mask;
     const uint32_t above = prefix | ~mask;  // largest key with this prefix
     uint32_t best = 0xffffffffu;
-    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
-        const uint32_t k = f2key(x[i]);
-        if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & (nb - 1)], 1u);
-        else if (find_next && k > above && k < best) best = k;
+    for (size_t i = (size_t)blockIdx.x * kT + t; i < a.n; i += (size_t)gridDim.x * kT) {
+        const uint32_t k = f2key(a.x[i]);
+        if ((k & mask) == prefix) atomicAdd(&h[(k >> a.shift) & (nb - 1)], 1u);
+        else if (find_next && k > above && k < best) best = k;  // successor candidates outside the 22-bit prefix
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += kT)
-        if (h[i]) atomicAdd(&hist[i], h[i]);
+    for (int i = t; i < nb; i += kT)
+        if (h[i]) atomicAdd(&a.hist[i], h[i]);
     if (find_next) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o); best = t < best ? t : best; }
-        if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = best;
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(best, o); best = v < best ? v : best; }
+        if ((t & 63) == 0) wmin[t >> 6] = best;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (t == 0) {
             for (int w = 1; w < kT / 64; ++w) best = wmin[w] < best ? wmin[w] : best;
-            if (best != 0xffffffffu) atomicMin(&st->next_above, best);
+            if (best != 0xffffffffu) atomicMin(&a.st->next_above, best);
         }
     }
-}
-
-__global__ void k_sel_init(SelState* st, unsigned long long rank) {
-    if (threadIdx.x != 0) return;
-    st->prefix = 0; st->mask = 0; st->rank = rank; st->key_lo = 0; st->key_hi = 0; st->cnt_in_bin = 0; st->next_key = 0xffffffffu;
-    st->next_above = 0xffffffffu;
-}
-
-// One workgroup: 256 threads each own nb/256 consecutive bins; an LDS scan of the 256 chunk sums finds the
-// chunk that holds the rank, its owner finishes inside the chunk.  Also re-zeroes the histogram.
-__global__ __launch_bounds__(kT) void k_sel_pick(uint32_t* hist, int shift, int bits, SelState* st, int last) {
-    __shared__ unsigned long long csum[kT];
-    __shared__ int sel_chunk, sel_bin;
-    const int nb = 1 << bits, per = nb / kT, t = threadIdx.x;  // nb in {1024, 2048}
-    uint32_t loc[8];
-    unsigned long long s = 0;
-    for (int i = 0; i < per; ++i) { loc[i] = hist[t * per + i]; s += loc[i]; }
-    csum[t] = s;
+    // ---- last workgroup: pick ------------------------------------------------------------------------------------
+    // Everything the workgroups exchange travels in agent-scope atomics (histogram, successor key, ticket) and is
+    // read back with agent-scope atomic loads, so no cache write-back / invalidate (__threadfence: a whole-L2 flush
+    // per workgroup on this multi-XCD part) is needed: only this wave's atomics must have been performed before
+    // the ticket is taken.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const unsigned long long r = st->rank;
-    if (t == 0) {
-        unsigned long long cum = 0;
-        int c = 0;
-        for (; c < kT; ++c) {
-            if (cum + csum[c] > r) break;
-            cum += csum[c];
-        }
-        if (c == kT) { c = kT - 1; cum -= csum[c]; }  // rank beyond the data (cannot happen for rank < n)
-        sel_chunk = c;
-        csum[0] = cum;  // exclusive prefix of the selected chunk
+    if (t == 0) is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    const int per = nb / kT;  // nb in {1024, 2048}: 4 or 8 consecutive bins per thread
+    uint32_t loc[8];
+    unsigned long long sum = 0;
+    for (int i = 0; i < per; ++i) { loc[i] = __hip_atomic_load(&a.hist[t * per + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sum += loc[i]; }
+    // inclusive scan of the 256 chunk sums (Hillis-Steele in LDS), then the one thread whose chunk straddles the rank
+    csum[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < kT; o <<= 1) {
+        const unsigned long long v = t >= o ? csum[t - o] : 0ull;
+        __syncthreads();
+        csum[t] += v;
+        __syncthreads();
     }
+    const unsigned long long r = a.pass == 0 ? a.rank0 : a.st->rank;
+    const unsigned long long incl = csum[t], excl = incl - sum;
+    if (t == 0) sel_chunk = kT - 1;  // rank beyond the data (cannot happen for rank < n): last chunk
+    __syncthreads();
+    if (excl <= r && r < incl) sel_chunk = t;
     __syncthreads();
     if (t == sel_chunk) {
-        unsigned long long cum = csum[0];
+        unsigned long long cum = excl;
         int i = 0;
         for (; i < per; ++i) {
             if (cum + loc[i] > r) break;
@@ -342,39 +351,38 @@ __global__ __launch_bounds__(kT) void k_sel_pick(uint32_t* hist, int shift, int 
         }
         if (i == per) i = per - 1;
         const int b = t * per + i;
-        st->prefix |= (uint32_t)b << shift;
-        st->mask |= (uint32_t)(nb - 1) << shift;
-        st->rank = r - cum;
-        if (last) { st->key_lo = st->prefix; st->cnt_in_bin = loc[i]; sel_bin = b; }
+        a.st->prefix = prefix | ((uint32_t)b << a.shift);
+        a.st->mask = mask | ((uint32_t)(nb - 1) << a.shift);
+        a.st->rank = r - cum;
+        if (a.pass == 0) a.st->next_above = 0xffffffffu;
+        if (last_pass) { a.st->key_lo = prefix | (uint32_t)b; a.st->cnt_in_bin = loc[i]; sel_bin = b; sel_rank = r - cum; sel_cnt = loc[i]; }
     }
-    if (last) {  // successor of x[k] among the distinct keys: next non-empty bin of this prefix, else the smallest key above it
+    if (last_pass) {  // successor of x[k] among the distinct keys, then np.percentile's float32 lerp
         __syncthreads();
-        __shared__ int first_after[kT];
         int f = 0x7fffffff;
         for (int i = per - 1; i >= 0; --i)
             if (loc[i] && t * per + i > sel_bin) f = t * per + i;
-        first_after[t] = f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(f, o); f = v < f ? v : f; }
+        if ((t & 63) == 0) first_after[t >> 6] = f;
         __syncthreads();
         if (t == 0) {
-            int m = 0x7fffffff;
-            for (int c = 0; c < kT; ++c) m = first_after[c] < m ? first_after[c] : m;
-            st->next_key = m != 0x7fffffff ? ((st->prefix & ~(uint32_t)(nb - 1)) | (uint32_t)m) : st->next_above;
+            int m = first_after[0];
+            for (int w = 1; w < kT / 64; ++w) m = first_after[w] < m ? first_after[w] : m;
+            const uint32_t next_above = __hip_atomic_load(&a.st->next_above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t next_key = m != 0x7fffffff ? (prefix | (uint32_t)m) : next_above;
+            const uint32_t key_lo = prefix | (uint32_t)sel_bin;
+            const float lo = key2f(key_lo);
+            float hi = lo;
+            if (a.has_next && sel_rank + 1 >= sel_cnt) hi = next_key == 0xffffffffu ? lo : key2f(next_key);  // else x[k+1] duplicates x[k]
+            const float diff = hi - lo;
+            float res = lo + diff * a.gamma;
+            if (a.gamma >= 0.5f) res = hi - diff * (1.0f - a.gamma);
+            *a.out = (double)res;  // a float32 value (np.percentile returns np.float32 here)
         }
     }
-    for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
-}
-
-// np.percentile's _lerp for a float32 array: everything in float32 (NumPy matches the virtual index and
-// gamma to the array dtype): diff = b - a; a + diff*t; and b - diff*(1-t) where t >= 0.5.
-__global__ void k_sel_lerp(const SelState* st, float gamma, int has_next, double* out) {
-    if (threadIdx.x != 0) return;
-    const float a = key2f(st->key_lo);
-    float b = a;
-    if (has_next && st->rank + 1 >= st->cnt_in_bin) b = st->next_key == 0xffffffffu ? a : key2f(st->next_key);
-    const float diff = b - a;
-    float r = a + diff * gamma;
-    if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
-    *out = (double)r;  // a float32 value (np.percentile returns np.float32 here)
+    for (int i = 0; i < per; ++i) a.hist[t * per + i] = 0;
+    if (t == 0) *a.ticket = 0;
 }
 
 // ---- opponent prep / maps / encode ------------------------------------------------------------------
@@ -525,22 +533,24 @@ int grid_for(avx_ctx* ctx, size_t items) {
 
 // ======================================= C ABI =======================================================
 struct UvScratch {
-    Stat3* partials; float4* stats; uint32_t* hist; SelState* sel; double* pct; float* mat;
+    Stat3* partials; float4* stats; uint32_t* hist; SelState* sel; uint32_t* ticket; double* pct; float* mat;
 };
 
 static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_ws** out_ws = nullptr) {
     avx_ws* ws = avx_workspace(ctx, stream);
     if (!ws) return AVX_ERR_NOMEM;
     if (out_ws) *out_ws = ws;
-    const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + 2048 * 4 + sizeof(SelState) + 16 * 8 + 16 * 129 * 4 + 4096;
+    const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + 2048 * 4 + sizeof(SelState) + 64 + 16 * 8 + 16 * 129 * 4 + 4096;
     if (ws->uv_small == nullptr) {
         AVX_HIP(ctx, hipMalloc(&ws->uv_small, need));
+        AVX_HIP(ctx, hipMemsetAsync(ws->uv_small, 0, need, stream));  // histogram and ticket start at zero; k_sel_pass leaves them so
     }
     char* p = (char*)ws->uv_small;
     s->partials = (Stat3*)p; p += (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3);
     s->stats = (float4*)p; p += 16 * sizeof(float4);
     s->hist = (uint32_t*)p; p += 2048 * 4;
     s->sel = (SelState*)p; p += sizeof(SelState) + 8;
+    s->ticket = (uint32_t*)p; p += 16;
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     s->pct = (double*)p; p += 16 * 8;
     s->mat = (float*)p;
@@ -556,17 +566,14 @@ static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size
     if (lo > (float)(n - 1)) lo = (float)(n - 1);
     const float gamma = vi - lo;
     const int has_next = (size_t)lo + 1 < n;
-    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, s, u.sel, (unsigned long long)lo);
-    AVX_HIP(ctx, hipMemsetAsync(u.hist, 0, 2048 * 4, s));
     // few, fat workgroups: every workgroup flushes its non-empty LDS bins with global atomics
     const size_t want = (n + (size_t)kT * 16 - 1) / ((size_t)kT * 16), cap = (size_t)ctx->num_cus * 2;
     const int g = (int)(want < cap ? (want ? want : 1) : cap);
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int p = 0; p < 3; ++p) {
-        hipLaunchKernelGGL(k_sel_hist, dim3(g), dim3(kT), 0, s, x, n, shifts[p], bits[p], u.sel, u.hist, (p == 2 && has_next) ? 1 : 0);
-        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kT), 0, s, u.hist, shifts[p], bits[p], u.sel, p == 2 ? 1 : 0);
+        SelPass a{x, n, p, shifts[p], bits[p], u.sel, u.hist, u.ticket, (unsigned long long)lo, gamma, has_next, out_dev};
+        hipLaunchKernelGGL(k_sel_pass, dim3(g), dim3(kT), 0, s, a);
     }
-    hipLaunchKernelGGL(k_sel_lerp, dim3(1), dim3(64), 0, s, u.sel, gamma, has_next, out_dev);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -146,7 +146,17 @@ class _Compiled:
                 return leaves.setdefault(("s", v.imm), v)
             return v
 
-        def visit(v: Val):
+        # a constant that feeds a binary operator rides in that instruction (AVX_EW_IMM_A/B): never gets a register
+        def imm_slot(node: Val) -> int:
+            if node.op in _BINARY:
+                a0, a1 = node.args
+                if a1.op == "const" and a0.op != "const":
+                    return 1
+                if a0.op == "const" and a1.op != "const":
+                    return 0
+            return -1
+
+        def visit(v: Val):  # iterative post-order; immediates are not visited (they get no register)
             v = canon(v)
             if id(v) in seen:
                 return
@@ -158,6 +168,8 @@ class _Compiled:
                     continue
                 if k < len(node.args):
                     stack.append((node, k + 1))
+                    if k == imm_slot(node):
+                        continue
                     child = canon(node.args[k])
                     if id(child) not in seen:
                         stack.append((child, 0))
@@ -170,8 +182,9 @@ class _Compiled:
         # last use (position in `order`; outputs are consumed right after their node is computed)
         last: Dict[int, int] = {}
         for pos, node in enumerate(order):
-            for a in node.args:
-                last[id(canon(a))] = pos
+            for k, a in enumerate(node.args):
+                if k != imm_slot(node):
+                    last[id(canon(a))] = pos
         out_of: Dict[int, list] = {}
         for o in outputs:
             out_of.setdefault(id(canon(o[1])), []).append(o)
@@ -195,10 +208,11 @@ class _Compiled:
         reg: Dict[int, int] = {}
         insn: List[Tuple[int, int, int, int, int]] = []
         for pos, node in enumerate(order):
-            srcs = [reg[id(canon(a))] for a in node.args]
+            islot = imm_slot(node)
+            srcs = [0 if k == islot else reg[id(canon(a))] for k, a in enumerate(node.args)]
             # registers of operands whose last use is this instruction can be reused for the result
             # (the interpreter reads every source before it writes the destination)
-            for a in {id(canon(a)): canon(a) for a in node.args}.values():
+            for a in {id(canon(a)): canon(a) for k, a in enumerate(node.args) if k != islot}.values():
                 if last.get(id(a)) == pos:
                     free.append(reg[id(a)])
             if not free:
@@ -215,7 +229,10 @@ class _Compiled:
             elif node.op in _UNARY:
                 insn.append((EW[_UNARY[node.op]], r, srcs[0], 0, 0))
             elif node.op in _BINARY:
-                insn.append((EW[_BINARY[node.op]], r, srcs[0], srcs[1], 0))
+                if islot >= 0:
+                    insn.append((EW[_BINARY[node.op]] | (0x40 if islot == 0 else 0x80), r, srcs[0], srcs[1], _f32_bits(node.args[islot].imm)))
+                else:
+                    insn.append((EW[_BINARY[node.op]], r, srcs[0], srcs[1], 0))
             elif node.op == "select":
                 insn.append((EW["SELECT"], r, srcs[0], srcs[1], srcs[2]))
             else:
@@ -229,7 +246,7 @@ class _Compiled:
             if id(node) not in last:  # nobody reads it later (an output-only node): release at once
                 free.append(r)
         top = max([t[1] for t in insn if t[1] < 0x80] + [t[2] for t in insn] + [t[3] for t in insn]
-                  + [t[4] for t in insn if t[0] == EW["SELECT"]] + [0]) + 1
+                  + [t[4] for t in insn if (t[0] & 0x3f) == EW["SELECT"]] + [0]) + 1
         acc_reg = {k: top + (v - 0x80) for k, v in acc_reg.items()}
         insn = [(op, top + (d - 0x80) if d >= 0x80 else d, a_, b_, imm) for (op, d, a_, b_, imm) in insn]
         self.n_regs = top + len(accs)

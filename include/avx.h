@@ -258,6 +258,9 @@ enum {  /* opcodes: dst = op(a, b); imm = constant bits / plane index / scalar s
     AVX_EW_SELECT,                      /* dst = a != 0 ? b : reg[imm & 0xff]  (np.where)                          */
     AVX_EW_ACCMIN, AVX_EW_ACCMAX, AVX_EW_ACCSUM   /* dst (an accumulator register) op= a                           */
 };
+/* Binary opcodes (ADD .. OR) may take ONE operand from the instruction itself: op | AVX_EW_IMM_A: a = float32(imm),
+ * op | AVX_EW_IMM_B: b = float32(imm) (the weak Python scalars of the reference's expressions). */
+enum { AVX_EW_OPCODE_MASK = 0x3f, AVX_EW_IMM_A = 0x40, AVX_EW_IMM_B = 0x80 };
 enum {  /* plane kinds: element i of the frame (i = y*W + x) is at ptr[i*stride] unless stated                    */
     AVX_EW_PLANE_F32 = 0,               /* float32, load/store (stride 3 + offset pointer = one channel of HWC)      */
     AVX_EW_PLANE_U8,                    /* uint8 -> float value of the byte, load only                              */
