@@ -55,13 +55,54 @@ class HoneyBee(Animal):
     def visualize(self, image: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         assert isinstance(image, np.ndarray), "Input must be a numpy ndarray."
         assert image.ndim == 3 and image.shape[2] == 3, "Input must be HxWx3 RGB."
-        if self.hsi_downsample and 0.05 <= self.hsi_scale < 1.0:
-            raise NotImplementedError("hsi_downsample needs the INTER_AREA/INTER_LINEAR resampling kernels (SURVEY 8f row 1)")
         if image.dtype != np.uint8:
             raise NotImplementedError(f"HoneyBee: device path implemented for uint8 frames, got {image.dtype}")
         op = self._operator()
         if self.hsi_model is not None:
             out = self.hsi_model.honeybee(image, op)
+        elif self.hsi_downsample and 0.05 <= self.hsi_scale < 1.0:
+            out = self._visualize_downsampled(image)
         else:
             out = op(image)
         return image, out
+
+    def _visualize_downsampled(self, image: np.ndarray) -> np.ndarray:
+        """honeybee.py:109-117: classic_rgb_to_hsi_scaled = INTER_AREA down -> lobes -> INTER_LINEAR up of the cube.
+        The three cone catches are linear in the cube, so they are taken at the reduced size and the 3-plane result is
+        upsampled (instead of 31 bands); the tail (adaptation, blur, map, encode) is the same device pipeline, fed
+        the catches as a 3-band cube with identity weights."""
+        import ctypes
+
+        from ..planevm import DeviceBackend, PlaneRef
+        from ..runtime import DeviceBuffer
+
+        plans = self.__dict__.setdefault("_ds_plans", {})
+        key = image.shape[:2]
+        hit = plans.get(key)
+        if hit is None:
+            if len(plans) >= 4:
+                plans.pop(next(iter(plans)))[0].close()
+            H, W = key
+            be = DeviceBackend(H, W)
+            img01 = be._alloc(4 * 3 * be.n)  # to_float01: byte / 255
+            for c in range(3):
+                be.store(be.load(PlaneRef(be.d_in, c, 3, "u8")) / 255.0, PlaneRef(img01, 4 * c, 3))
+            be.lin_hwc = img01
+            op = self._operator()
+            be.spectral_planes(self.lambdas, op.weights, self.hsi_scale, downsample=True)
+            be.flush()
+            tail = HoneybeeOp(lambdas=self.lambdas, illuminant=self.E, curves=(self.UV_curve, self.Blue_curve, self.Green_curve),
+                              reflectance=self.assume_hsi_is_reflectance, adaptation=self.adaptation, mapping_mode=self.mapping_mode,
+                              custom_matrix=self.custom_matrix, blur_sigma_px=self.blur_sigma_px, eps=self._eps, ctx=be.ctx)
+            tail.weights = np.eye(3, dtype=np.float32)
+            tail.desc.bands = 3
+            tail.desc.weights_host = tail.weights.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            hit = (be, tail)
+            plans[key] = hit
+        be, tail = hit
+        ctx = be.ctx
+        H, W = key
+        ctx.upload(np.ascontiguousarray(image), be.d_in)
+        be.run_device()
+        tail.run_device(None, be.d_out, 1, H, W, hsi_ptr=be.last_stack.ptr, hsi_layout=0, hsi_dtype=0)
+        return ctx.download(be.d_out, image.shape, np.uint8)

@@ -545,23 +545,29 @@ class DeviceBackend:
 
     def bands(self, lambdas: np.ndarray, bands: Sequence[Tuple[float, float]], hsi_scale: float) -> List[Val]:
         """classic_rgb_to_hsi(_scaled)(baseline_lin) then integrate_band per (lo, hi): raw band planes."""
-        H, W = self.H, self.W
-        K = len(bands)
         wts = np.ascontiguousarray(np.stack([bandpass_weights(lambdas, lo, hi) for lo, hi in bands]), dtype=np.float32)
+        return self.spectral_planes(lambdas, wts, hsi_scale)
+
+    def spectral_planes(self, lambdas: np.ndarray, wts: np.ndarray, hsi_scale: float, downsample: Optional[bool] = None) -> List[Val]:
+        """K weighted sums over the wavelength axis of classic_rgb_to_hsi(_scaled)(self.lin_hwc): wts is K x B."""
+        H, W = self.H, self.W
+        K = wts.shape[0]
+        wts = np.ascontiguousarray(wts, dtype=np.float32)
         gains, denom = lobe_tables(lambdas)
         M = fold_rgb_matrix(wts, lambdas)
         d = BandStackDesc()
         d.struct_size = ctypes.sizeof(BandStackDesc)
         fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))  # noqa: E731
         d.n_bands, d.band_matrix_host, d.n_wavelengths, d.lobe_gains_host, d.lobe_denom, d.band_weights_host = K, fp(M), int(lambdas.size), fp(gains), denom, fp(wts)
-        if 0.0 < hsi_scale < 1.0:
+        if (0.0 < hsi_scale < 1.0) if downsample is None else downsample:
             hs, ws = max(1, int(round(H * hsi_scale))), max(1, int(round(W * hsi_scale)))
             if (hs, ws) != (H, W):
                 d.small_h, d.small_w = hs, ws
         self._keep += [wts, gains, M, d]
         stack = self._alloc(4 * self.n * K)
         ctx, lin = self.ctx, self.lin_hwc
-        self._call(lambda s: ctx._check(lib.avx_band_stack(ctx._h, lin.ptr, H, W, ctypes.byref(d), stack.ptr, s)))
+        self._call(lambda s: ctx._check(lib.avx_band_stack(ctx._h, lin.ptr, H, W, ctypes.byref(d), stack.ptr, s)), "band_stack")
+        self.last_stack = stack
         return [self.load(PlaneRef(stack, 4 * k, K)) for k in range(K)]
 
     def encode(self, rgb: Sequence):

@@ -740,14 +740,18 @@ def honeybee_tail(U, B, G, orig_dtype=np.uint8, *, adaptation="white_patch", map
     return out_srgb.astype(orig_dtype), rgb_lin
 
 
-def honeybee_visualize(image: np.ndarray, *, hsi: Optional[np.ndarray] = None, lambdas=None, **kw):
-    """animals/honeybee.py:99-175 with the as-coded HSI source (analytic lobes, F3/F5),
-    or with a caller-supplied cube (the MST++ route of the north star)."""
+def honeybee_visualize(image: np.ndarray, *, hsi: Optional[np.ndarray] = None, lambdas=None, hsi_downsample: bool = False,
+                       hsi_scale: float = 0.1, **kw):
+    """animals/honeybee.py:99-175 with the as-coded HSI source (analytic lobes, F3/F5; at reduced size when
+    `hsi_downsample`, :109-117), or with a caller-supplied cube (the MST++ route of the north star)."""
     assert isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] == 3
     lambdas = np.linspace(400.0, 700.0, 31, dtype=np.float32) if lambdas is None else np.asarray(lambdas, np.float32)
     img01 = to_float01(image)
     if hsi is None:
-        hsi = classic_rgb_to_hsi_lobes(img01, lambdas)
+        if hsi_downsample and 0.05 <= hsi_scale < 1.0:
+            hsi = classic_rgb_to_hsi_scaled(img01, wavelengths=lambdas, scale=hsi_scale)
+        else:
+            hsi = classic_rgb_to_hsi_lobes(img01, lambdas)
     U, B, G = honeybee_catches(hsi, lambdas)
     out, _ = honeybee_tail(U, B, G, image.dtype, **kw)
     return image, out

@@ -165,6 +165,8 @@ def test_honeybee_end_to_end_bit_exact(oracle):
         head = parts[0]
         if head == "opponent_noblur":
             kw = dict(blur_sigma_px=0.0)
+        elif head.startswith("downsample"):
+            kw = dict(hsi_downsample=True, hsi_scale=int(head[len("downsample"):]) / 100.0)
         else:
             for adapt in ("white_patch", "gray_world"):
                 if head.endswith("_" + adapt):

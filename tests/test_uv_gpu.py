@@ -110,6 +110,8 @@ def test_honeybee_vs_reference_golden(uv):
         head = key[: -len(tail) - 1]
         if head == "opponent_noblur":
             bee = HoneyBee(blur_sigma_px=0.0)
+        elif head.startswith("downsample"):  # a14: hsi_downsample route (area down, lobes, linear up)
+            bee = HoneyBee(hsi_downsample=True, hsi_scale=int(head[len("downsample"):]) / 100.0)
         else:
             adapt = "white_patch" if head.endswith("white_patch") else "gray_world"
             mode = head[: -len(adapt) - 1]
@@ -121,6 +123,18 @@ def test_honeybee_vs_reference_golden(uv):
         _u8_close(out, g[key], max_frac=5e-3)
         checked += 1
     assert checked >= 20
+
+
+def test_honeybee_downsample_vs_oracle_other_size(uv, oracle):
+    from animal_vision_amd.animals import HoneyBee
+    from animal_vision_amd.synthetic import structured_frame
+
+    frame = structured_frame(2, 270, 481)
+    bee = HoneyBee(hsi_downsample=True, hsi_scale=0.1)
+    for f in (frame, np.ascontiguousarray(frame[::-1])):  # second frame replays the recorded plan
+        base, out = bee.visualize(f)
+        assert base is f
+        _u8_close(out, oracle.honeybee_visualize(f, hsi_downsample=True, hsi_scale=0.1)[1], max_frac=5e-3)
 
 
 def test_honeybee_planes_and_1080p_vs_oracle(uv, oracle):

@@ -295,6 +295,11 @@ def g_honeybee():
                 out[f"{mode}_{adapt}_{k}"] = res
     bee = hb.HoneyBee(blur_sigma_px=0.0)
     out["opponent_noblur_s40"] = bee.visualize(frames["s40"])[1]
+    # a14: the hsi_downsample route (INTER_AREA down, lobes, INTER_LINEAR up of the 31-band cube)
+    for sc_name, sc in (("025", 0.25), ("060", 0.6)):
+        bee = hb.HoneyBee(hsi_downsample=True, hsi_scale=sc)
+        for k, f in frames.items():
+            out[f"downsample{sc_name}_{k}"] = bee.visualize(f)[1]
     # intermediates for the default species on s40: catches after adaptation + blur
     bee = hb.HoneyBee()
     img01 = ref_uvh.to_float01(frames["s40"])
