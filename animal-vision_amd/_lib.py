@@ -227,6 +227,7 @@ _SIGS = {
     "avx_rgb_to_hsi_lobes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_float, _vp, _vp]),
     "avx_honeybee_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(HoneybeeDesc), _vp, _vp]),
     "avx_uv_front_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "avx_panorama_warp_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "avx_band_stack": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(BandStackDesc), _vp, _vp]),
     "avx_percentile_dev": (_i, [_vp, _vp, _sz, ctypes.c_double, _vp, _vp]),
     "avx_ew_run": (_i, [_vp, ctypes.POINTER(EwProgram), _vp]),

@@ -28,12 +28,13 @@ class UVSpecies(Animal):
         from ..planevm import DeviceBackend
 
         plans: Dict[tuple, object] = self.__dict__.setdefault("_plans", {})
-        key = (image.shape[0], image.shape[1], variant)
+        floats = image.dtype != np.uint8
+        key = (image.shape[0], image.shape[1], variant, floats)
         be = plans.get(key)
         if be is None:
             if len(plans) >= self._MAX_PLANS:
                 plans.pop(next(iter(plans))).close()
-            be = DeviceBackend(image.shape[0], image.shape[1])
+            be = DeviceBackend(image.shape[0], image.shape[1], float_frames=floats)
             if variant is None:
                 self.render(be, image)
             else:
@@ -45,8 +46,8 @@ class UVSpecies(Animal):
     def visualize(self, image: np.ndarray, **kw) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         assert isinstance(image, np.ndarray), "Input must be a numpy ndarray."
         assert image.ndim == 3 and image.shape[2] == 3, "Input must be HxWx3 RGB."
-        if image.dtype != np.uint8:
-            raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 frames, got {image.dtype}")
+        if image.dtype != np.uint8 and not np.issubdtype(image.dtype, np.floating):
+            raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 and float frames, got {image.dtype}")
         from ..planevm import DeviceProbes
 
         return self._plan(image, self.variant(image, DeviceProbes, **kw)).run(image)

@@ -278,6 +278,13 @@ extern "C" int avx_uv_front_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W
     return uv_front(ctx, in_hwc, H, W, newW, tmp, lin_hwc_out, baseline_hwc_out, s);
 }
 
+extern "C" int avx_panorama_warp_f32(avx_ctx* ctx, const float* src_hwc, int H, int W, int new_w, float* dst_hwc, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, src_hwc && dst_hwc && src_hwc != dst_hwc && H > 0 && W > 0 && new_w > W, "avx_panorama_warp_f32: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    return avx_geom_panorama_cubic(ctx, src_hwc, H, W, new_w, (new_w - W) / 2, dst_hwc, avx_pick_stream(ctx, stream));
+}
+
 extern "C" int avx_band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, const avx_band_stack_desc* d, float* stack_hwk_out, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_band_stack_desc), "avx_band_stack: desc is NULL or struct_size mismatch");

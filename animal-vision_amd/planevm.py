@@ -276,8 +276,10 @@ class DeviceBackend:
     N_SCALARS = 256
     name = "device"
 
-    def __init__(self, H: int, W: int, ctx: Optional[Context] = None):
+    def __init__(self, H: int, W: int, ctx: Optional[Context] = None, float_frames: bool = False):
+        """float_frames: the frames are float32 HxWx3 (sRGB in [0,1] or [0,255]); outputs are float32 too."""
         self.ctx = ctx or get_context()
+        self.float_frames = bool(float_frames)
         self.H, self.W, self.n = int(H), int(W), int(H) * int(W)
         self.plan: List = []          # callables(stream)
         self.pending: List = []       # outputs of the elementwise program being assembled
@@ -287,9 +289,10 @@ class DeviceBackend:
         self._slot = 0
         self._bufs: List[DeviceBuffer] = [self.scalars]
         self._keep: List = []         # ctypes structs / host arrays referenced by the recorded calls
-        self.d_in = self.ctx.malloc(3 * self.n)
-        self.d_base = self.ctx.malloc(3 * self.n)
-        self.d_out = self.ctx.malloc(3 * self.n)
+        item = 4 if self.float_frames else 1
+        self.d_in = self.ctx.malloc(3 * self.n * item)
+        self.d_base = self.ctx.malloc(3 * self.n * item)
+        self.d_out = self.ctx.malloc(3 * self.n * item)
         self._bufs += [self.d_in, self.d_base, self.d_out]
         self.n_programs = 0
         self.n_insn = 0
@@ -527,10 +530,13 @@ class DeviceBackend:
         return [self.load(PlaneRef(out, 4 * c, K)) for c in range(K)]
 
     # -- species skeleton ------------------------------------------------------------------------------
+    def _linear_to_srgb(self, l):
+        """uv_helpers.linear_to_srgb (:40-44) as an expression (float frames; uint8 frames use the threshold table)."""
+        a = 0.055
+        return self.where(l <= 0.0031308, l * 12.92, (1 + a) * self.power(self.maximum(l, 0.0), 1 / 2.4) - a)
+
     def front(self, image: np.ndarray, panorama_scale: float) -> List[Val]:
-        """to_float01 + srgb_to_linear + panorama_warp; the uint8 baseline goes to d_base.  -> linear [R, G, B]."""
-        if image.dtype != np.uint8:
-            raise NotImplementedError(f"device UV path implemented for uint8 frames, got {image.dtype}")
+        """to_float01 + srgb_to_linear + panorama_warp; the baseline (input dtype) goes to d_base.  -> linear [R, G, B]."""
         H, W = self.H, self.W
         new_w = W
         if panorama_scale and panorama_scale != 1.0 and abs(panorama_scale - 1.0) >= 1e-3:
@@ -540,8 +546,23 @@ class DeviceBackend:
         lin = self._alloc(4 * 3 * self.n)
         self.lin_hwc = lin
         ctx, d_in, d_base = self.ctx, self.d_in, self.d_base
-        self._call(lambda s: ctx._check(lib.avx_uv_front_u8(ctx._h, d_in.ptr, H, W, new_w, lin.ptr, d_base.ptr, s)))
-        return [self.load(PlaneRef(lin, 4 * c, 3)) for c in range(3)]
+        if not self.float_frames:
+            self._call(lambda s: ctx._check(lib.avx_uv_front_u8(ctx._h, d_in.ptr, H, W, new_w, lin.ptr, d_base.ptr, s)))
+            return [self.load(PlaneRef(lin, 4 * c, 3)) for c in range(3)]
+        # float frames (uv_helpers.py:15-23,33-37): /255 and clip only when the frame's maximum exceeds 1.001
+        y = [self.load(PlaneRef(d_in, 4 * c, 3)) for c in range(3)]
+        mx = self.max(self.maximum(self.maximum(y[0], y[1]), y[2]))
+        a = 0.055
+        pre = self._alloc(4 * 3 * self.n) if new_w > W else lin
+        for c in range(3):
+            v = self.where(mx > 1.001, self.clip01(y[c] / 255.0), y[c])
+            self.store(self.where(v <= 0.04045, v / 12.92, ((v + a) / (1 + a)) ** 2.4), PlaneRef(pre, 4 * c, 3))
+        if new_w > W:
+            self._call(lambda s: ctx._check(lib.avx_panorama_warp_f32(ctx._h, pre.ptr, H, W, new_w, lin.ptr, s)), "panorama")
+        rgb = [self.load(PlaneRef(lin, 4 * c, 3)) for c in range(3)]
+        for c in range(3):  # baseline = linear_to_srgb(clip(baseline_lin, 0, 1)).astype(dtype)
+            self.store(self._linear_to_srgb(self.clip01(rgb[c])), PlaneRef(d_base, 4 * c, 3))
+        return rgb
 
     def bands(self, lambdas: np.ndarray, bands: Sequence[Tuple[float, float]], hsi_scale: float) -> List[Val]:
         """classic_rgb_to_hsi(_scaled)(baseline_lin) then integrate_band per (lo, hi): raw band planes."""
@@ -571,21 +592,27 @@ class DeviceBackend:
         return [self.load(PlaneRef(stack, 4 * k, K)) for k in range(K)]
 
     def encode(self, rgb: Sequence):
-        """from_float01(linear_to_srgb(clip(render, 0, 1)), uint8) -> d_out (HWC)."""
+        """from_float01(linear_to_srgb(clip(render, 0, 1)), dtype) -> d_out (HWC)."""
         for c, v in enumerate(rgb):
-            self.store(self._v(v), PlaneRef(self.d_out, c, 3, "u8_enc"))
+            if self.float_frames:
+                self.store(self._linear_to_srgb(self.clip01(self._v(v))), PlaneRef(self.d_out, 4 * c, 3))
+            else:
+                self.store(self._v(v), PlaneRef(self.d_out, c, 3, "u8_enc"))
         self.flush()
 
     # -- replay ----------------------------------------------------------------------------------------
     def run(self, image: np.ndarray, stream=None) -> Tuple[np.ndarray, np.ndarray]:
         ctx = self.ctx
-        assert image.shape == (self.H, self.W, 3) and image.dtype == np.uint8
-        ctx.upload(np.ascontiguousarray(image), self.d_in, stream)
+        dt = np.float32 if self.float_frames else np.uint8
+        assert image.shape == (self.H, self.W, 3) and (image.dtype == np.uint8) == (not self.float_frames)
+        ctx.upload(np.ascontiguousarray(image, dtype=dt), self.d_in, stream)  # float64 frames: x.astype(float32), the reference's first step
         s = ctx._s(stream)
         for fn in self.plan:
             fn(s)
-        base = ctx.download(self.d_base, image.shape, np.uint8, stream=stream, sync=False)
-        out = ctx.download(self.d_out, image.shape, np.uint8, stream=stream)
+        base = ctx.download(self.d_base, image.shape, dt, stream=stream, sync=False)
+        out = ctx.download(self.d_out, image.shape, dt, stream=stream)
+        if image.dtype != dt:  # `.astype(orig_dtype)` of from_float01
+            base, out = base.astype(image.dtype), out.astype(image.dtype)
         return base, out
 
     def run_device(self, stream=None):
@@ -598,25 +625,30 @@ class DeviceBackend:
 class DeviceProbes:
     """Frame statistics a species branches on, computed on the device (8 bytes come back to the host)."""
 
-    _cache: Dict[Tuple[int, int], tuple] = {}
+    _cache: Dict[tuple, tuple] = {}
 
     @classmethod
     def median_luma(cls, image: np.ndarray) -> float:
         """float(np.median(0.2126 R + 0.7152 G + 0.0722 B)) of to_float01(image) (rat_uv.py:100-105)."""
-        assert image.dtype == np.uint8
         H, W = image.shape[:2]
-        hit = cls._cache.get((H, W))
+        floats = image.dtype != np.uint8
+        hit = cls._cache.get((H, W, floats))
         if hit is None:
             if len(cls._cache) >= 4:
                 cls._cache.pop(next(iter(cls._cache)))[0].close()
-            be = DeviceBackend(H, W)
-            ch = [be.load(PlaneRef(be.d_in, c, 3, "u8")) / 255.0 for c in range(3)]
+            be = DeviceBackend(H, W, float_frames=floats)
+            if floats:
+                y = [be.load(PlaneRef(be.d_in, 4 * c, 3)) for c in range(3)]
+                mx = be.max(be.maximum(be.maximum(y[0], y[1]), y[2]))
+                ch = [be.where(mx > 1.001, be.clip01(v / 255.0), v) for v in y]
+            else:
+                ch = [be.load(PlaneRef(be.d_in, c, 3, "u8")) / 255.0 for c in range(3)]
             slot_val = be.percentile(0.2126 * ch[0] + 0.7152 * ch[1] + 0.0722 * ch[2], 50.0)
             be.flush()
             hit = (be, slot_val.imm)
-            cls._cache[(H, W)] = hit
+            cls._cache[(H, W, floats)] = hit
         be, slot = hit
         ctx = be.ctx
-        ctx.upload(np.ascontiguousarray(image), be.d_in)
+        ctx.upload(np.ascontiguousarray(image, dtype=np.float32 if floats else np.uint8), be.d_in)
         be.run_device()
         return float(ctx.download(be.scalars.view(8 * slot, 8), (1,), np.float64)[0])

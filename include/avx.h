@@ -225,6 +225,8 @@ int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_baseline_hwc
  * (baseline_hwc_out may be NULL).  lin_hwc_out: H x W x 3 float32. */
 int avx_uv_front_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, int pano_new_w, float* lin_hwc_out,
                     uint8_t* baseline_hwc_out, void* stream);
+/* uv_helpers.panorama_warp (:84-99) of an H x W x 3 float32 image: INTER_CUBIC widen to new_w (> W), centre crop. */
+int avx_panorama_warp_f32(avx_ctx* ctx, const float* src_hwc, int H, int W, int new_w, float* dst_hwc, void* stream);
 /* classic_rgb_to_hsi / classic_rgb_to_hsi_scaled (uv_helpers.py:155-183) followed by N x integrate_band
  * (:142-146): H x W x 3 linear float32 -> H x W x N float32 (raw band integrals; safe_norm is the caller's). */
 typedef struct avx_band_stack_desc {
