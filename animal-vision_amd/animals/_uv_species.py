@@ -53,6 +53,43 @@ class UVSpecies(Animal):
         return self._plan(image, self.variant(image, DeviceProbes, **kw)).run(image)
 
 
+class SpeciesStreamOp:
+    """Adapter that lets pipeline.FramePipeline / run_video stream uint8 frames through a UV species: one recorded
+    plan per pipeline slot (each owns its device frames, which the pipeline copies into / out of directly), replayed
+    on the slot's stream.  `output`: "out" (the stylised frame) or "baseline".  Species whose plan depends on frame
+    content (RatUV's mode="auto") need the branch fixed by `variant`."""
+
+    def __init__(self, species: UVSpecies, H: int, W: int, *, depth: int = 3, variant=None, ctx=None):
+        from ..planevm import DeviceBackend
+
+        self.species, self.H, self.W, self.ctx = species, int(H), int(W), ctx
+        probe = np.zeros((H, W, 3), np.uint8)
+        self.plans = []
+        for _ in range(depth):
+            be = DeviceBackend(H, W, ctx)
+            if variant is None:
+                species.render(be, probe)
+            else:
+                species.render(be, probe, variant)
+            be.flush()
+            self.plans.append(be)
+        self.ctx = self.plans[0].ctx
+        self._by_in = {be.d_in.ptr: be for be in self.plans}
+
+    def slot_buffers(self, k: int):
+        be = self.plans[k]
+        return be.d_in, be.d_out
+
+    def run_device(self, d_in, d_out, n_frames: int, H: int, W: int, stream=None):
+        assert n_frames == 1 and (H, W) == (self.H, self.W)
+        self._by_in[d_in.ptr].run_device(stream)
+
+    def close(self):
+        for be in self.plans:
+            be.close()
+        self.plans = []
+
+
 def default_lambdas(lambdas) -> np.ndarray:
     """The 300-700 nm / 81-band grid every UV species but HoneyBee defaults to (e.g. reindeer.py:56-58)."""
     lam = np.asarray(lambdas, dtype=np.float32) if lambdas is not None else np.linspace(300.0, 700.0, 81, dtype=np.float32)

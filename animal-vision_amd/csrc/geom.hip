@@ -201,6 +201,25 @@ __global__ __launch_bounds__(kGT) void k_resize_nearest_f32(const float* __restr
     }
 }
 
+// make_split_frame (renderers/video.py:229-239) without the labels: left half original, right half modified,
+// 1-px white seam at W//2.  16 bytes per thread where the row segment allows it.
+__global__ __launch_bounds__(kGT) void k_split_compose(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ mod, uint8_t* __restrict__ out, int H, int W,
+                                                       int draw_seam) {
+    const size_t row_bytes = (size_t)W * 3, total = (size_t)H * row_bytes;
+    const size_t mid_b = (size_t)(W / 2) * 3;
+    for (size_t i = ((size_t)blockIdx.x * kGT + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * kGT * 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t j = i + k;
+            if (j >= total) break;
+            const size_t xb = j % row_bytes;
+            uint8_t v = xb < mid_b ? orig[j] : mod[j];
+            if (draw_seam && xb >= mid_b && xb < mid_b + 3) v = 255;
+            out[j] = v;
+        }
+    }
+}
+
 // cv2.Sobel(plane, CV_32F, dx, dy, ksize=3, BORDER_REFLECT_101): small-kernel forms, row filter then column filter
 __global__ __launch_bounds__(kGT) void k_sobel3(const float* __restrict__ src, int H, int W, float* __restrict__ gx, float* __restrict__ gy) {
     const size_t total = (size_t)H * W;
@@ -446,6 +465,16 @@ int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, con
     const size_t nbytes = (size_t)H * W * 3;
     hipLaunchKernelGGL(k_any_gt1, dim3(grid_for(ctx, nbytes)), dim3(kGT), 0, s, in_hwc, nbytes, flag);
     hipLaunchKernelGGL(k_binocular_warp, dim3(grid_for(ctx, (size_t)Ho * Wo)), dim3(kGT), 0, s, a);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+int avx_split_compose_u8(avx_ctx* ctx, const uint8_t* original_hwc, const uint8_t* modified_hwc, uint8_t* out_hwc, int H, int W, int draw_seam, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, original_hwc && modified_hwc && out_hwc && H > 0 && W > 0, "avx_split_compose_u8: bad arguments");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    hipLaunchKernelGGL(k_split_compose, dim3(grid_for(ctx, (size_t)H * W * 3 / 4 + 1)), dim3(kGT), 0, s, original_hwc, modified_hwc, out_hwc, H, W, draw_seam);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -81,25 +81,32 @@ class FramePipeline:
     """Runs `op.run_device(d_in, d_out, 1, H, W, stream=...)` (DichromatOp / HoneybeeOp) over a stream of
     uint8 frames with `depth` frames in flight."""
 
-    def __init__(self, op, H: int, W: int, *, ctx=None, depth: int = 3):
+    def __init__(self, op, H: int, W: int, *, ctx=None, depth: int = 3, split_compare: bool = False, draw_seam: bool = True):
+        """split_compare: emit make_split_frame(original, transformed) composed on the device (renderers/video.py:198-245,
+        labels excepted) instead of the transformed frame."""
         from .runtime import get_context
 
         self.op, self.H, self.W, self.depth = op, H, W, depth
+        self.split_compare, self.draw_seam = bool(split_compare), bool(draw_seam)
         self.ctx = ctx or getattr(op, "ctx", None) or get_context()
         if getattr(op, "ctx", None) is None:
             op.ctx = self.ctx
         nbytes = H * W * 3
-        self.slots = [
-            _Slot(self.ctx.stream_create(), self.ctx.pinned((H, W, 3), np.uint8), self.ctx.pinned((H, W, 3), np.uint8),
-                  self.ctx.malloc(nbytes), self.ctx.malloc(nbytes))
-            for _ in range(depth)
-        ]
+        # ops that own their device frames (recorded species plans, animals/_uv_species.py::SpeciesStreamOp) lend them per slot
+        lend = getattr(op, "slot_buffers", None)
+        self._lent = lend is not None
+        self.slots = []
+        for k in range(depth):
+            d_in, d_out = lend(k) if lend else (self.ctx.malloc(nbytes), self.ctx.malloc(nbytes))
+            self.slots.append(_Slot(self.ctx.stream_create(), self.ctx.pinned((H, W, 3), np.uint8), self.ctx.pinned((H, W, 3), np.uint8), d_in, d_out))
 
     def close(self):
         for s in self.slots:
             self.ctx.sync(s.stream)
             self.ctx.stream_destroy(s.stream)
-            s.h_in.free(); s.h_out.free(); s.d_in.free(); s.d_out.free()
+            s.h_in.free(); s.h_out.free()
+            if not self._lent:
+                s.d_in.free(); s.d_out.free()
         self.slots = []
 
     def _retire(self, s: _Slot, emit: Callable[[int, np.ndarray], None]):
@@ -122,6 +129,8 @@ class FramePipeline:
             s.h_in.array[...] = frame
             ctx._check(lib.avx_memcpy_h2d(ctx._h, s.d_in.ptr, s.h_in.ptr, nbytes, s.stream))
             self.op.run_device(s.d_in, s.d_out, 1, self.H, self.W, stream=s.stream)
+            if self.split_compare:
+                ctx._check(lib.avx_split_compose_u8(ctx._h, s.d_in.ptr, s.d_out.ptr, s.d_out.ptr, self.H, self.W, int(self.draw_seam), s.stream))
             ctx._check(lib.avx_memcpy_d2h(ctx._h, s.h_out.ptr, s.d_out.ptr, nbytes, s.stream))
             s.index, s.busy = index, True
             n += 1
@@ -132,27 +141,22 @@ class FramePipeline:
 
 def run_video(animal_op, renderer, *, rank: int = 0, world: int = 1, depth: int = 3, split_compare: bool = False, dist=None) -> StreamStats:
     """main.py:53-72 on the device: read -> visualize -> (split-compose) -> render, this rank's shard only."""
-    from .renderers.video import split_compose
-
     first = renderer.get_image()
     if first is None:
         return reduce_stats(StreamStats(), dist)
     H, W, _ = first.shape
-    pipe = FramePipeline(animal_op, H, W, depth=depth)
-    originals = {}
+    pipe = FramePipeline(animal_op, H, W, depth=depth, split_compare=split_compare)
 
     def frames():
         i, f = 0, first
         while f is not None:
             if owner_of(i, world) == rank:
-                if split_compare:
-                    originals[i] = f
                 yield i, f
             i += 1
             f = renderer.get_image()
 
     def emit(i, out):
-        renderer.render(split_compose(originals.pop(i), out) if split_compare else out)
+        renderer.render(out)  # already split-composed on the device when split_compare
 
     try:
         stats = pipe.run(frames(), emit)

@@ -177,6 +177,12 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
 int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, const float* xL_host, const float* xR_host, const float* ymap_host,
                           const float* wL_host, const float* wR_host, int Ho, int Wo, float* out_hwc_f32, void* stream);
 
+/* VideoRenderer.make_split_frame (renderers/video.py:198-245) for two frames of the same size, without the
+ * Hershey-font labels: left half `original`, right half `modified`, optional 1-px white seam at W//2.
+ * out_hwc may alias modified_hwc (each byte is read before it is written by the same thread). */
+int avx_split_compose_u8(avx_ctx* ctx, const uint8_t* original_hwc, const uint8_t* modified_hwc, uint8_t* out_hwc,
+                         int H, int W, int draw_seam, void* stream);
+
 /* cv2.remap(src, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT, borderValue) on K float32 planes that share two
  * per-pixel float32 maps (anableps.py:217-226): coordinates quantised to 1/32 px like OpenCV. */
 int avx_remap_linear_planes(avx_ctx* ctx, const float* src_planes, int K, int H, int W, const float* mapx_dev,

@@ -52,3 +52,26 @@ def test_split_compare_stream(tmp_path):
     for k in range(4):
         f = src.get_image()
         assert np.array_equal(got[k], split_compose(f, Wolf().visualize(f)[1]))
+
+
+def test_uv_species_stream_through_pipeline():
+    """run_video-style streaming of a plane-program species: one recorded plan per slot, 3 frames in flight."""
+    from animal_vision_amd.animals import Reindeer
+    from animal_vision_amd.animals._uv_species import SpeciesStreamOp
+    from animal_vision_amd.pipeline import FramePipeline
+    from animal_vision_amd.renderers import split_compose
+    from animal_vision_amd.synthetic import structured_frame
+
+    H, W = 96, 128
+    sp = Reindeer()
+    frames = [structured_frame(i, H, W) for i in range(7)]
+    want = [sp.visualize(f)[1] for f in frames]
+    for split in (False, True):
+        op = SpeciesStreamOp(sp, H, W, depth=3)
+        pipe = FramePipeline(op, H, W, depth=3, split_compare=split)
+        got = {}
+        pipe.run(((i, f) for i, f in enumerate(frames)), lambda i, o: got.__setitem__(i, o))
+        pipe.close()
+        op.close()
+        for i, f in enumerate(frames):
+            assert np.array_equal(got[i], split_compose(f, want[i]) if split else want[i]), (split, i)
