@@ -240,6 +240,7 @@ _SIGS = {
     "avx_mst_gram": (_i, [_vp, _vp, _i, _sz, _i, _i, _vp, _vp, _vp, _vp]),
     "avx_dwconv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "avx_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _i, ctypes.c_float, _vp]),
+    "avx_layernorm_rows_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _i, ctypes.c_float, _i, _i, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = stale libavx.so: rebuild

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kMT) void k_dwconv3x3(const T* __restrict__ x, cons
 // ---- LayerNorm over the last dim of (rows x C), biased variance, fp32 statistics ---------------------
 template <typename T>
 __global__ __launch_bounds__(kMT) void k_layernorm(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   T* __restrict__ y, size_t rows, int C, float eps, int RB) {
+                                                   T* __restrict__ y, size_t rows, int C, float eps, int RB, int group, int real) {
     extern __shared__ float tile[];  // [RB][CP], CP odd: a lane per row walks its row without bank conflicts
     const int CP = C | 1;
     for (size_t r0 = (size_t)blockIdx.x * RB; r0 < rows; r0 += (size_t)gridDim.x * RB) {
@@ -201,13 +201,16 @@ __global__ __launch_bounds__(kMT) void k_layernorm(const T* __restrict__ x, cons
         __syncthreads();
         if ((int)threadIdx.x < nr) {
             float* row = tile + threadIdx.x * CP;
+            // channels c with (c % group) >= real are zero padding (31-channel groups stored 32 wide): not part of the
+            // statistics, and they stay zero
+            const float cnt = (float)(C / group * real);
             float s = 0.f;
-            for (int c = 0; c < C; ++c) s += row[c];
-            const float mean = s / (float)C;
+            for (int c = 0; c < C; ++c) s += (c % group) < real ? row[c] : 0.f;
+            const float mean = s / cnt;
             float v = 0.f;
-            for (int c = 0; c < C; ++c) { const float dlt = row[c] - mean; v = __builtin_fmaf(dlt, dlt, v); }
-            const float rstd = rsqrtf(v / (float)C + eps);
-            for (int c = 0; c < C; ++c) row[c] = (row[c] - mean) * rstd * gamma[c] + beta[c];
+            for (int c = 0; c < C; ++c) { const float dlt = (c % group) < real ? row[c] - mean : 0.f; v = __builtin_fmaf(dlt, dlt, v); }
+            const float rstd = rsqrtf(v / cnt + eps);
+            for (int c = 0; c < C; ++c) row[c] = (c % group) < real ? (row[c] - mean) * rstd * gamma[c] + beta[c] : 0.f;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < nr * C; i += kMT) {
@@ -276,11 +279,12 @@ int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, 
     return AVX_OK;
 }
 
-int avx_layernorm_rows(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps,
-                       void* stream) {
+static int layernorm_impl(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps, int group,
+                          int real, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, x && gamma && beta && y && rows > 0 && C > 0 && C <= 1024, "avx_layernorm_rows: bad arguments");
     AVX_REQUIRE(ctx, dtype == 0 || dtype == 1, "avx_layernorm_rows: dtype");
+    AVX_REQUIRE(ctx, group >= 1 && real >= 1 && real <= group && C % group == 0, "avx_layernorm_rows: bad channel grouping");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     const int CP = C | 1;
@@ -292,13 +296,23 @@ int avx_layernorm_rows(avx_ctx* ctx, const void* x, const float* gamma, const fl
     if (g > cap) g = cap;
     if (dtype == 0) {
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_layernorm<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_layernorm<float>, dim3((unsigned)g), dim3(kMT), lds, s, (const float*)x, gamma, beta, (float*)y, rows, C, eps, RB);
+        hipLaunchKernelGGL(k_layernorm<float>, dim3((unsigned)g), dim3(kMT), lds, s, (const float*)x, gamma, beta, (float*)y, rows, C, eps, RB, group, real);
     } else {
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_layernorm<__half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_layernorm<__half>, dim3((unsigned)g), dim3(kMT), lds, s, (const __half*)x, gamma, beta, (__half*)y, rows, C, eps, RB);
+        hipLaunchKernelGGL(k_layernorm<__half>, dim3((unsigned)g), dim3(kMT), lds, s, (const __half*)x, gamma, beta, (__half*)y, rows, C, eps, RB, group, real);
     }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
+}
+
+int avx_layernorm_rows(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps,
+                       void* stream) {
+    return layernorm_impl(ctx, x, gamma, beta, y, dtype, rows, C, eps, C, C, stream);
+}
+
+int avx_layernorm_rows_grouped(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps,
+                               int group, int real, void* stream) {
+    return layernorm_impl(ctx, x, gamma, beta, y, dtype, rows, C, eps, group, real, stream);
 }
 
 }  // extern "C"

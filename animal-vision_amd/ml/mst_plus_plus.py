@@ -12,6 +12,10 @@ inference-only and NHWC-first for MI355X instead of as a module tree:
     of column norms, so the normalised N x C tensors are never materialised;
   * `attn @ v` followed by `proj` (:132-135) collapses to one GEMM: v @ M + b with
     M = blockdiag(attn_h^T) @ W_proj^T (C x C), exact in real arithmetic;
+  * every 31-channel group is stored 32 wide (weights zero-padded once, at first use): rows of 62 B become 64 B, so
+    GEMM operands, depthwise convs and elementwise ops are aligned and vectorise; the padding channel stays exactly
+    zero through every linear op / GELU / LayerNorm (statistics over the 31 real channels) and is masked out of the
+    attention softmax;
   * weights live in a flat dict under the reference's key names; `load_reference_state_dict` strips the
     DataParallel 'module.' prefix like architecture/__init__.py:36-40.
 
@@ -25,6 +29,31 @@ import torch
 import torch.nn.functional as F
 
 DIM = 31
+PAD = 32  # storage width of one 31-channel group
+
+
+def padded(n: int) -> int:
+    """Storage width of n = m * 31 channels."""
+    assert n % DIM == 0
+    return n // DIM * PAD
+
+
+def pad_index(n: int, device=None) -> torch.Tensor:
+    """Position of original channel i in the padded layout: group i // 31 starts at 32 * (i // 31)."""
+    i = torch.arange(n, device=device)
+    return (i // DIM) * PAD + i % DIM
+
+
+def pad_channels(t: torch.Tensor, dims) -> torch.Tensor:
+    """Zero-pad the given dims of a weight from m*31 to m*32 entries (group-wise)."""
+    for d in dims:
+        n = t.shape[d]
+        shape = list(t.shape)
+        shape[d] = padded(n)
+        out = torch.zeros(shape, dtype=t.dtype, device=t.device)
+        out.index_copy_(d, pad_index(n, t.device), t)
+        t = out
+    return t
 
 
 class _AvxOps:
@@ -82,15 +111,16 @@ class _AvxOps:
                                           torch.cuda.current_stream(x.device).cuda_stream))
         return y
 
-    def layernorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    def layernorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, group: int = 0, real: int = 0) -> torch.Tensor:
+        """LayerNorm over the last dim; with group/real, over the channels c with (c % group) < real (padded groups)."""
         from .._lib import lib
 
         c = x.shape[-1]
         x = x.contiguous()
         y = torch.empty_like(x)
         ctx = self.ctx(x.device)
-        ctx._check(lib.avx_layernorm_rows(ctx._h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), self._dt(x), x.numel() // c, c, eps,
-                                          torch.cuda.current_stream(x.device).cuda_stream))
+        ctx._check(lib.avx_layernorm_rows_grouped(ctx._h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), self._dt(x), x.numel() // c, c, eps,
+                                                  group or c, real or c, torch.cuda.current_stream(x.device).cuda_stream))
         return y
 
 
@@ -199,19 +229,24 @@ class MSTPlusPlus(torch.nn.Module):
             self._prepared[key] = t
         return t
 
-    # ---- blocks (x is NHWC) ------------------------------------------------------------------------
+    def _w(self, k: str, dims) -> torch.Tensor:
+        """Reference weight `k` with the channel dims `dims` zero-padded to 32-wide groups (cached)."""
+        return self._prep(k + ".pad" + "".join(map(str, dims)), lambda: pad_channels(self._p(k), dims).contiguous())
+
+    # ---- blocks (x is NHWC, channel groups 32 wide) -------------------------------------------------
     def _conv_nhwc(self, x: torch.Tensor, w: torch.Tensor, **kw) -> torch.Tensor:
         y = F.conv2d(x.permute(0, 3, 1, 2), w, **kw)  # NCHW view of channels-last memory: no copy
         return y.permute(0, 2, 3, 1)
 
     def _ms_msa(self, x: torch.Tensor, p: str, heads: int) -> torch.Tensor:
-        b, h, w, c = x.shape
+        b, h, w, c = x.shape  # c = heads * 32
         n = h * w
         x2 = x.reshape(b, n, c)
-        wqkv = self._prep(p + ".qkv", lambda: torch.cat([self._p(p + ".to_q.weight"), self._p(p + ".to_k.weight"), self._p(p + ".to_v.weight")], 0).t().contiguous())
+        wqkv = self._prep(p + ".qkv", lambda: torch.cat([self._w(p + ".to_q.weight", (0, 1)), self._w(p + ".to_k.weight", (0, 1)),
+                                                         self._w(p + ".to_v.weight", (0, 1))], 0).t().contiguous())
         qkv = x2 @ wqkv  # (b, n, 3c): one GEMM, one pass over x
         q, k, v = qkv[..., :c], qkv[..., c : 2 * c], qkv[..., 2 * c :]
-        d = c // heads
+        d = c // heads  # 32: 31 real channels + the zero padding
         # Gram matrix per head over ALL pixels (the global contraction of :129), fp32 accumulate
         if x.is_cuda and _AVX.enabled:
             gram, nq, nk = _AVX.gram(qkv, heads)  # one pass over qkv: k^T q and every column norm (csrc/mst.hip)
@@ -225,12 +260,13 @@ class MSTPlusPlus(torch.nn.Module):
             nk = torch.linalg.vector_norm(k.float(), dim=1).reshape(b, heads, d, 1).clamp_min(1e-12)
         attn = gram / (nk * nq)
         attn = attn * self._p(p + ".rescale").float().reshape(1, heads, 1, 1)
-        attn = attn.softmax(dim=-1)  # over j
+        attn[..., DIM:] = float("-inf")  # the padding column takes no part in the softmax over j
+        attn = attn.softmax(dim=-1)
         # out_c = proj(concat_h(attn_h @ v_h)) == v @ M + bias,  M = blockdiag(attn_h^T) @ W_proj^T
-        wp = self._p(p + ".proj.weight")  # (c_out, c_in)
-        wp_h = wp.t().reshape(heads, d, c).float()  # rows of W_proj^T grouped by head: (heads, d, c)
+        wp = self._w(p + ".proj.weight", (0, 1))  # (c_out, c_in)
+        wp_h = wp.t().reshape(heads, d, c).float()  # rows of W_proj^T grouped by head (padding rows are zero)
         M = torch.matmul(attn.transpose(-2, -1), wp_h.unsqueeze(0)).reshape(b, c, c).to(x.dtype)  # (b, c, c)
-        out_c = torch.baddbmm(self._p(p + ".proj.bias").to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
+        out_c = torch.baddbmm(self._w(p + ".proj.bias", (0,)).to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
         vi = v.reshape(b, h, w, c)
         pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False)
         return out_c + pe
@@ -239,20 +275,23 @@ class MSTPlusPlus(torch.nn.Module):
         """Depthwise 3x3 (+ GELU) on an NHWC tensor: csrc/mst.hip on the GPU, torch ops otherwise."""
         c = x.shape[-1]
         if x.is_cuda and _AVX.enabled:
-            w9 = self._prep(key + ".c9f32", lambda: self._p(key).reshape(c, 9).float().contiguous())
+            w9 = self._prep(key + ".c9f32", lambda: self._w(key, (0,)).reshape(c, 9).float().contiguous())
             return _AVX.dwconv(x, w9, gelu)
-        y = self._conv_nhwc(x, self._p(key), padding=1, groups=c)
+        y = self._conv_nhwc(x, self._w(key, (0,)), padding=1, groups=c)
         return F.gelu(y) if gelu else y
 
     def _ffn(self, x: torch.Tensor, p: str) -> torch.Tensor:
         b, h, w, c = x.shape
+        g32 = self._prep(p + ".g32", lambda: self._w(p + ".norm.weight", (0,)).float().contiguous())
+        b32 = self._prep(p + ".b32", lambda: self._w(p + ".norm.bias", (0,)).float().contiguous())
         if x.is_cuda and _AVX.enabled:
-            y = _AVX.layernorm(x, self._prep(p + ".g32", lambda: self._p(p + ".norm.weight").float().contiguous()),
-                               self._prep(p + ".b32", lambda: self._p(p + ".norm.bias").float().contiguous()))
-        else:
-            y = F.layer_norm(x.float(), (c,), self._p(p + ".norm.weight").float(), self._p(p + ".norm.bias").float()).to(x.dtype)
-        w1 = self._prep(p + ".w1", lambda: self._p(p + ".fn.net.0.weight").reshape(4 * c, c).t().contiguous())
-        w2 = self._prep(p + ".w2", lambda: self._p(p + ".fn.net.4.weight").reshape(c, 4 * c).t().contiguous())
+            y = _AVX.layernorm(x, g32, b32, group=PAD, real=DIM)
+        else:  # LayerNorm over the real channels only; the padding channels stay zero
+            real = self._prep(p + ".real", lambda: pad_index(c // PAD * DIM, x.device))
+            yr = F.layer_norm(x.float().index_select(-1, real), (real.numel(),), g32.index_select(0, real), b32.index_select(0, real))
+            y = torch.zeros_like(x, dtype=torch.float32).index_copy_(-1, real, yr).to(x.dtype)
+        w1 = self._prep(p + ".w1", lambda: self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous())
+        w2 = self._prep(p + ".w2", lambda: self._w(p + ".fn.net.4.weight", (0, 1)).reshape(c, 4 * c).t().contiguous())
         y = F.gelu(y.reshape(b, h * w, c) @ w1).reshape(b, h, w, 4 * c)
         y = self._dw(y, p + ".fn.net.2.weight", gelu=True)
         return (y.reshape(b, h * w, 4 * c) @ w2).reshape(b, h, w, c)
@@ -262,37 +301,43 @@ class MSTPlusPlus(torch.nn.Module):
         return self._ffn(x, p + ".blocks.0.1") + x
 
     def _mst(self, x: torch.Tensor, p: str) -> torch.Tensor:
-        fea = self._conv_nhwc(x, self._p(p + ".embedding.weight"), padding=1)
+        fea = self._conv_nhwc(x, self._w(p + ".embedding.weight", (0, 1)), padding=1)
         skips: List[torch.Tensor] = []
         heads = 1
         for i in range(2):
             fea = self._msab(fea, f"{p}.encoder_layers.{i}.0", heads)
             skips.append(fea)
-            fea = self._conv_nhwc(fea, self._p(f"{p}.encoder_layers.{i}.1.weight"), stride=2, padding=1)
+            fea = self._conv_nhwc(fea, self._w(f"{p}.encoder_layers.{i}.1.weight", (0, 1)), stride=2, padding=1)
             heads *= 2
         fea = self._msab(fea, p + ".bottleneck", heads)
         for i in range(2):
-            up = F.conv_transpose2d(fea.permute(0, 3, 1, 2), self._p(f"{p}.decoder_layers.{i}.0.weight"),
-                                    self._p(f"{p}.decoder_layers.{i}.0.bias"), stride=2).permute(0, 2, 3, 1)
+            up = F.conv_transpose2d(fea.permute(0, 3, 1, 2), self._w(f"{p}.decoder_layers.{i}.0.weight", (0, 1)),
+                                    self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)), stride=2).permute(0, 2, 3, 1)
             heads //= 2
-            cat = torch.cat([up, skips[1 - i]], dim=-1)
+            cat = torch.cat([up, skips[1 - i]], dim=-1)  # [up | skip]: the group-wise padding of the 2c input channels of the fusion conv
             b, h, w, c2 = cat.shape
-            wf = self._prep(f"{p}.fuse{i}", lambda: self._p(f"{p}.decoder_layers.{i}.1.weight").reshape(c2 // 2, c2).t().contiguous())
+            wf = self._prep(f"{p}.fuse{i}", lambda: self._w(f"{p}.decoder_layers.{i}.1.weight", (0, 1)).reshape(c2 // 2, c2).t().contiguous())
             fea = (cat.reshape(b, h * w, c2) @ wf).reshape(b, h, w, c2 // 2)
             fea = self._msab(fea, f"{p}.decoder_layers.{i}.2", heads)
-        return self._conv_nhwc(fea, self._p(p + ".mapping.weight"), padding=1) + x
+        return self._conv_nhwc(fea, self._w(p + ".mapping.weight", (0, 1)), padding=1) + x
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x: (b, 3, H, W) in [0, 1] -> (b, 31, H, W).  Same pad-to-8 / crop as MST_Plus_Plus.forward :279-293."""
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (b, 3, H, W) in [0, 1] -> (b, H, W, 32) channels-last, bands 0..30 + one zero padding channel (the layout
+        the device hand-off consumes).  Same pad-to-8 / crop as MST_Plus_Plus.forward :279-293."""
         b, c, h_inp, w_inp = x.shape
         pad_h, pad_w = (8 - h_inp % 8) % 8, (8 - w_inp % 8) % 8
         if pad_h or pad_w:
             x = F.pad(x, [0, pad_w, 0, pad_h], mode="reflect")
         x = x.to(self._p("conv_in.weight").dtype).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)  # NHWC view
-        x = self._conv_nhwc(x, self._p("conv_in.weight"), padding=1)
+        x = self._conv_nhwc(x, self._w("conv_in.weight", (0,)), padding=1)
         hfe = x
         for s in range(self.stage):
             hfe = self._mst(hfe, f"body.{s}")
-        hfe = self._conv_nhwc(hfe, self._p("conv_out.weight"), padding=1) + x
-        return hfe.permute(0, 3, 1, 2)[:, :, :h_inp, :w_inp]
+        hfe = self._conv_nhwc(hfe, self._w("conv_out.weight", (0, 1)), padding=1) + x
+        return hfe[:, :h_inp, :w_inp, :]
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (b, 3, H, W) in [0, 1] -> (b, 31, H, W), the reference's signature."""
+        return self.forward_nhwc(x)[..., :DIM].permute(0, 3, 1, 2)

@@ -67,20 +67,26 @@ class MSTPlusPlusPredictor:
             model.load_reference_state_dict(torch.load(weights, map_location="cpu", weights_only=True), strict=False)
         else:
             model.load_reference_state_dict(weights)
+        self._padded_ops = {}
         self.model = model.to(self.device).eval()
         if self.half:
             self.model = self.model.half()
 
-    def predict_device(self, frame_dev):
-        """uint8 (H,W,3) torch tensor on the device -> (31, H, W) contiguous tensor (fp16 when half)."""
+    def predict_device_nhwc(self, frame_dev):
+        """uint8 (H,W,3) torch tensor on the device -> (H, W, 32) contiguous channels-last cube: bands 0..30 and one
+        zero padding channel (64-byte pixels; fp16 when half).  This is what the libavx hand-off consumes."""
         torch = self.torch
         H, W, _ = frame_dev.shape
         x = frame_dev.to(torch.float32).div_(255.0).permute(2, 0, 1).unsqueeze(0)  # 1x3xHxW
         t, b, l, r = pad_amounts(H, W, self.stride)
         if t or b or l or r:
             x = torch.nn.functional.pad(x, [l, r, t, b], mode="reflect")
-        y = self.model(x.half() if self.half else x)
-        return y[0, :, t : t + H, l : l + W].contiguous()
+        y = self.model.forward_nhwc(x.half() if self.half else x)
+        return y[0, t : t + H, l : l + W, :].contiguous()
+
+    def predict_device(self, frame_dev):
+        """uint8 (H,W,3) torch tensor on the device -> (31, H, W) contiguous tensor (fp16 when half)."""
+        return self.predict_device_nhwc(frame_dev)[..., :31].permute(2, 0, 1).contiguous()
 
     def predict(self, image: np.ndarray) -> np.ndarray:
         """predict_rgb_to_hsi_torch for one image: HxWx3 (uint8 or float) -> HxWx31 float32."""
@@ -93,7 +99,7 @@ class MSTPlusPlusPredictor:
 
     def honeybee(self, image: np.ndarray, op) -> np.ndarray:
         """uint8 frame -> MST++ cube -> HoneybeeOp (csrc/uv.hip), the cube handed over on the device:
-        the (31,H,W) tensor's data_ptr goes straight into avx_honeybee_u8 on torch's current stream."""
+        the (H,W,32) channels-last tensor's data_ptr goes straight into avx_honeybee_u8 on torch's current stream."""
         torch = self.torch
         if self.device.type != "cuda":
             raise RuntimeError("MST++ -> libavx hand-off needs the GPU (no CPU path)")
@@ -101,10 +107,13 @@ class MSTPlusPlusPredictor:
 
         H, W, _ = image.shape
         frame = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)
-        cube = self.predict_device(frame)
+        cube = self.predict_device_nhwc(frame)  # (H, W, 32): the layout the forward pass computes in, no transpose
         out = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         ctx = op._ctx()
         stream = torch.cuda.current_stream().cuda_stream
-        op.run_device(None, DeviceBuffer(ctx, out.data_ptr(), out.numel(), owned=False), 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=1,
-                      hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
+        op32 = self._padded_ops.get(id(op))
+        if op32 is None:
+            op32 = self._padded_ops.setdefault(id(op), op.padded_clone(cube.shape[-1]))
+        op32.run_device(None, DeviceBuffer(ctx, out.data_ptr(), out.numel(), owned=False), 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=0,
+                        hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
         return out.cpu().numpy()

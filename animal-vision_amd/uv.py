@@ -242,6 +242,23 @@ class HoneybeeOp:
             self.ctx = get_context()
         return self.ctx
 
+    def padded_clone(self, bands: int) -> "HoneybeeOp":
+        """The same pipeline for a cube stored with `bands` >= B channels per pixel, the extra ones being padding
+        (weights zero): what MSTPlusPlus.forward_nhwc emits (31 bands in a 32-wide, 64-byte-aligned group)."""
+        import copy
+
+        op = copy.copy(self)
+        K, B = self.weights.shape
+        assert bands >= B
+        op.weights = np.zeros((K, bands), np.float32)
+        op.weights[:, :B] = self.weights
+        d = HoneybeeDesc()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(self.desc), ctypes.sizeof(HoneybeeDesc))
+        d.bands = bands
+        d.weights_host = _fptr(op.weights)
+        op.desc = d
+        return op
+
     def run_device(self, d_in: Optional[DeviceBuffer], d_out: DeviceBuffer, n_frames: int, H: int, W: int, *, hsi_ptr: int = 0,
                    hsi_layout: int = 1, hsi_dtype: int = 0, debug: Optional[DeviceBuffer] = None, stream=None):
         """uint8 frames (or an HSI cube at hsi_ptr, e.g. the MST++ output tensor) -> uint8 frames, all on device."""

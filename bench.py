@@ -130,11 +130,13 @@ def main():
             ctx.stream_destroy(stream)
             stream = torch.cuda.current_stream().cuda_stream  # libavx launches ride torch's stream
 
+            op32 = op.padded_clone(32)  # the cube arrives channels-last, 31 bands in a 32-wide group
+
             def run_step():
                 for j in range(B):
-                    cube = mst.predict_device(t_in[j])
-                    op.run_device(None, DeviceBuffer(ctx, t_out[j].data_ptr(), t_out[j].numel(), owned=False), 1, H, W,
-                                  hsi_ptr=cube.data_ptr(), hsi_layout=1, hsi_dtype=1, stream=stream)
+                    cube = mst.predict_device_nhwc(t_in[j])
+                    op32.run_device(None, DeviceBuffer(ctx, t_out[j].data_ptr(), t_out[j].numel(), owned=False), 1, H, W,
+                                    hsi_ptr=cube.data_ptr(), hsi_layout=0, hsi_dtype=1, stream=stream)
         else:
             def run_step():
                 op.run_device(d_in, d_out, B, H, W, stream=stream)

@@ -305,6 +305,10 @@ int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, 
 
 /* nn.LayerNorm(C) (PreNorm :57-65) over the last dim of (rows x C): biased variance, float32 statistics. */
 int avx_layernorm_rows(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps, void* stream);
+/* The same over channel groups stored with zero padding (MST++'s 31-channel groups kept 32 wide so that every row
+ * is 64-byte aligned): channel c takes part iff (c % group) < real; padding channels are written as zero. */
+int avx_layernorm_rows_grouped(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps,
+                               int group, int real, void* stream);
 
 /* The constant tables compiled into the library (reference outputs, see csrc/srgb_tables.h):
  * which = 0: 256 x f32 decode LUT; 1: 255 x f32 encode thresholds; 2: 255 x f64 encode thresholds.
