@@ -124,6 +124,15 @@ __global__ void k_mst_gram_final(const float* __restrict__ partial, int nblocks,
 
 // ---- depthwise 3x3, NHWC, zero padding 1, stride 1, optional GELU -----------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU for a float16 RESULT: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below half
+// an fp16 ulp of the output), one v_exp + one v_rcp instead of libm's erff polynomial ladder
+__device__ __forceinline__ float gelu_erf_h(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
+}
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(kMT) void k_dwconv3x3(const T* __restrict__ x, const float* __restrict__ w_g /*[C][9]*/, T* __restrict__ y, int B,
@@ -181,6 +190,72 @@ __global__ __launch_bounds__(kMT) void k_dwconv3x3(const T* __restrict__ x, cons
         } else {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) st<T>(dst + v, gelu ? gelu_erf(acc[v]) : acc[v]);
+        }
+    }
+}
+
+// fp16, C % 8 == 0: a thread owns ONE group of 8 channels (its 72 weights live in registers for the whole launch) and
+// walks (x, 4-row strip) items: each of the 6 input rows of a strip is loaded once (3 pixels x 16 B) and feeds up to
+// three output rows, so 4.5 16-byte loads serve 8 channels x 4 outputs (the one-output-per-thread form needs 9 8-byte
+// loads + 36 LDS weight reads for 4 channels).  float32 accumulation, exact-erf GELU.
+constexpr int kDwR = 4;
+__global__ __launch_bounds__(kMT) void k_dwconv3x3_h8(const __half* __restrict__ x, const float* __restrict__ w_g /*[C][9]*/, __half* __restrict__ y, int B, int H,
+                                                     int W, int C, int gelu) {
+    const int CV = C / 8;
+    const int cg = (int)(((size_t)blockIdx.x * kMT + threadIdx.x) % CV);  // fixed per thread: grid stride is a multiple of CV
+    float wt[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) wt[t][v] = w_g[(size_t)(cg * 8 + v) * 9 + t];
+    const int strips = (H + kDwR - 1) / kDwR;
+    const size_t total = (size_t)B * strips * W * CV;
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < total; i += (size_t)gridDim.x * kMT) {
+        const size_t p = i / CV;
+        const int xw = (int)(p % W);
+        const int st = (int)((p / W) % strips);
+        const size_t b = p / ((size_t)W * strips);
+        const int y0 = st * kDwR;
+        float acc[kDwR][8];
+#pragma unroll
+        for (int r = 0; r < kDwR; ++r)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc[r][v] = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kDwR + 2; ++rr) {  // input row y0 - 1 + rr
+            const int yy = y0 - 1 + rr;
+            if (yy < 0 || yy >= H) continue;
+            const __half* rowp = x + ((b * H + yy) * (size_t)W) * C + (size_t)cg * 8;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = xw + kx - 1;
+                if (xx < 0 || xx >= W) continue;
+                const uint4 raw = *reinterpret_cast<const uint4*>(rowp + (size_t)xx * C);
+                const __half2* hp = reinterpret_cast<const __half2*>(&raw);
+                float f[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float2 t2 = __half22float2(hp[q]); f[2 * q] = t2.x; f[2 * q + 1] = t2.y; }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {  // this input row is tap row ky of output row r = rr - ky
+                    const int r = rr - ky;
+                    if (r < 0 || r >= kDwR) continue;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) acc[r][v] = __builtin_fmaf(f[v], wt[ky * 3 + kx][v], acc[r][v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kDwR; ++r) {
+            const int yo = y0 + r;
+            if (yo >= H) break;
+            __half2 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a0 = acc[r][2 * q], a1 = acc[r][2 * q + 1];
+                if (gelu) { a0 = gelu_erf_h(a0); a1 = gelu_erf_h(a1); }
+                o[q] = __floats2half2_rn(a0, a1);
+            }
+            *reinterpret_cast<uint4*>(y + ((b * H + yo) * (size_t)W + xw) * C + (size_t)cg * 8) = *reinterpret_cast<const uint4*>(o);
         }
     }
 }
@@ -272,6 +347,15 @@ int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, 
     size_t g = (items + kMT - 1) / kMT;
     const size_t cap = (size_t)ctx->num_cus * 16;
     if (g > cap) g = cap;
+    const bool vec8 = dtype == 1 && (C % 8 == 0) && (kMT % (C / 8) == 0) && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
+    if (vec8) {
+        const size_t it8 = (size_t)B * ((H + kDwR - 1) / kDwR) * W * (C / 8);
+        size_t g8 = (it8 + kMT - 1) / kMT;
+        if (g8 > cap) g8 = cap;
+        hipLaunchKernelGGL(k_dwconv3x3_h8, dim3((unsigned)g8), dim3(kMT), 0, s, (const __half*)x, w_c9, (__half*)y, B, H, W, C, gelu_out);
+        AVX_HIP(ctx, hipGetLastError());
+        return AVX_OK;
+    }
     if (dtype == 0) hipLaunchKernelGGL((k_dwconv3x3<float, 1>), dim3((unsigned)g), dim3(kMT), lds, s, (const float*)x, w_c9, (float*)y, B, H, W, C, gelu_out);
     else if (vec4) hipLaunchKernelGGL((k_dwconv3x3<__half, 4>), dim3((unsigned)g), dim3(kMT), lds, s, (const __half*)x, w_c9, (__half*)y, B, H, W, C, gelu_out);
     else hipLaunchKernelGGL((k_dwconv3x3<__half, 1>), dim3((unsigned)g), dim3(kMT), lds, s, (const __half*)x, w_c9, (__half*)y, B, H, W, C, gelu_out);
