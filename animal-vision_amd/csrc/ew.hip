@@ -189,22 +189,33 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
     }
     __syncthreads();
     if (!is_last) return;
-    for (int k = wave; k < a.n_acc; k += kET / 64) {  // one wave per accumulator
+    for (int k = wave; k < a.n_acc; k += kET / 64) {  // one wave per accumulator; 8 independent (uncached) loads in flight per lane
         const int kind = a.acc_out_kind[k];
-        if (kind == AVX_EW_ACC_MIN || kind == AVX_EW_ACC_MAX) {
-            float v = kind == AVX_EW_ACC_MIN ? INFINITY : -INFINITY;
-            for (int i = lane; i < (int)gridDim.x; i += 64)
-                v = acc_merge(kind, v, __hip_atomic_load(&a.partial[(size_t)i * a.n_acc + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const bool mm = kind == AVX_EW_ACC_MIN || kind == AVX_EW_ACC_MAX;
+        const float init = kind == AVX_EW_ACC_MIN ? INFINITY : (kind == AVX_EW_ACC_MAX ? -INFINITY : 0.f);
+        float vm = init;
+        double vs = 0.0;
+        for (int i0 = lane; i0 < (int)gridDim.x; i0 += 64 * 8) {
+            float vals[8];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = acc_merge(kind, v, __shfl_xor(v, o));
-            if (lane == 0) a.scalars_out[a.acc_slot[k]] = (double)v;
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + 64 * j;
+                vals[j] = i < (int)gridDim.x ? __hip_atomic_load(&a.partial[(size_t)i * a.n_acc + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : init;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (mm) vm = acc_merge(kind, vm, vals[j]);
+                else vs += (double)vals[j];
+            }
+        }
+        if (mm) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vm = acc_merge(kind, vm, __shfl_xor(vm, o));
+            if (lane == 0) a.scalars_out[a.acc_slot[k]] = (double)vm;
         } else {
-            double v = 0.0;
-            for (int i = lane; i < (int)gridDim.x; i += 64)
-                v += (double)__hip_atomic_load(&a.partial[(size_t)i * a.n_acc + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) a.scalars_out[a.acc_slot[k]] = kind == AVX_EW_ACC_MEAN ? (double)((float)v / (float)a.n) : (double)(float)v;
+            for (int o = 32; o > 0; o >>= 1) vs += __shfl_xor(vs, o);
+            if (lane == 0) a.scalars_out[a.acc_slot[k]] = kind == AVX_EW_ACC_MEAN ? (double)((float)vs / (float)a.n) : (double)(float)vs;
         }
     }
     if (tid == 0) *a.ticket = 0;
@@ -267,7 +278,8 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
         max_reg = max_reg > reg ? max_reg : reg;
         a.acc_out_kind[k] = (uint8_t)kind; a.acc_slot[k] = slot;
     }
-    const size_t want = (a.n + kET * PX - 1) / (kET * PX), cap = (size_t)ctx->num_cus * 8;
+    // programs with reductions: fewer, fatter workgroups (the last one folds gridDim partials per accumulator)
+    const size_t want = (a.n + kET * PX - 1) / (kET * PX), cap = (size_t)ctx->num_cus * (p->n_acc ? 4 : 8);
     const int grid = (int)(want < cap ? want : cap);
     if (p->n_acc && ws->d_ew == nullptr) {  // per-block partials + the ticket (zero at rest)
         const size_t full = (size_t)ctx->num_cus * 8 * AVX_EW_MAX_ACC * sizeof(float) + 256;
