@@ -295,10 +295,22 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a) {
     const uint32_t prefix = a.pass == 0 ? 0u : a.st->prefix, mask = a.pass == 0 ? 0u : a.st->mask;
     const uint32_t above = prefix | ~mask;  // largest key with this prefix
     uint32_t best = 0xffffffffu;
-    for (size_t i = (size_t)blockIdx.x * kT + t; i < a.n; i += (size_t)gridDim.x * kT) {
-        const uint32_t k = f2key(a.x[i]);
+    auto visit = [&](float f) {
+        const uint32_t k = f2key(f);
         if ((k & mask) == prefix) atomicAdd(&h[(k >> a.shift) & (nb - 1)], 1u);
         else if (find_next && k > above && k < best) best = k;  // successor candidates outside the 22-bit prefix
+    };
+    // 16-byte loads over the aligned body; the (<= 3 + 3) head / tail elements go to the first threads of block 0
+    const size_t head = ((16 - ((uintptr_t)a.x & 15)) & 15) / 4 < a.n ? ((16 - ((uintptr_t)a.x & 15)) & 15) / 4 : a.n;
+    const size_t nvec = (a.n - head) / 4, tail0 = head + nvec * 4;
+    const float4* xv = reinterpret_cast<const float4*>(a.x + head);
+    for (size_t i = (size_t)blockIdx.x * kT + t; i < nvec; i += (size_t)gridDim.x * kT) {
+        const float4 v = xv[i];
+        visit(v.x); visit(v.y); visit(v.z); visit(v.w);
+    }
+    if (blockIdx.x == 0) {
+        if ((size_t)t < head) visit(a.x[t]);
+        if (tail0 + t < a.n && t < 4) visit(a.x[tail0 + t]);
     }
     __syncthreads();
     for (int i = t; i < nb; i += kT)
@@ -326,7 +338,11 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a) {
     const int per = nb / kT;  // nb in {1024, 2048}: 4 or 8 consecutive bins per thread
     uint32_t loc[8];
     unsigned long long sum = 0;
-    for (int i = 0; i < per; ++i) { loc[i] = __hip_atomic_load(&a.hist[t * per + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sum += loc[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)  // independent uncached loads: all in flight together
+        loc[i] = i < per ? __hip_atomic_load(&a.hist[t * per + (i < per ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += loc[i];
     // inclusive scan of the 256 chunk sums (Hillis-Steele in LDS), then the one thread whose chunk straddles the rank
     csum[t] = sum;
     __syncthreads();
@@ -567,7 +583,7 @@ static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size
     const float gamma = vi - lo;
     const int has_next = (size_t)lo + 1 < n;
     // few, fat workgroups: every workgroup flushes its non-empty LDS bins with global atomics
-    const size_t want = (n + (size_t)kT * 16 - 1) / ((size_t)kT * 16), cap = (size_t)ctx->num_cus * 2;
+    const size_t want = (n + (size_t)kT * 16 - 1) / ((size_t)kT * 16), cap = (size_t)ctx->num_cus;  // measured: 1 workgroup per CU (same-address global atomics scale with the grid)
     const int g = (int)(want < cap ? (want ? want : 1) : cap);
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int p = 0; p < 3; ++p) {
