@@ -230,6 +230,8 @@ _SIGS = {
     "avx_panorama_warp_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "avx_band_stack": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(BandStackDesc), _vp, _vp]),
     "avx_percentile_dev": (_i, [_vp, _vp, _sz, ctypes.c_double, _vp, _vp]),
+    "avx_percentiles_dev": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(ctypes.c_void_p), _vp]),
     "avx_ew_run": (_i, [_vp, ctypes.POINTER(EwProgram), _vp]),
     "avx_mantis_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, ctypes.POINTER(MantisDesc), _vp]),
     "avx_resize_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),

@@ -71,11 +71,9 @@ class Hummingbird(UVSpecies):
         Bv, Gv, Rv = be.safe_norm(b_raw), be.safe_norm(g_raw), be.safe_norm(r_raw)
         combos = [be.safe_norm(U * Bv), be.safe_norm(U * Gv), be.safe_norm(U * Rv)]                       # :143-145
         small, large = be.blur(combos, 0.8), be.blur(combos, 2.0)                                         # :148-157 `bandpass`
-        bp = []
-        for m1, m2 in zip(small, large):
-            d = be.clip01(m1 - m2)
-            bp.append(be.mat(be.clip01(d / (be.percentile(d, 95.0) + 1e-8))))
-        UxB, UxG, UxR = bp
+        dogs = [be.clip01(m1 - m2) for m1, m2 in zip(small, large)]
+        p95 = be.percentiles(dogs, 95.0)  # three independent order statistics: one set of radix passes
+        UxB, UxG, UxR = [be.mat(be.clip01(d / (p + 1e-8))) for d, p in zip(dogs, p95)]
         rgb = [be.clip01(R * (1.0 - self.red_kill)), G, B]                                                # :160-163
         if self.base_soft_sigma > 0.0:
             rgb = be.blur(rgb, self.base_soft_sigma)

@@ -12,6 +12,7 @@ using namespace avxk;
 
 // from uv.hip / geom.hip (same library)
 int avx_uv_percentile_device(avx_ctx* ctx, const float* x, size_t n, double q, double* out_dev, hipStream_t s);
+int avx_uv_percentiles_device(avx_ctx* ctx, int count, const float* const* x, const size_t* n, const double* q, double* const* out_dev, hipStream_t s);
 int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize, const double* taps_host, hipStream_t s);
 extern "C" int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C, void* dst, int Hd, int Wd, int interp, void* stream);
 extern "C" int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
@@ -306,6 +307,15 @@ extern "C" int avx_band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, 
     float* base = (float*)ws->d_scratch;
     return band_stack(ctx, lin_hwc, H, W, K, d->band_matrix_host, B, d->lobe_gains_host, d->lobe_denom, d->band_weights_host, hs, wsm, base + o_tab, base + o_small,
                       base + o_sstack, stack_hwk_out, s);
+}
+
+extern "C" int avx_percentiles_dev(avx_ctx* ctx, int count, const float* const* data_dev, const size_t* n, const double* q, double* const* out_dev, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, count >= 1 && count <= 16 && data_dev && n && q && out_dev, "avx_percentiles_dev: bad arguments");
+    for (int i = 0; i < count; ++i)
+        AVX_REQUIRE(ctx, data_dev[i] && out_dev[i] && n[i] > 0 && q[i] >= 0.0 && q[i] <= 100.0, "avx_percentiles_dev: bad request %d", i);
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    return avx_uv_percentiles_device(ctx, count, data_dev, n, q, out_dev, avx_pick_stream(ctx, stream));
 }
 
 extern "C" int avx_percentile_dev(avx_ctx* ctx, const float* data_dev, size_t n, double q, double* out_dev, void* stream) {

@@ -275,56 +275,69 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // atomics; the LAST workgroup to finish (ticket counter behind an agent-scope fence) picks the bin that holds the rank,
 // narrows the prefix, re-zeroes the histogram and the ticket, and -- on the last pass -- resolves the successor key
 // and performs NumPy's float32 lerp.  Pass 0 takes its state from the arguments: no init launch, no memset.
-struct SelPass {
-    const float* x; size_t n; int pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket;
-    unsigned long long rank0; float gamma; int has_next; double* out;
-};
+constexpr int kSelMax = 4;  // order statistics resolved together by one set of passes
+struct SelJob { const float* x; size_t n; unsigned long long rank0; float gamma; int has_next; double* out; };
+struct SelPass { int n_jobs, pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket; SelJob job[kSelMax]; };
 
+// NJ percentiles per launch: the data pass walks the NJ arrays one after the other into NJ LDS histograms, and the
+// last workgroup picks for each in turn -- the per-launch fixed costs (LDS clear / flush, ticket, tail latency)
+// are paid once, which is most of the time of a pass at 1080p.
+template <int NJ>
 __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a) {
-    __shared__ uint32_t h[2048];
+    __shared__ uint32_t h[NJ][2048];
     __shared__ uint32_t wmin[kT / 64];
     __shared__ unsigned long long csum[kT];
-    __shared__ int first_after[kT];
+    __shared__ int first_after[kT / 64];
     __shared__ int sel_chunk, sel_bin, is_last;
     __shared__ unsigned long long sel_rank;
     __shared__ uint32_t sel_cnt;
     const int nb = 1 << a.bits, t = threadIdx.x;
-    const bool last_pass = a.pass == 2, find_next = last_pass && a.has_next;
-    for (int i = t; i < nb; i += kT) h[i] = 0;
+    const bool last_pass = a.pass == 2;
+    for (int i = t; i < NJ * 2048; i += kT) (&h[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t prefix = a.pass == 0 ? 0u : a.st->prefix, mask = a.pass == 0 ? 0u : a.st->mask;
-    const uint32_t above = prefix | ~mask;  // largest key with this prefix
-    uint32_t best = 0xffffffffu;
-    auto visit = [&](float f) {
-        const uint32_t k = f2key(f);
-        if ((k & mask) == prefix) atomicAdd(&h[(k >> a.shift) & (nb - 1)], 1u);
-        else if (find_next && k > above && k < best) best = k;  // successor candidates outside the 22-bit prefix
-    };
-    // 16-byte loads over the aligned body; the (<= 3 + 3) head / tail elements go to the first threads of block 0
-    const size_t head = ((16 - ((uintptr_t)a.x & 15)) & 15) / 4 < a.n ? ((16 - ((uintptr_t)a.x & 15)) & 15) / 4 : a.n;
-    const size_t nvec = (a.n - head) / 4, tail0 = head + nvec * 4;
-    const float4* xv = reinterpret_cast<const float4*>(a.x + head);
-    for (size_t i = (size_t)blockIdx.x * kT + t; i < nvec; i += (size_t)gridDim.x * kT) {
-        const float4 v = xv[i];
-        visit(v.x); visit(v.y); visit(v.z); visit(v.w);
-    }
-    if (blockIdx.x == 0) {
-        if ((size_t)t < head) visit(a.x[t]);
-        if (tail0 + t < a.n && t < 4) visit(a.x[tail0 + t]);
-    }
-    __syncthreads();
-    for (int i = t; i < nb; i += kT)
-        if (h[i]) atomicAdd(&a.hist[i], h[i]);
-    if (find_next) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(best, o); best = v < best ? v : best; }
-        if ((t & 63) == 0) wmin[t >> 6] = best;
-        __syncthreads();
-        if (t == 0) {
-            for (int w = 1; w < kT / 64; ++w) best = wmin[w] < best ? wmin[w] : best;
-            if (best != 0xffffffffu) atomicMin(&a.st->next_above, best);
+    for (int j = 0; j < NJ; ++j) {
+        if (j >= a.n_jobs) break;
+        const SelJob jb = a.job[j];
+        SelState* st = a.st + j;
+        const bool find_next = last_pass && jb.has_next;
+        const uint32_t prefix = a.pass == 0 ? 0u : st->prefix, mask = a.pass == 0 ? 0u : st->mask;
+        const uint32_t above = prefix | ~mask;  // largest key with this prefix
+        uint32_t best = 0xffffffffu;
+        auto visit = [&](float f) {
+            const uint32_t k = f2key(f);
+            if ((k & mask) == prefix) atomicAdd(&h[j][(k >> a.shift) & (nb - 1)], 1u);
+            else if (find_next && k > above && k < best) best = k;  // successor candidates outside the 22-bit prefix
+        };
+        // 16-byte loads over the aligned body; the (<= 3 + 3) head / tail elements go to the first threads of block 0
+        const size_t mis = ((16 - ((uintptr_t)jb.x & 15)) & 15) / 4;
+        const size_t head = mis < jb.n ? mis : jb.n;
+        const size_t nvec = (jb.n - head) / 4, tail0 = head + nvec * 4;
+        const float4* xv = reinterpret_cast<const float4*>(jb.x + head);
+        for (size_t i = (size_t)blockIdx.x * kT + t; i < nvec; i += (size_t)gridDim.x * kT) {
+            const float4 v = xv[i];
+            visit(v.x); visit(v.y); visit(v.z); visit(v.w);
+        }
+        if (blockIdx.x == 0) {
+            if ((size_t)t < head) visit(jb.x[t]);
+            if (tail0 + t < jb.n && t < 4) visit(jb.x[tail0 + t]);
+        }
+        if (find_next) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(best, o); best = v < best ? v : best; }
+            __syncthreads();
+            if ((t & 63) == 0) wmin[t >> 6] = best;
+            __syncthreads();
+            if (t == 0) {
+                for (int w = 1; w < kT / 64; ++w) best = wmin[w] < best ? wmin[w] : best;
+                if (best != 0xffffffffu) atomicMin(&st->next_above, best);
+            }
         }
     }
+    __syncthreads();
+    for (int j = 0; j < a.n_jobs; ++j)
+        for (int i = t; i < nb; i += kT)
+            if (h[j][i]) atomicAdd(&a.hist[j * 2048 + i], h[j][i]);
     // ---- last workgroup: pick ------------------------------------------------------------------------------------
     // Everything the workgroups exchange travels in agent-scope atomics (histogram, successor key, ticket) and is
     // read back with agent-scope atomic loads, so no cache write-back / invalidate (__threadfence: a whole-L2 flush
@@ -336,68 +349,76 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a) {
     __syncthreads();
     if (!is_last) return;
     const int per = nb / kT;  // nb in {1024, 2048}: 4 or 8 consecutive bins per thread
-    uint32_t loc[8];
-    unsigned long long sum = 0;
+    for (int j = 0; j < a.n_jobs; ++j) {
+        const SelJob jb = a.job[j];
+        SelState* st = a.st + j;
+        uint32_t* hist = a.hist + j * 2048;
+        const uint32_t prefix = a.pass == 0 ? 0u : st->prefix, mask = a.pass == 0 ? 0u : st->mask;
+        uint32_t loc[8];
+        unsigned long long sum = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)  // independent uncached loads: all in flight together
-        loc[i] = i < per ? __hip_atomic_load(&a.hist[t * per + (i < per ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (int i = 0; i < 8; ++i)  // independent uncached loads: all in flight together
+            loc[i] = i < per ? __hip_atomic_load(&hist[t * per + (i < per ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sum += loc[i];
-    // inclusive scan of the 256 chunk sums (Hillis-Steele in LDS), then the one thread whose chunk straddles the rank
-    csum[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < kT; o <<= 1) {
-        const unsigned long long v = t >= o ? csum[t - o] : 0ull;
+        for (int i = 0; i < 8; ++i) sum += loc[i];
+        // inclusive scan of the 256 chunk sums (Hillis-Steele in LDS), then the one thread whose chunk straddles the rank
         __syncthreads();
-        csum[t] += v;
+        csum[t] = sum;
         __syncthreads();
-    }
-    const unsigned long long r = a.pass == 0 ? a.rank0 : a.st->rank;
-    const unsigned long long incl = csum[t], excl = incl - sum;
-    if (t == 0) sel_chunk = kT - 1;  // rank beyond the data (cannot happen for rank < n): last chunk
-    __syncthreads();
-    if (excl <= r && r < incl) sel_chunk = t;
-    __syncthreads();
-    if (t == sel_chunk) {
-        unsigned long long cum = excl;
-        int i = 0;
-        for (; i < per; ++i) {
-            if (cum + loc[i] > r) break;
-            cum += loc[i];
+        for (int o = 1; o < kT; o <<= 1) {
+            const unsigned long long v = t >= o ? csum[t - o] : 0ull;
+            __syncthreads();
+            csum[t] += v;
+            __syncthreads();
         }
-        if (i == per) i = per - 1;
-        const int b = t * per + i;
-        a.st->prefix = prefix | ((uint32_t)b << a.shift);
-        a.st->mask = mask | ((uint32_t)(nb - 1) << a.shift);
-        a.st->rank = r - cum;
-        if (a.pass == 0) a.st->next_above = 0xffffffffu;
-        if (last_pass) { a.st->key_lo = prefix | (uint32_t)b; a.st->cnt_in_bin = loc[i]; sel_bin = b; sel_rank = r - cum; sel_cnt = loc[i]; }
-    }
-    if (last_pass) {  // successor of x[k] among the distinct keys, then np.percentile's float32 lerp
+        const unsigned long long r = a.pass == 0 ? jb.rank0 : st->rank;
+        const unsigned long long incl = csum[t], excl = incl - sum;
+        if (t == 0) sel_chunk = kT - 1;  // rank beyond the data (cannot happen for rank < n): last chunk
         __syncthreads();
-        int f = 0x7fffffff;
-        for (int i = per - 1; i >= 0; --i)
-            if (loc[i] && t * per + i > sel_bin) f = t * per + i;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(f, o); f = v < f ? v : f; }
-        if ((t & 63) == 0) first_after[t >> 6] = f;
+        if (excl <= r && r < incl) sel_chunk = t;
         __syncthreads();
-        if (t == 0) {
-            int m = first_after[0];
-            for (int w = 1; w < kT / 64; ++w) m = first_after[w] < m ? first_after[w] : m;
-            const uint32_t next_above = __hip_atomic_load(&a.st->next_above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t next_key = m != 0x7fffffff ? (prefix | (uint32_t)m) : next_above;
-            const uint32_t key_lo = prefix | (uint32_t)sel_bin;
-            const float lo = key2f(key_lo);
-            float hi = lo;
-            if (a.has_next && sel_rank + 1 >= sel_cnt) hi = next_key == 0xffffffffu ? lo : key2f(next_key);  // else x[k+1] duplicates x[k]
-            const float diff = hi - lo;
-            float res = lo + diff * a.gamma;
-            if (a.gamma >= 0.5f) res = hi - diff * (1.0f - a.gamma);
-            *a.out = (double)res;  // a float32 value (np.percentile returns np.float32 here)
+        if (t == sel_chunk) {
+            unsigned long long cum = excl;
+            int i = 0;
+            for (; i < per; ++i) {
+                if (cum + loc[i] > r) break;
+                cum += loc[i];
+            }
+            if (i == per) i = per - 1;
+            const int b = t * per + i;
+            st->prefix = prefix | ((uint32_t)b << a.shift);
+            st->mask = mask | ((uint32_t)(nb - 1) << a.shift);
+            st->rank = r - cum;
+            if (a.pass == 0) st->next_above = 0xffffffffu;
+            if (last_pass) { st->key_lo = prefix | (uint32_t)b; st->cnt_in_bin = loc[i]; sel_bin = b; sel_rank = r - cum; sel_cnt = loc[i]; }
         }
+        if (last_pass) {  // successor of x[k] among the distinct keys, then np.percentile's float32 lerp
+            __syncthreads();
+            int f = 0x7fffffff;
+            for (int i = per - 1; i >= 0; --i)
+                if (loc[i] && t * per + i > sel_bin) f = t * per + i;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(f, o); f = v < f ? v : f; }
+            if ((t & 63) == 0) first_after[t >> 6] = f;
+            __syncthreads();
+            if (t == 0) {
+                int m = first_after[0];
+                for (int w = 1; w < kT / 64; ++w) m = first_after[w] < m ? first_after[w] : m;
+                const uint32_t next_above = __hip_atomic_load(&st->next_above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t next_key = m != 0x7fffffff ? (prefix | (uint32_t)m) : next_above;
+                const uint32_t key_lo = prefix | (uint32_t)sel_bin;
+                const float lo = key2f(key_lo);
+                float hi = lo;
+                if (jb.has_next && sel_rank + 1 >= sel_cnt) hi = next_key == 0xffffffffu ? lo : key2f(next_key);  // else x[k+1] duplicates x[k]
+                const float diff = hi - lo;
+                float res = lo + diff * jb.gamma;
+                if (jb.gamma >= 0.5f) res = hi - diff * (1.0f - jb.gamma);
+                *jb.out = (double)res;  // a float32 value (np.percentile returns np.float32 here)
+            }
+        }
+        for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
+        __syncthreads();
     }
-    for (int i = 0; i < per; ++i) a.hist[t * per + i] = 0;
     if (t == 0) *a.ticket = 0;
 }
 
@@ -556,7 +577,7 @@ static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_
     avx_ws* ws = avx_workspace(ctx, stream);
     if (!ws) return AVX_ERR_NOMEM;
     if (out_ws) *out_ws = ws;
-    const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + 2048 * 4 + sizeof(SelState) + 64 + 16 * 8 + 16 * 129 * 4 + 4096;
+    const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + kSelMax * 2048 * 4 + kSelMax * sizeof(SelState) + 64 + 16 * 8 + 16 * 129 * 4 + 4096;
     if (ws->uv_small == nullptr) {
         AVX_HIP(ctx, hipMalloc(&ws->uv_small, need));
         AVX_HIP(ctx, hipMemsetAsync(ws->uv_small, 0, need, stream));  // histogram and ticket start at zero; k_sel_pass leaves them so
@@ -564,8 +585,8 @@ static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_
     char* p = (char*)ws->uv_small;
     s->partials = (Stat3*)p; p += (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3);
     s->stats = (float4*)p; p += 16 * sizeof(float4);
-    s->hist = (uint32_t*)p; p += 2048 * 4;
-    s->sel = (SelState*)p; p += sizeof(SelState) + 8;
+    s->hist = (uint32_t*)p; p += kSelMax * 2048 * 4;
+    s->sel = (SelState*)p; p += kSelMax * sizeof(SelState) + 8;
     s->ticket = (uint32_t*)p; p += 16;
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     s->pct = (double*)p; p += 16 * 8;
@@ -573,25 +594,43 @@ static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_
     return AVX_OK;
 }
 
-// exact np.percentile(x, q) (linear interpolation) of n device floats -> *out_dev (device double)
-static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size_t n, double q, double* out_dev, hipStream_t s) {
-    // NumPy (2.x) evaluates the virtual index in the array's dtype: float32(n-1) * (float32(q)/float32(100)).
-    const float vi = (float)(n - 1) * ((float)q / 100.0f);
-    float lo = floorf(vi);
-    if (lo < 0) lo = 0;
-    if (lo > (float)(n - 1)) lo = (float)(n - 1);
-    const float gamma = vi - lo;
-    const int has_next = (size_t)lo + 1 < n;
-    // few, fat workgroups: every workgroup flushes its non-empty LDS bins with global atomics
-    const size_t want = (n + (size_t)kT * 16 - 1) / ((size_t)kT * 16), cap = (size_t)ctx->num_cus;  // measured: 1 workgroup per CU (same-address global atomics scale with the grid)
-    const int g = (int)(want < cap ? (want ? want : 1) : cap);
-    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-    for (int p = 0; p < 3; ++p) {
-        SelPass a{x, n, p, shifts[p], bits[p], u.sel, u.hist, u.ticket, (unsigned long long)lo, gamma, has_next, out_dev};
-        hipLaunchKernelGGL(k_sel_pass, dim3(g), dim3(kT), 0, s, a);
+// exact np.percentile(x_j, q_j) (linear interpolation) of n_j device floats -> *out_j (device doubles), up to kSelMax
+// order statistics resolved by the same three passes
+struct PctReq { const float* x; size_t n; double q; double* out_dev; };
+static int run_percentiles(avx_ctx* ctx, const UvScratch& u, const PctReq* req, int count, hipStream_t s) {
+    for (int base = 0; base < count; base += kSelMax) {
+        const int nj = count - base < kSelMax ? count - base : kSelMax;
+        SelPass a{};
+        a.n_jobs = nj; a.st = u.sel; a.hist = u.hist; a.ticket = u.ticket;
+        size_t nmax = 0;
+        for (int j = 0; j < nj; ++j) {
+            const PctReq& r = req[base + j];
+            // NumPy (2.x) evaluates the virtual index in the array's dtype: float32(n-1) * (float32(q)/float32(100)).
+            const float vi = (float)(r.n - 1) * ((float)r.q / 100.0f);
+            float lo = floorf(vi);
+            if (lo < 0) lo = 0;
+            if (lo > (float)(r.n - 1)) lo = (float)(r.n - 1);
+            a.job[j] = SelJob{r.x, r.n, (unsigned long long)lo, vi - lo, (size_t)lo + 1 < r.n ? 1 : 0, r.out_dev};
+            nmax = r.n > nmax ? r.n : nmax;
+        }
+        // few, fat workgroups: every workgroup flushes its non-empty LDS bins with global atomics
+        const size_t want = (nmax + (size_t)kT * 16 - 1) / ((size_t)kT * 16);
+        const size_t cap = (size_t)ctx->num_cus;  // measured: 1 workgroup per CU (same-address global atomics scale with the grid)
+        const int g = (int)(want < cap ? (want ? want : 1) : cap);
+        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+        for (int p = 0; p < 3; ++p) {
+            a.pass = p; a.shift = shifts[p]; a.bits = bits[p];
+            if (nj == 1) hipLaunchKernelGGL(k_sel_pass<1>, dim3(g), dim3(kT), 0, s, a);
+            else if (nj == 2) hipLaunchKernelGGL(k_sel_pass<2>, dim3(g), dim3(kT), 0, s, a);
+            else hipLaunchKernelGGL(k_sel_pass<4>, dim3(g), dim3(kT), 0, s, a);
+        }
     }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
+}
+static int run_percentile(avx_ctx* ctx, const UvScratch& u, const float* x, size_t n, double q, double* out_dev, hipStream_t s) {
+    const PctReq r{x, n, q, out_dev};
+    return run_percentiles(ctx, u, &r, 1, s);
 }
 
 // ---- internal entry points for other translation units of the library (mantis.hip) ---------------------
@@ -600,6 +639,16 @@ int avx_uv_percentile_device(avx_ctx* ctx, const float* x, size_t n, double q, d
     int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     return run_percentile(ctx, u, x, n, q, out_dev, s);
+}
+
+int avx_uv_percentiles_device(avx_ctx* ctx, int count, const float* const* x, const size_t* n, const double* q, double* const* out_dev, hipStream_t s) {
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, s, &u);
+    if (rc) return rc;
+    PctReq rq[16];
+    if (count > 16) return avx_fail(ctx, AVX_ERR_INVALID, "at most 16 percentiles per call");
+    for (int i = 0; i < count; ++i) rq[i] = PctReq{x[i], n[i], q[i], out_dev[i]};
+    return run_percentiles(ctx, u, rq, count, s);
 }
 
 int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize, const double* taps_host, hipStream_t s) {
@@ -778,15 +827,17 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
         m.enc_thr = ctx->d_enc_thr_f32; m.coarse = ctx->d_coarse_f32; m.lo_key = ctx->coarse_lo_key[0]; m.pass = 0;
         if (d->mapping == 2) {
             hipLaunchKernelGGL(k_opponent_prep, dim3(g), dim3(kT), 0, s, ubg, n, aux, aux + n);
-            if ((rc = run_percentile(ctx, u, aux, n, 95.0, u.pct + 0, s))) return rc;
-            if ((rc = run_percentile(ctx, u, aux + n, n, 95.0, u.pct + 1, s))) return rc;
+            const PctReq rq[2] = {{aux, n, 95.0, u.pct + 0}, {aux + n, n, 95.0, u.pct + 1}};
+            if ((rc = run_percentiles(ctx, u, rq, 2, s))) return rc;
         } else if (d->mapping == 0 || d->mapping == 4) {
-            for (int k = 0; k < 3; ++k)
-                if ((rc = run_percentile(ctx, u, ubg + (size_t)k * n, n, 95.0, u.pct + k, s))) return rc;
+            PctReq rq[4];
+            int nr = 0;
+            for (int k = 0; k < 3; ++k) rq[nr++] = PctReq{ubg + (size_t)k * n, n, 95.0, u.pct + k};
+            if (d->mapping == 4) rq[nr++] = PctReq{ubg, n, 98.0, u.pct + 3};
+            if ((rc = run_percentiles(ctx, u, rq, nr, s))) return rc;
         }
         if (d->mapping == 3) { if ((rc = run_percentile(ctx, u, ubg, n, 98.0, u.pct + 0, s))) return rc; }
         if (d->mapping == 4) {
-            if ((rc = run_percentile(ctx, u, ubg, n, 98.0, u.pct + 3, s))) return rc;
             m.pass = 1;
             hipLaunchKernelGGL(k_map_encode, dim3(g), dim3(kT), 0, s, m);
             if ((rc = run_percentile(ctx, u, aux, 3 * n, 99.0, u.pct + 4, s))) return rc;

@@ -466,6 +466,20 @@ class DeviceBackend:
         self._call(lambda s: ctx._check(lib.avx_percentile_dev(ctx._h, ptr, count, float(q), out, s)))
         return self.scalar(slot)
 
+    def percentiles(self, vals: Sequence, q: float) -> List[Val]:
+        """np.percentile(v, q) for several independent planes: resolved together (one set of radix passes per four)."""
+        ptrs = [self._contiguous([v])[0] for v in vals]
+        slots = [self.new_slot() for _ in vals]
+        k = len(vals)
+        a_ptr = (ctypes.c_void_p * k)(*ptrs)
+        a_n = (ctypes.c_size_t * k)(*([self.n] * k))
+        a_q = (ctypes.c_double * k)(*([float(q)] * k))
+        a_out = (ctypes.c_void_p * k)(*[self.scalars.ptr + 8 * s_ for s_ in slots])
+        self._keep += [a_ptr, a_n, a_q, a_out]
+        ctx = self.ctx
+        self._call(lambda s: ctx._check(lib.avx_percentiles_dev(ctx._h, k, a_ptr, a_n, a_q, a_out, s)))
+        return [self.scalar(s_) for s_ in slots]
+
     def _contiguous(self, vals: Sequence) -> Tuple[int, List[Val]]:
         """Device pointer of K consecutive float32 planes holding `vals` (materialising if they are not already so)."""
         vals = [self._v(v) for v in vals]

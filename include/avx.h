@@ -249,6 +249,10 @@ int avx_band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, const avx_b
                    float* stack_hwk_out, void* stream);
 /* avx_percentile with the result left on the device (one double, the float32 value NumPy would return). */
 int avx_percentile_dev(avx_ctx* ctx, const float* data_dev, size_t n, double q, double* out_dev, void* stream);
+/* `count` (<= 16) independent percentiles; up to four are resolved by the same three radix passes (the arrays of
+ * pointers / sizes are host arrays of device pointers). */
+int avx_percentiles_dev(avx_ctx* ctx, int count, const float* const* data_dev, const size_t* n, const double* q,
+                        double* const* out_dev, void* stream);
 
 /* ---- fused elementwise programs over float32 planes (csrc/ew.hip) --------------------------------------------
  * The remaining UV species (animals/reindeer.py:83-135, goldfish.py:86-180, ... ) are NumPy expression chains over

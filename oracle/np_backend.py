@@ -57,6 +57,10 @@ class NumpyBackend:
         return np.percentile(v, q)
 
     @staticmethod
+    def percentiles(vals, q):
+        return [np.percentile(v, q) for v in vals]
+
+    @staticmethod
     def mat(v):
         return v
 
