@@ -369,6 +369,17 @@ struct TableCache {
 
 }  // namespace
 
+// Drop every cached table when more than `limit` slots are taken (callers that look a table up and then call other
+// entry points trim FIRST, so that nothing they hold is evicted under them).
+int avx_geom_cache_trim(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int limit) {
+    if (ws->n_geom_tabs <= limit) return AVX_OK;
+    AVX_HIP(ctx, hipStreamSynchronize(s));  // launches may still be reading the tables
+    for (int i = 0; i < ws->n_geom_tabs; ++i)
+        if (((ws->geom_tabs[i].key >> 54) & 0xf) < 8) (void)hipFree(ws->geom_tabs[i].dev);
+    ws->n_geom_tabs = 0;
+    return AVX_OK;
+}
+
 // uv_helpers.panorama_warp (:84-99): INTER_CUBIC widen to newW, then the centre crop [start, start+W): only the
 // cropped columns are computed (the x table is sliced); the height is unchanged (cubic taps 0,1,0,0: identity).
 int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s) {

@@ -17,6 +17,7 @@ int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, i
 extern "C" int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C, void* dst, int Hd, int Wd, int interp, void* stream);
 extern "C" int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
 int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s);
+int avx_geom_cache_trim(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int limit);
 
 namespace {
 
@@ -245,10 +246,32 @@ static int uv_front(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, int newW,
 // tab: (K*3 + B*3 + K*B) floats of device scratch; small / sstack: 3*hs*ws and hs*ws*K floats (reduced-size route).
 static int band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, int K, const float* M_host, int B, const float* gains_host, float denom,
                       const float* wts_host, int hs, int wsm, float* tab, float* small, float* sstack, float* stack, hipStream_t s) {
-    float* dM = tab; float* dgains = dM + K * 3; float* dwts = dgains + 3 * B;
-    AVX_HIP(ctx, hipMemcpyAsync(dM, M_host, sizeof(float) * K * 3, hipMemcpyHostToDevice, s));
-    AVX_HIP(ctx, hipMemcpyAsync(dgains, gains_host, sizeof(float) * B * 3, hipMemcpyHostToDevice, s));
-    AVX_HIP(ctx, hipMemcpyAsync(dwts, wts_host, sizeof(float) * B * K, hipMemcpyHostToDevice, s));
+    // The three small tables are constants of a species: cached on the device under a hash of their contents (one
+    // blocking upload the first time, no per-frame copies afterwards); `tab` is unused when the cache holds them.
+    (void)tab;
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    { int rc0 = avx_geom_cache_trim(ctx, ws, s, 36); if (rc0) return rc0; }  // the resizes below trim at 48: they will not evict what we look up here
+    uint64_t hkey = 1469598103934665603ull;
+    auto mix = [&](const float* p, size_t cnt) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+        for (size_t i = 0; i < cnt; ++i) { hkey ^= w[i]; hkey *= 1099511628211ull; }
+    };
+    mix(M_host, (size_t)K * 3); mix(gains_host, (size_t)B * 3); mix(wts_host, (size_t)B * K);
+    hkey = (hkey & 0x003fffffffffffffull) | (7ull << 58);  // kind 7 (geometry tables use 1..3), component 0: a real pointer
+    float* dM = nullptr;
+    for (int i = 0; i < ws->n_geom_tabs; ++i)
+        if (ws->geom_tabs[i].key == hkey) dM = (float*)ws->geom_tabs[i].dev;
+    if (!dM) {
+        if (ws->n_geom_tabs >= 60) return avx_fail(ctx, AVX_ERR_NOMEM, "band-table cache full");
+        const size_t cnt = (size_t)K * 3 + (size_t)B * 3 + (size_t)B * K;
+        AVX_HIP(ctx, hipMalloc((void**)&dM, cnt * sizeof(float) + 256));
+        AVX_HIP(ctx, hipMemcpy(dM, M_host, sizeof(float) * K * 3, hipMemcpyHostToDevice));
+        AVX_HIP(ctx, hipMemcpy(dM + K * 3, gains_host, sizeof(float) * B * 3, hipMemcpyHostToDevice));
+        AVX_HIP(ctx, hipMemcpy(dM + K * 3 + 3 * B, wts_host, sizeof(float) * B * K, hipMemcpyHostToDevice));
+        ws->geom_tabs[ws->n_geom_tabs++] = {hkey, dM};
+    }
+    float* dgains = dM + K * 3; float* dwts = dgains + 3 * B;
     const size_t n = (size_t)H * W, nsmall = (size_t)hs * wsm;
     int rc;
     if (hs != H || wsm != W) {
