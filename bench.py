@@ -28,6 +28,9 @@ WORKLOADS = {
     "cat_4k": ("cat", 2160, 3840, 8),
     "dog_4k": ("dog", 2160, 3840, 8),
     "wolf_1080p": ("wolf", 1080, 1920, 32),
+    "lion_1080p": ("lion", 1080, 1920, 32),
+    "squirrel_1080p": ("squirrel", 1080, 1920, 32),
+    "sheep_1080p": ("sheep", 1080, 1920, 32),
     # honeybee: "honeybee" = the route the reference codes (analytic lobes, F3/F5); "honeybee_mst" = MST++ cube
     "honeybee_1080p": ("honeybee", 1080, 1920, 8),
     "honeybee_4k": ("honeybee", 2160, 3840, 4),
