@@ -151,6 +151,53 @@ __global__ __launch_bounds__(kT) void k_spectral_integrate(const void* __restric
     block_stats_store<KMAX>(mn, mx, sm, K, partials);
 }
 
+// The same for a float16 NHWC cube (what an MST++-style model emits; BASELINE config 5), at HBM rate: pixels are
+// B*2 bytes (62 for 31 bands) -- unaligned for any vector load done per pixel -- so a workgroup stages the
+// contiguous span of its 256 pixels in LDS with 16-byte loads and each thread then walks its own pixel there.
+// Weights arrive band-major and zero-padded to KP ([B][KP]): for one band the KP weights are wave-uniform and
+// contiguous, i.e. scalar loads feeding the FMAs as SGPR operands.  Same FMA order over b as the generic kernel.
+template <int KP>
+__global__ __launch_bounds__(kT) void k_spectral_nhwc_h(const __half* __restrict__ cube, size_t n, int B, const float* __restrict__ wT /*[B][KP]*/, int K,
+                                                        float* __restrict__ out, Stat3* partials) {
+    extern __shared__ __align__(16) unsigned char tile_raw[];
+    const __half* tile = reinterpret_cast<const __half*>(tile_raw);
+    float mn[KP], mx[KP];
+    double sm[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; sm[k] = 0.0; }
+    const int t = threadIdx.x;
+    for (size_t p0 = (size_t)blockIdx.x * kT; p0 < n; p0 += (size_t)gridDim.x * kT) {
+        const int np = (int)(n - p0 < (size_t)kT ? n - p0 : kT);
+        const size_t bytes = (size_t)np * B * 2;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(cube) + p0 * B * 2;  // 16-byte aligned: p0 % 256 == 0
+        __syncthreads();  // the previous tile is no longer read
+        const int nvec = (int)(bytes / 16);
+        for (int i = t; i < nvec; i += kT) reinterpret_cast<uint4*>(tile_raw)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (int i = nvec * 16 + t * 2; i < (int)bytes; i += kT * 2) *reinterpret_cast<uint16_t*>(tile_raw + i) = *reinterpret_cast<const uint16_t*>(src + i);
+        __syncthreads();
+        if (t < np) {
+            float acc[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) acc[k] = 0.0f;
+            const __half* px = tile + (size_t)t * B;
+#pragma unroll 4
+            for (int b = 0; b < B; ++b) {
+                const float x = __half2float(px[b]);
+                const float* wb = wT + b * KP;  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < KP; ++k) acc[k] = fma_t(x, wb[k], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+                if (k < K) {
+                    out[(size_t)k * n + p0 + t] = acc[k];
+                    mn[k] = fminf(mn[k], acc[k]); mx[k] = fmaxf(mx[k], acc[k]); sm[k] += (double)acc[k];
+                }
+        }
+    }
+    block_stats_store<KP>(mn, mx, sm, K, partials);
+}
+
 // ---- plain statistics of existing planes ----------------------------------------------------------
 template <int KMAX>
 __global__ __launch_bounds__(kT) void k_plane_stats(const float* __restrict__ planes, size_t n, int K, Stat3* partials) {
@@ -694,9 +741,49 @@ int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype,
     int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     const size_t n = (size_t)H * W;
-    AVX_HIP(ctx, hipMemcpyAsync(u.mat, weights_host, sizeof(float) * K * B, hipMemcpyHostToDevice, s));
-    const int g = grid_for(ctx, n);
-    hipLaunchKernelGGL(k_spectral_integrate<16>, dim3(g), dim3(kT), sizeof(float) * K * B, s, hsi, layout, dtype, n, B, u.mat, K, out_planes, u.partials);
+    int g = grid_for(ctx, n);
+    if (layout == 0 && dtype == 1 && ((uintptr_t)hsi & 15u) == 0) {  // float16 NHWC: the staged, HBM-rate kernel
+        const int KP = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : 16));
+        float wT[129 * 16];
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < KP; ++k) wT[b * KP + k] = k < K ? weights_host[(size_t)k * B + b] : 0.0f;
+        // weights are constants of the caller's pipeline: cached on the device under a hash of their contents (one blocking
+        // upload the first time; no copy, no synchronisation afterwards)
+        avx_ws* wsp = avx_workspace(ctx, s);
+        if (!wsp) return AVX_ERR_NOMEM;
+        uint64_t hk = 1469598103934665603ull;
+        for (int i = 0; i < B * KP; ++i) { uint32_t bits; memcpy(&bits, &wT[i], 4); hk ^= bits; hk *= 1099511628211ull; }
+        hk ^= (uint64_t)B * 131u + (uint64_t)KP;
+        hk = (hk & 0x003fffffffffffffull) | (6ull << 58);  // kind 6, component 0 (a real device pointer)
+        float* dwT = nullptr;
+        for (int i = 0; i < wsp->n_geom_tabs; ++i)
+            if (wsp->geom_tabs[i].key == hk) dwT = (float*)wsp->geom_tabs[i].dev;
+        if (!dwT) {
+            if (wsp->n_geom_tabs >= 60) {  // full: drop everything (launches may still be reading the tables)
+                AVX_HIP(ctx, hipStreamSynchronize(s));
+                for (int i = 0; i < wsp->n_geom_tabs; ++i)
+                    if (((wsp->geom_tabs[i].key >> 54) & 0xf) < 8) (void)hipFree(wsp->geom_tabs[i].dev);
+                wsp->n_geom_tabs = 0;
+            }
+            AVX_HIP(ctx, hipMalloc((void**)&dwT, sizeof(float) * B * KP + 256));
+            AVX_HIP(ctx, hipMemcpy(dwT, wT, sizeof(float) * B * KP, hipMemcpyHostToDevice));
+            wsp->geom_tabs[wsp->n_geom_tabs++] = {hk, dwT};
+        }
+        const size_t lds = (size_t)kT * B * 2 + 16;
+        const size_t tiles = (n + kT - 1) / kT, cap = (size_t)ctx->num_cus * 8;
+        g = (int)(tiles < cap ? tiles : cap);
+        const __half* c = (const __half*)hsi;
+#define AVX_SPEC(KPV)                                                                                                                        \
+        {                                                                                                                                    \
+            AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_spectral_nhwc_h<KPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+            hipLaunchKernelGGL(k_spectral_nhwc_h<KPV>, dim3(g), dim3(kT), lds, s, c, n, B, dwT, K, out_planes, u.partials);                \
+        }
+        if (KP == 4) AVX_SPEC(4) else if (KP == 8) AVX_SPEC(8) else if (KP == 12) AVX_SPEC(12) else AVX_SPEC(16)
+#undef AVX_SPEC
+    } else {
+        AVX_HIP(ctx, hipMemcpyAsync(u.mat, weights_host, sizeof(float) * K * B, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_spectral_integrate<16>, dim3(g), dim3(kT), sizeof(float) * K * B, s, hsi, layout, dtype, n, B, u.mat, K, out_planes, u.partials);
+    }
     hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(1024), 0, s, u.partials, g, K, n, 0, 0.0f, u.stats);
     AVX_HIP(ctx, hipGetLastError());
     if (stats_host) {

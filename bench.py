@@ -36,6 +36,10 @@ WORKLOADS = {
     "honeybee_4k": ("honeybee", 2160, 3840, 4),
     "honeybee_mst_1080p": ("honeybee_mst", 1080, 1920, 2),
     "honeybee_mst_4k": ("honeybee_mst", 2160, 3840, 1),
+    # BASELINE config 5: standalone spectral integration of an fp16 NHWC cube, (N bands-out, B bands-in) = (12,31), (10,81)
+    "spectral_4k_12x31": ("spectral:12x31", 2160, 3840, 8),
+    "spectral_4k_10x81": ("spectral:10x81", 2160, 3840, 4),
+    "spectral_1080p_12x31": ("spectral:12x31", 1080, 1920, 8),
     # the other UV species: "uv:<module>" = plane-program species, "mantis" = the fused mantis stack
     "mantis_1080p": ("mantis", 1080, 1920, 4),
     "mantis_4k": ("mantis", 2160, 3840, 2),
@@ -47,6 +51,10 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
 MFMA_FP16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, same guide
 MSTPP_FLOP_PER_PX = 703.4e3  # 2 x 351.7 kMAC/px (23.05 GMAC at 256x256)
+
+
+def DeviceBuffer_view(buf, nbytes):
+    return buf.view(0, nbytes)
 
 
 def log(*a):
@@ -87,6 +95,7 @@ def main():
     ctx = av.get_context(local_rank)
     bee = species.startswith("honeybee")
     uvsp = species.startswith("uv:") or species == "mantis"
+    spectral = species.startswith("spectral:")
     from animal_vision_amd.synthetic import structured_frame
 
     # This rank's shard of the synthetic stream: global frame index i = rank + j*world (round-robin).
@@ -98,7 +107,24 @@ def main():
     stream = ctx.stream_create()
     mst = None
     uv_obj = None
-    if uvsp:
+    if spectral:
+        from animal_vision_amd._lib import lib
+        from animal_vision_amd.uv import bandpass_weights
+
+        Kp, Bn = (int(v) for v in species.split(":")[1].split("x"))
+        lam = np.linspace(300.0 if Bn == 81 else 400.0, 700.0, Bn, dtype=np.float32)
+        edges = np.linspace(float(lam[0]), float(lam[-1]), Kp + 1)
+        wts = np.ascontiguousarray(np.stack([bandpass_weights(lam, float(lo), float(hi)) for lo, hi in zip(edges[:-1], edges[1:])]), dtype=np.float32)
+        rng = np.random.default_rng(1234 + rank)
+        cube_h = rng.random((H, W, Bn), dtype=np.float32).astype(np.float16)  # one synthetic cube, integrated B times per step
+        d_cube = ctx.upload(cube_h)
+        d_planes = ctx.malloc(4 * Kp * H * W * min(B, 4))
+
+        def run_step():
+            for j in range(B):
+                ctx._check(lib.avx_spectral_integrate(ctx._h, d_cube.ptr, 0, 1, H, W, Bn, wts.ctypes.data, Kp,
+                                                      d_planes.ptr + 4 * Kp * H * W * (j % min(B, 4)), None, stream))
+    elif uvsp:
         d_base = ctx.malloc(pool[0].nbytes)
         if species == "mantis":
             uv_obj = animals.MantisShrimp()
@@ -182,6 +208,8 @@ def main():
     # 3 B/px read + 3 B/px written (dichromat, and the fused analytic bee route); the other UV species
     # also write the warped uint8 baseline: 9 B/px
     alg_bytes = (9.0 if uvsp else 6.0) * B * H * W
+    if spectral:
+        alg_bytes = (2.0 * Bn + 4.0 * Kp) * B * H * W  # B*s read + 4K written per pixel
     achieved = alg_bytes / launch_s / 1e9
     if mst is not None:
         roof = {"bound": "mfma", "achieved": round(MSTPP_FLOP_PER_PX * B * H * W / launch_s / 1e12, 2), "peak": MFMA_FP16_PEAK_TFLOPS,
@@ -191,7 +219,7 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": ("honeybee passes (catches, blur, 2x radix select, map+encode)" if bee else
+                "kernel": ("spectral integration (fp16 NHWC cube -> K float32 planes)" if spectral else "honeybee passes (catches, blur, 2x radix select, map+encode)" if bee else
                            ("whole species plan per step (front, band stack, blurs, fused elementwise programs, encode)" if uvsp else
                             "dichromat fused launch (main + all<=1 fix-up)")),
                 "us_per_launch": round(launch_s * 1e6, 2)}
@@ -207,9 +235,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if uvsp else "f64" if species == "cat" else ("f16" if mst is not None else "f32"),
+        "dtype": "f16" if spectral else "f32" if uvsp else "f64" if species == "cat" else ("f16" if mst is not None else "f32"),
         "data": "synthetic",
-        "config": {"workload": (f"{species} species, full visualize" if uvsp else f"{species} dichromat core" if not bee else ("honeybee UV path, MST++ HSI (seeded weights) + spectral remap" if mst is not None else "honeybee UV path as coded (analytic lobes), opponent map")) + f", {W}x{H} uint8 frames, {B} frames/step per GPU, device-resident",
+        "config": {"workload": (f"spectral integrate {species[9:]} (bands out x bands in), fp16 NHWC cube" if spectral else f"{species} species, full visualize" if uvsp else f"{species} dichromat core" if not bee else ("honeybee UV path, MST++ HSI (seeded weights) + spectral remap" if mst is not None else "honeybee UV path as coded (analytic lobes), opponent map")) + f", {W}x{H} uint8 frames, {B} frames/step per GPU, device-resident",
                    "frames_per_step_per_gpu": B, "fps": round(value * 1e6 / (H * W), 1), "sharding": f"round-robin x{world}"},
         "roofline": roof,
     }
@@ -226,7 +254,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_ref
 
-        if uvsp:
+        if spectral:
+            def cpu_fn(_f):
+                sub = cube_h[:540, :960].astype(np.float32)
+                return None, np.tensordot(sub, wts.T, axes=([2], [0]))
+
+            name = "np.tensordot on a 960x540 float32 crop of the cube"
+        elif uvsp:
             if species == "mantis":
                 def cpu_fn(f):
                     return cpu_ref.mantis_visualize(f)
@@ -261,11 +295,18 @@ def main():
             if time.perf_counter() - t_cpu0 > args.cpu_seconds or n >= 64:
                 break
         t_cpu = time.perf_counter() - t_cpu0
+        cpu_px = 960 * 540 if spectral else H * W
         result["cpu_baseline"] = {
-            "value": round(n * H * W / 1e6 / t_cpu, 2), "unit": "MP/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames {W}x{H} through {name}, 1 thread of {len(os.sched_getaffinity(0))} available",
+            "value": round(n * cpu_px / 1e6 / t_cpu, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames {W}x{H} through {name}, 1 thread of {len(os.sched_getaffinity(0))} available" if not spectral
+                      else f"{n} x {name}, BLAS threads as configured ({len(os.sched_getaffinity(0))} cores available)",
         }
-        if mst is None:
+        if spectral:
+            got = ctx.download(DeviceBuffer_view(d_planes, 4 * Kp * H * W), (Kp, H, W), np.float32)[:, :540, :960]
+            _, want = cpu_fn(None)
+            err = np.abs(got.transpose(1, 2, 0) - want)
+            result["parity_checked"] = bool(err.max() <= 1e-4 * max(1.0, float(np.abs(want).max())))
+        elif mst is None:
             if uvsp and species != "mantis":
                 got = ctx.download(plan.d_out, pool[0].shape, np.uint8)[None]
             else:
@@ -281,7 +322,7 @@ def main():
             else:
                 result["parity_checked"] = bool(np.array_equal(got[0], want))
 
-    if mst is None and not uvsp and rank == 0 and world == 1 and not args.no_e2e:
+    if mst is None and not uvsp and not spectral and rank == 0 and world == 1 and not args.no_e2e:
         # PCIe-inclusive leg (never `value`): the same op through pipeline.FramePipeline, host frames in, host frames out.
         from animal_vision_amd.pipeline import FramePipeline
 
