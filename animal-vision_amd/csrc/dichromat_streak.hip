@@ -28,31 +28,80 @@ struct StreakArgs {
     int stride;
 };
 
+// v2 schedule (the arithmetic is unchanged: same FMA chains, same order).  One workgroup per image row:
+//   * the row lives in LDS as three PLANES (channel-major) with a 16-sample halo each side that holds the reflect-101
+//     mirror, so the along-row passes index without any border logic;
+//   * along-row passes: a thread owns 4 adjacent samples of one channel and reads its (4 + 2*RB)-sample window with
+//     16-byte LDS loads (conflict-free), RB in {4, 8, 12, 16} picked per row from the row's radius; taps beyond the
+//     radius are zero, and fma(x, 0, s) == s exactly, so the padded chain is bit-identical to the reference's;
+//   * bucketed quantiser; bytes are staged in LDS and leave with 4-byte stores.
+constexpr int kPad = 16;  // halo samples per side (>= the largest radius, multiple of 4)
+
+template <int RB>
+__device__ __forceinline__ void streak_along_row(const float* __restrict__ src, float* __restrict__ dst, int W, int PW, const float* __restrict__ td /*taps by distance, zero beyond r*/,
+                                                int tid) {
+    const int ngroups = (W + 3) / 4;
+    for (int item = tid; item < 3 * ngroups; item += kST) {
+        const int c = item / ngroups, xg = item - c * ngroups;
+        const float* base = src + (size_t)c * PW + kPad + 4 * xg - RB;  // 16-byte aligned: PW, kPad, RB multiples of 4
+        float w[4 + 2 * RB];
+#pragma unroll
+        for (int q = 0; q < (4 + 2 * RB) / 4; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(base)[q];
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            float sacc = w[RB + x] * td[0];
+#pragma unroll
+            for (int j = 1; j <= RB; ++j) sacc = fma_t(w[RB + x + j] + w[RB + x - j], td[j], sacc);
+            o[x] = sacc;
+        }
+        *reinterpret_cast<float4*>(dst + (size_t)c * PW + kPad + 4 * xg) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// mirror the interior of each plane into its halo (BORDER_REFLECT_101 on W)
+__device__ __forceinline__ void streak_fill_halo(float* buf, int W, int PW, int r, int tid) {
+    for (int item = tid; item < 3 * 2 * r; item += kST) {
+        const int c = item / (2 * r), e = item - c * 2 * r;
+        const int x = e < r ? -1 - e : W + (e - r);
+        buf[(size_t)c * PW + kPad + x] = buf[(size_t)c * PW + kPad + reflect101(x, W)];
+    }
+}
+
 template <bool DARK>
-__global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, StreakArgs st) {
+__global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, StreakArgs st, QuantCoarse qc) {
     extern __shared__ __align__(16) float smem_f[];
-    float* buf0 = smem_f;                 // W*3
-    float* buf1 = smem_f + (size_t)a.W * 3;
+    const int W = a.W, n3 = a.W * 3;
+    const int PW = ((W + 3) / 4 * 4) + 2 * kPad;     // plane pitch (multiple of 4)
+    float* buf0 = smem_f;                            // 3 planes
+    float* buf1 = smem_f + (size_t)3 * PW;           // 3 planes
+    uint8_t* outb = reinterpret_cast<uint8_t*>(smem_f + (size_t)6 * PW);  // W*3 bytes (+ pad)
     __shared__ float lut[256];
     __shared__ float thr[256];
-    __shared__ float t1[16], t2[40];
+    __shared__ uint8_t coarse[1024];
+    __shared__ float t1[16], td1[20], td2[20];
+    __shared__ int idx1[3][16];
     const int tid = threadIdx.x;
     for (int i = tid; i < 256; i += kST) { lut[i] = a.decode_lut[i]; thr[i] = reinterpret_cast<const float*>(a.enc_thr)[i]; }
-    const int W = a.W, n3 = a.W * 3;
+    for (int i = tid; i < 1024; i += kST) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
     const size_t frame_bytes = (size_t)a.H * a.W * 3;
     const int total_rows = a.n_frames * a.H;
     for (int gr = blockIdx.x; gr < total_rows; gr += gridDim.x) {
         const int f = gr / a.H, y = gr - f * a.H;
-        __syncthreads();  // tables of the previous row are no longer read
+        __syncthreads();  // tables and buffers of the previous row are no longer read
         if (DARK && a.flags[f] != 0u) continue;
         const float* rt = st.rows + (size_t)y * st.stride;
         const int k1 = (int)rt[0], k2 = (int)rt[1];
         const int r1 = k1 / 2, r2 = k2 / 2;
-        if (tid < 13) t1[tid] = rt[2 + tid];
-        if (tid < 33) t2[tid] = rt[15 + tid];
+        if (tid < 16) t1[tid] = tid < k1 ? rt[2 + tid] : 0.f;
+        if (tid < 20) { td1[tid] = tid <= r1 ? rt[2 + r1 + tid] : 0.f; td2[tid] = tid <= r2 ? rt[15 + r2 + tid] : 0.f; }
+        if (tid < 48) { const int c = tid / 16, j = tid - 16 * c; idx1[c][j] = j < k1 ? reflect101(c - r1 + j, 3) : 0; }
         const uint8_t* src = a.in + frame_bytes * f + (size_t)y * n3;
         uint8_t* dst = a.out + frame_bytes * f + (size_t)y * n3;
-        // ---- decode + colour stage -> buf0[x*3 + c] ------------------------------------------------
+        // ---- decode + colour stage -> buf0 planes -----------------------------------------------------
         uint32_t seen = 0;
         for (int x = tid; x < W; x += kST) {
             const uint32_t b0 = src[3 * x], b1 = src[3 * x + 1], b2 = src[3 * x + 2];
@@ -60,49 +109,56 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
             float c0, c1, c2;
             if (DARK) { c0 = b0 ? 1.0f : 0.0f; c1 = b1 ? 1.0f : 0.0f; c2 = b2 ? 1.0f : 0.0f; }
             else { c0 = lut[b0]; c1 = lut[b1]; c2 = lut[b2]; }
-            buf0[3 * x + 0] = fma_t(c2, a.M[2], fma_t(c1, a.M[1], c0 * a.M[0]));
-            buf0[3 * x + 1] = fma_t(c2, a.M[5], fma_t(c1, a.M[4], c0 * a.M[3]));
-            buf0[3 * x + 2] = fma_t(c2, a.M[8], fma_t(c1, a.M[7], c0 * a.M[6]));
+            buf0[kPad + x] = fma_t(c2, a.M[2], fma_t(c1, a.M[1], c0 * a.M[0]));
+            buf0[PW + kPad + x] = fma_t(c2, a.M[5], fma_t(c1, a.M[4], c0 * a.M[3]));
+            buf0[2 * PW + kPad + x] = fma_t(c2, a.M[8], fma_t(c1, a.M[7], c0 * a.M[6]));
         }
         if (!DARK && seen) a.flags[f] = 1u;
         __syncthreads();
-        // ---- pass 1, "row" direction = across the 3 channels (width 3, reflect-101) -> buf1 ----------
-        for (int i = tid; i < n3; i += kST) {
-            const int x = i / 3, c = i - 3 * x;
-            const float* px = buf0 + 3 * x;
-            float s = px[reflect101(c - r1, 3)] * t1[0];
-            for (int j = 1; j < k1; ++j) s = fma_t(px[reflect101(c - r1 + j, 3)], t1[j], s);
-            buf1[i] = s;
-        }
-        __syncthreads();
-        // ---- pass 1, "column" direction = along the image row (reflect-101 on W) -> buf0 -------------
-        for (int i = tid; i < n3; i += kST) {
-            const int x = i / 3, c = i - 3 * x;
-            float s = buf1[i] * t1[r1];
-            for (int j = 1; j <= r1; ++j)
-                s = fma_t(buf1[3 * reflect101(x + j, W) + c] + buf1[3 * reflect101(x - j, W) + c], t1[r1 + j], s);
-            buf0[i] = s;
-        }
-        __syncthreads();
-        // ---- pass 2: 1-tap row direction is x*1.0 (exact); column direction along the image row, sy ----
+        // ---- pass 1, "row" direction = across the 3 channels (width 3, reflect-101) -> buf1 planes --------
         for (int x = tid; x < W; x += kST) {
-            float v[3];
+            const float px[3] = {buf0[kPad + x], buf0[PW + kPad + x], buf0[2 * PW + kPad + x]};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float s = buf0[3 * x + c] * t2[r2];
-                for (int j = 1; j <= r2; ++j)
-                    s = fma_t(buf0[3 * reflect101(x + j, W) + c] + buf0[3 * reflect101(x - j, W) + c], t2[r2 + j], s);
-                v[c] = s;
+                float sacc = px[idx1[c][0]] * t1[0];
+                for (int j = 1; j < k1; ++j) sacc = fma_t(px[idx1[c][j]], t1[j], sacc);
+                buf1[(size_t)c * PW + kPad + x] = sacc;
             }
+        }
+        __syncthreads();
+        // the halo is filled out to the window radius RB (>= r): the zero taps beyond r must meet finite values
+        const int rb1 = r1 <= 4 ? 4 : 8, rb2 = r2 <= 4 ? 4 : (r2 <= 8 ? 8 : (r2 <= 12 ? 12 : 16));
+        streak_fill_halo(buf1, W, PW, rb1, tid);
+        __syncthreads();
+        // ---- pass 1, "column" direction = along the image row (sigma_x) -> buf0 ----------------------------
+        if (r1 <= 4) streak_along_row<4>(buf1, buf0, W, PW, td1, tid);
+        else streak_along_row<8>(buf1, buf0, W, PW, td1, tid);
+        __syncthreads();
+        streak_fill_halo(buf0, W, PW, rb2, tid);
+        __syncthreads();
+        // ---- pass 2: 1-tap row direction is x*1.0 (exact); along the image row again (sigma_y) -> buf1 ----
+        if (r2 <= 4) streak_along_row<4>(buf0, buf1, W, PW, td2, tid);
+        else if (r2 <= 8) streak_along_row<8>(buf0, buf1, W, PW, td2, tid);
+        else if (r2 <= 12) streak_along_row<12>(buf0, buf1, W, PW, td2, tid);
+        else streak_along_row<16>(buf0, buf1, W, PW, td2, tid);
+        __syncthreads();
+        // ---- chroma compression (rabbit, panda), quantise -> staged bytes -----------------------------------
+        for (int x = tid; x < W; x += kST) {
+            float v[3] = {buf1[kPad + x], buf1[PW + kPad + x], buf1[2 * PW + kPad + x]};
             if (a.chroma_enable) {  // apply_chroma_compression, animal_utils.py:180-181
                 const float gray = ((v[0] + v[1]) + v[2]) / 3.0f;
                 v[0] = gray + (v[0] - gray) * a.chroma_keep;
                 v[1] = gray + (v[1] - gray) * a.chroma_keep;
                 v[2] = gray + (v[2] - gray) * a.chroma_keep;
             }
-            dst[3 * x + 0] = (uint8_t)quantize<float>(v[0], thr);
-            dst[3 * x + 1] = (uint8_t)quantize<float>(v[1], thr);
-            dst[3 * x + 2] = (uint8_t)quantize<float>(v[2], thr);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) outb[3 * x + c] = (uint8_t)quantize_coarse<float, 2>(v[c], thr, coarse, qc.lo_key);
+        }
+        __syncthreads();
+        if ((((uintptr_t)dst | (uintptr_t)n3) & 3u) == 0) {
+            for (int i = tid; i < n3 / 4; i += kST) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(outb)[i];
+        } else {
+            for (int i = tid; i < n3; i += kST) dst[i] = outb[i];
         }
     }
 }
@@ -111,7 +167,10 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
 
 int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, const avx_dichromat_desc* d, hipStream_t s) {
     AVX_REQUIRE(ctx, d->streak_rows_host != nullptr && d->streak_stride >= 48, "avx_dichromat_u8: streak tables missing (stride >= 48)");
-    const size_t lds = sizeof(float) * (size_t)a.W * 3 * 2;
+    const int PW = ((a.W + 3) / 4 * 4) + 2 * 16;
+    const size_t lds = sizeof(float) * (size_t)PW * 6 + (((size_t)a.W * 3 + 15) & ~(size_t)15);
+    AVX_REQUIRE(ctx, ctx->coarse_n_fix[0] <= 2, "quantiser needs %d refinements, kernel built for 2", ctx->coarse_n_fix[0]);
+    QuantCoarse qc{ctx->d_coarse_f32, ctx->coarse_lo_key[0], ctx->coarse_n_keys[0], ctx->coarse_n_fix[0]};
     AVX_REQUIRE(ctx, lds <= 150 * 1024, "avx_dichromat_u8: frame width %d too large for the streak kernel (row must fit LDS)", a.W);
     const size_t tbytes = sizeof(float) * (size_t)a.H * d->streak_stride;
     if (tbytes > ws->row_gain_cap * sizeof(float)) {  // the per-row table shares the row-gain buffer
@@ -131,9 +190,9 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
     const long cap = (long)ctx->num_cus * 4;
     const int grid = (int)(rows < cap ? rows : cap);
     AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
-    hipLaunchKernelGGL(kmain, dim3(grid), dim3(kST), lds, s, a, st);
+    hipLaunchKernelGGL(kmain, dim3(grid), dim3(kST), lds, s, a, st, qc);
     AVX_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(kdark, dim3(grid), dim3(kST), lds, s, a, st);
+    hipLaunchKernelGGL(kdark, dim3(grid), dim3(kST), lds, s, a, st, qc);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
