@@ -49,6 +49,11 @@ struct avx_ctx {
     avx_ws ws[kMaxWorkspaces];
     int n_ws = 0;
     int num_cus = 256;
+    // Measured launch geometry of the marching kernels (dichromat_march.hip): rows-per-workgroup split that was
+    // fastest for (kernel configuration, batch, frame size), found by timing the candidates on the first call.
+    struct tuned { uint64_t key; int nchunks; };
+    tuned march_tuned[64] = {};
+    int n_march_tuned = 0;
 };
 
 int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...);

@@ -452,21 +452,69 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
     MarchGeom g{};
     g.nstrips = (a.W + C::SW - 1) / C::SW;
     g.sw = ((a.W + g.nstrips - 1) / g.nstrips + C::XPT - 1) / C::XPT * C::XPT;
-    // Chunks: one resident wave of equal workgroups when the batch allows it (no tail), else one
-    // chunk per (frame, strip); never shorter than 8*SY rows (priming costs 2R rows per chunk).
+    // Row chunks per (frame, strip).  The best split depends on how the workgroup count tiles the resident slots, the XCD
+    // round-robin and the priming cost (2R rows per chunk): measured, not modelled -- the first call for a (kernel
+    // configuration, batch, frame size) times a handful of candidates on the caller's own frames (the output does not
+    // depend on the split) and the winner is remembered in the context.  AVX_MARCH_CHUNKS pins it.
     const long resident = (long)ctx->num_cus * per_cu;
     const long cols = (long)a.n_frames * g.nstrips;
-    long nchunks = cols >= resident ? 1 : (resident + cols - 1) / cols;
+    const long max_chunks = a.H / (8 * SY) > 0 ? a.H / (8 * SY) : 1;  // never shorter than 8*SY rows
+    auto set_chunks = [&](long nc) {
+        if (nc > max_chunks) nc = max_chunks;
+        if (nc < 1) nc = 1;
+        g.ch = (int)(((a.H + nc - 1) / nc + SY - 1) / SY * SY);
+        g.nchunks = (a.H + g.ch - 1) / g.ch;
+        const long tot = cols * g.nchunks;
+        g.xcd_remap = (tot % 8 == 0) ? 1 : 0;
+        return tot;
+    };
+    long nchunks = cols >= resident ? 1 : (resident + cols - 1) / cols;  // fallback: one resident wave of equal workgroups
     const char* e = getenv("AVX_MARCH_CHUNKS");
-    if (e) nchunks = atol(e);
-    const long max_chunks = a.H / (8 * SY) > 0 ? a.H / (8 * SY) : 1;
-    if (nchunks > max_chunks) nchunks = max_chunks;
-    if (nchunks < 1) nchunks = 1;
-    g.ch = (int)(((a.H + nchunks - 1) / nchunks + SY - 1) / SY * SY);
-    g.nchunks = (a.H + g.ch - 1) / g.ch;
-    const long total = cols * g.nchunks;
+    const uint64_t tkey = ((uint64_t)(sizeof(T) == 8) << 63) | ((uint64_t)R << 56) | ((uint64_t)NG << 46) |
+                          ((uint64_t)(a.n_frames & 0xfff) << 32) | ((uint64_t)(a.H & 0xffff) << 16) | (uint64_t)(a.W & 0xffff);
+    if (e && *e) {
+        nchunks = atol(e);
+    } else {
+        int found = 0;
+        for (int i = 0; i < ctx->n_march_tuned; ++i)
+            if (ctx->march_tuned[i].key == tkey) { found = ctx->march_tuned[i].nchunks; break; }
+        if (!found && (size_t)a.n_frames * a.H * a.W >= (size_t)256 * 1024) {  // tiny launches: not worth timing
+            const long cand[] = {nchunks, 1, 2, 3, 4, 6, 8, 12, 16, 24};
+            float best_ms = 3.4e38f;
+            hipEvent_t e0, e1;
+            AVX_HIP(ctx, hipEventCreate(&e0));
+            AVX_HIP(ctx, hipEventCreate(&e1));
+            long tried[10];
+            int ntried = 0;
+            for (long nc : cand) {
+                if (nc > max_chunks) nc = max_chunks;
+                bool dup = false;
+                for (int i = 0; i < ntried; ++i) dup = dup || tried[i] == nc;
+                if (dup) continue;
+                tried[ntried++] = nc;
+                const long tot = set_chunks(nc);
+                if (tot >= (1L << 30)) continue;
+                float ms_min = 3.4e38f;
+                for (int rep = 0; rep < 2; ++rep) {  // second run: warm instruction cache / tables
+                    AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
+                    AVX_HIP(ctx, hipEventRecord(e0, s));
+                    hipLaunchKernelGGL(kmain, dim3((unsigned)tot), dim3(kMarchThreads), lds, s, a, taps, qc, g);
+                    AVX_HIP(ctx, hipEventRecord(e1, s));
+                    AVX_HIP(ctx, hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    AVX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+                    ms_min = ms < ms_min ? ms : ms_min;
+                }
+                if (ms_min < best_ms) { best_ms = ms_min; found = (int)nc; }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (found && ctx->n_march_tuned < 64) ctx->march_tuned[ctx->n_march_tuned++] = {tkey, found};
+        }
+        if (found) nchunks = found;
+    }
+    const long total = set_chunks(nchunks);
     AVX_REQUIRE(ctx, total < (1L << 30), "avx_dichromat_u8: too many workgroups");
-    g.xcd_remap = (total % 8 == 0) ? 1 : 0;
     if (getenv("AVX_STAMPS")) {
         if constexpr (R == 6 || R == 14) {
             auto kst = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, NG, MINW, NFIX, true>;

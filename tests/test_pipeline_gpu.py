@@ -75,3 +75,22 @@ def test_uv_species_stream_through_pipeline():
         op.close()
         for i, f in enumerate(frames):
             assert np.array_equal(got[i], split_compose(f, want[i]) if split else want[i]), (split, i)
+
+
+def test_baseline_config0_png_through_image_renderer(tmp_path, oracle):
+    """BASELINE.json configs[0]: dog.py on one 640x480 PNG via ImageRenderer (the reference's own CPU-runnable case),
+    here PNG -> get_image -> Dog().visualize on the device -> save PNG -> read back == the oracle's frame, bit for bit."""
+    from animal_vision_amd.animals import Dog
+    from animal_vision_amd.renderers import ImageRenderer
+    from animal_vision_amd.synthetic import noise_frame
+
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    ImageRenderer(save_to=src).render(noise_frame(0, 480, 640))
+    frame = ImageRenderer(src).get_image()
+    assert frame.shape == (480, 640, 3) and frame.dtype == np.uint8
+    base, out = Dog().visualize(frame)
+    assert base is frame
+    ImageRenderer(save_to=dst).render(out)
+    back = ImageRenderer(dst).get_image()
+    _, want = oracle.dichromat_visualize(oracle.DICHROMATS["dog"], frame)
+    assert np.array_equal(back, want)
