@@ -548,12 +548,8 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
 
 }  // namespace
 
-int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, hipStream_t s) {
+static int march_dispatch(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, bool ng64, hipStream_t s) {
     constexpr int NF = 2;
-    // 192-thread workgroups (5 per CU) for the float64 cat tail, 384-thread ones for float32 (A/B on MI355X:
-    // cat 70 vs 52-56 GP/s, wolf 94 vs 104); AVX_MARCH_NG=64|128 overrides for tuning.
-    bool ng64 = f64_cat;
-    { const char* e = getenv("AVX_MARCH_NG"); if (e && *e) ng64 = atoi(e) == 64; }
     const int w = f64_cat ? 1 : 0;
     AVX_REQUIRE(ctx, ctx->coarse_n_fix[w] <= NF, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[w], NF);
     QuantCoarse qc{f64_cat ? ctx->d_coarse_f64 : ctx->d_coarse_f32, ctx->coarse_lo_key[w], ctx->coarse_n_keys[w], ctx->coarse_n_fix[w]};
@@ -574,4 +570,37 @@ int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichrom
 #undef AVX_MARCH_F32
         default: return AVX_ERR_UNSUPPORTED;
     }
+}
+
+int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, hipStream_t s) {
+    // Workgroup width: 192 threads (NG = 64) or 384 (NG = 128).  Which is faster depends on the radius, the element type
+    // and the batch geometry (cat: 64; dog: 128; wolf at 1080p: 64 by 13 %), so like the row split it is measured on the
+    // first call per (radius, type, batch, frame size) and remembered.  AVX_MARCH_NG=64|128 pins it.
+    { const char* e = getenv("AVX_MARCH_NG"); if (e && *e) return march_dispatch(ctx, a, d, f64_cat, atoi(e) == 64, s); }
+    const uint64_t key = (1ull << 62) | ((uint64_t)f64_cat << 61) | ((uint64_t)a.r << 52) | ((uint64_t)(a.n_frames & 0xfff) << 32) |
+                         ((uint64_t)(a.H & 0xffff) << 16) | (uint64_t)(a.W & 0xffff);
+    for (int i = 0; i < ctx->n_march_tuned; ++i)
+        if (ctx->march_tuned[i].key == key) return march_dispatch(ctx, a, d, f64_cat, ctx->march_tuned[i].nchunks == 64, s);
+    if ((size_t)a.n_frames * a.H * a.W < (size_t)256 * 1024) return march_dispatch(ctx, a, d, f64_cat, f64_cat, s);  // tiny: defaults
+    hipEvent_t e0, e1;
+    AVX_HIP(ctx, hipEventCreate(&e0));
+    AVX_HIP(ctx, hipEventCreate(&e1));
+    float ms[2] = {3.4e38f, 3.4e38f};
+    int rc = AVX_OK;
+    for (int v = 0; v < 2 && rc == AVX_OK; ++v) {
+        const bool ng64 = v == 0;
+        rc = march_dispatch(ctx, a, d, f64_cat, ng64, s);  // first call: tunes its own row split
+        if (rc) break;
+        AVX_HIP(ctx, hipEventRecord(e0, s));
+        rc = march_dispatch(ctx, a, d, f64_cat, ng64, s);
+        AVX_HIP(ctx, hipEventRecord(e1, s));
+        AVX_HIP(ctx, hipEventSynchronize(e1));
+        AVX_HIP(ctx, hipEventElapsedTime(&ms[v], e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    const bool pick64 = ms[0] <= ms[1];
+    if (ctx->n_march_tuned < 64) ctx->march_tuned[ctx->n_march_tuned++] = {key, pick64 ? 64 : 128};
+    return march_dispatch(ctx, a, d, f64_cat, pick64, s);
 }
