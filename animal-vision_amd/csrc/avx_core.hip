@@ -133,6 +133,7 @@ int avx_init(int device, avx_ctx** out_ctx) {
         ctx->coarse_n_fix[which] = n_fix;
     }
 #undef INIT_HIP
+    avx_march_seed_tuned(ctx);
     *out_ctx = ctx;
     return AVX_OK;
 }

@@ -57,6 +57,7 @@ struct avx_ctx {
 };
 
 int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...);
+void avx_march_seed_tuned(avx_ctx* ctx);  // dichromat_march.hip: measured launch geometries of the standard workloads
 avx_ws* avx_workspace(avx_ctx* ctx, hipStream_t stream);  // find or create; NULL when all slots are taken
 int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes);
 

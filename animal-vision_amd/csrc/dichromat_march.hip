@@ -471,7 +471,7 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
     long nchunks = cols >= resident ? 1 : (resident + cols - 1) / cols;  // fallback: one resident wave of equal workgroups
     const char* e = getenv("AVX_MARCH_CHUNKS");
     const uint64_t tkey = ((uint64_t)(sizeof(T) == 8) << 63) | ((uint64_t)R << 56) | ((uint64_t)NG << 46) |
-                          ((uint64_t)(a.n_frames & 0xfff) << 32) | ((uint64_t)(a.H & 0xffff) << 16) | (uint64_t)(a.W & 0xffff);
+                          ((uint64_t)(a.n_frames & 0xfff) << 32) | ((uint64_t)(a.H & 0xffff) << 16) | (uint64_t)(a.W & 0xffff);  // == chunk_key()
     if (e && *e) {
         nchunks = atol(e);
     } else {
@@ -510,6 +510,7 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (found && ctx->n_march_tuned < 64) ctx->march_tuned[ctx->n_march_tuned++] = {tkey, found};
+            if (getenv("AVX_TUNE_LOG")) fprintf(stderr, "[avx tune] chunks: f64=%d R=%d NG=%d frames=%d H=%d W=%d -> %d (%.3f ms)\n", (int)(sizeof(T) == 8), R, NG, a.n_frames, a.H, a.W, found, best_ms);
         }
         if (found) nchunks = found;
     }
@@ -548,6 +549,32 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
 
 }  // namespace
 
+static uint64_t chunk_key(bool f64, int R, int NG, int frames, int H, int W) {
+    return ((uint64_t)f64 << 63) | ((uint64_t)R << 56) | ((uint64_t)NG << 46) | ((uint64_t)(frames & 0xfff) << 32) | ((uint64_t)(H & 0xffff) << 16) | (uint64_t)(W & 0xffff);
+}
+static uint64_t width_key(bool f64, int R, int frames, int H, int W) {
+    return (1ull << 62) | ((uint64_t)f64 << 61) | ((uint64_t)R << 52) | ((uint64_t)(frames & 0xfff) << 32) | ((uint64_t)(H & 0xffff) << 16) | (uint64_t)(W & 0xffff);
+}
+
+// Launch geometries measured on MI355X for the BASELINE.json workloads (tools/gpu_bench.sh with AVX_TUNE_LOG=1): these
+// shapes start tuned; any other (kernel, batch, frame size) is measured on its first call.
+void avx_march_seed_tuned(avx_ctx* ctx) {
+    static const struct { int f64, R, frames, H, W, NG, chunks; } kSeed[] = {
+        {1, 4, 32, 1080, 1920, 64, 12},   // cat 1080p (default bench)
+        {1, 4, 8, 2160, 3840, 64, 16},    // cat 4K
+        {0, 14, 32, 1080, 1920, 128, 1},  // dog 1080p
+        {0, 14, 8, 2160, 3840, 128, 8},   // dog 4K
+        {0, 6, 32, 1080, 1920, 64, 8},    // wolf 1080p
+        {0, 5, 32, 1080, 1920, 64, 8},    // lion / tiger 1080p
+        {0, 3, 32, 1080, 1920, 128, 4},   // squirrel 1080p
+    };
+    for (const auto& e : kSeed) {
+        if (ctx->n_march_tuned + 2 > 64) break;
+        ctx->march_tuned[ctx->n_march_tuned++] = {width_key(e.f64, e.R, e.frames, e.H, e.W), e.NG};
+        ctx->march_tuned[ctx->n_march_tuned++] = {chunk_key(e.f64, e.R, e.NG, e.frames, e.H, e.W), e.chunks};
+    }
+}
+
 static int march_dispatch(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, bool ng64, hipStream_t s) {
     constexpr int NF = 2;
     const int w = f64_cat ? 1 : 0;
@@ -577,8 +604,7 @@ int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichrom
     // and the batch geometry (cat: 64; dog: 128; wolf at 1080p: 64 by 13 %), so like the row split it is measured on the
     // first call per (radius, type, batch, frame size) and remembered.  AVX_MARCH_NG=64|128 pins it.
     { const char* e = getenv("AVX_MARCH_NG"); if (e && *e) return march_dispatch(ctx, a, d, f64_cat, atoi(e) == 64, s); }
-    const uint64_t key = (1ull << 62) | ((uint64_t)f64_cat << 61) | ((uint64_t)a.r << 52) | ((uint64_t)(a.n_frames & 0xfff) << 32) |
-                         ((uint64_t)(a.H & 0xffff) << 16) | (uint64_t)(a.W & 0xffff);
+    const uint64_t key = width_key(f64_cat, a.r, a.n_frames, a.H, a.W);
     for (int i = 0; i < ctx->n_march_tuned; ++i)
         if (ctx->march_tuned[i].key == key) return march_dispatch(ctx, a, d, f64_cat, ctx->march_tuned[i].nchunks == 64, s);
     if ((size_t)a.n_frames * a.H * a.W < (size_t)256 * 1024) return march_dispatch(ctx, a, d, f64_cat, f64_cat, s);  // tiny: defaults
@@ -602,5 +628,6 @@ int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichrom
     if (rc) return rc;
     const bool pick64 = ms[0] <= ms[1];
     if (ctx->n_march_tuned < 64) ctx->march_tuned[ctx->n_march_tuned++] = {key, pick64 ? 64 : 128};
+    if (getenv("AVX_TUNE_LOG")) fprintf(stderr, "[avx tune] width: f64=%d R=%d frames=%d H=%d W=%d -> NG=%d (%.3f vs %.3f ms)\n", (int)f64_cat, a.r, a.n_frames, a.H, a.W, pick64 ? 64 : 128, ms[0], ms[1]);
     return march_dispatch(ctx, a, d, f64_cat, pick64, s);
 }
