@@ -64,6 +64,7 @@ class HoneybeeDesc(ctypes.Structure):
         ("mapping", ctypes.c_int32),
         ("custom_matrix", ctypes.c_float * 9),
         ("mixed_alpha", ctypes.c_float),
+        ("out_float", ctypes.c_int32),
     ]
 
 

@@ -56,40 +56,51 @@ class HoneyBee(Animal):
         assert isinstance(image, np.ndarray), "Input must be a numpy ndarray."
         assert image.ndim == 3 and image.shape[2] == 3, "Input must be HxWx3 RGB."
         if image.dtype != np.uint8:
-            raise NotImplementedError(f"HoneyBee: device path implemented for uint8 frames, got {image.dtype}")
+            if not np.issubdtype(image.dtype, np.floating) or self.hsi_model is not None:
+                raise NotImplementedError(f"HoneyBee: device path implemented for uint8 and float frames, got {image.dtype}")
+            return image, self._visualize_staged(image, floats=True)
         op = self._operator()
         if self.hsi_model is not None:
             out = self.hsi_model.honeybee(image, op)
         elif self.hsi_downsample and 0.05 <= self.hsi_scale < 1.0:
-            out = self._visualize_downsampled(image)
+            out = self._visualize_staged(image, floats=False)
         else:
             out = op(image)
         return image, out
 
-    def _visualize_downsampled(self, image: np.ndarray) -> np.ndarray:
-        """honeybee.py:109-117: classic_rgb_to_hsi_scaled = INTER_AREA down -> lobes -> INTER_LINEAR up of the cube.
-        The three cone catches are linear in the cube, so they are taken at the reduced size and the 3-plane result is
-        upsampled (instead of 31 bands); the tail (adaptation, blur, map, encode) is the same device pipeline, fed
-        the catches as a 3-band cube with identity weights."""
+    def _visualize_staged(self, image: np.ndarray, floats: bool) -> np.ndarray:
+        """The routes the fused uint8 kernel does not take, as a recorded sequence of stage calls (planevm.py):
+        * `hsi_downsample` (honeybee.py:109-117): classic_rgb_to_hsi_scaled = INTER_AREA down -> lobes -> INTER_LINEAR up
+          of the cube.  The three cone catches are linear in the cube, so they are taken at the reduced size and the
+          3-plane result is upsampled (instead of 31 bands);
+        * float frames (to_float01's `max > 1.001` rule, float output = linear_to_srgb(clip(rgb_lin)).astype(dtype)).
+        The tail (adaptation, blur, map, encode) is the same device pipeline, fed the catches as a 3-band cube with
+        identity weights."""
         import ctypes
 
         from ..planevm import DeviceBackend, PlaneRef
-        from ..runtime import DeviceBuffer
 
-        plans = self.__dict__.setdefault("_ds_plans", {})
-        key = image.shape[:2]
+        down = self.hsi_downsample and 0.05 <= self.hsi_scale < 1.0
+        plans = self.__dict__.setdefault("_staged_plans", {})
+        key = (image.shape[0], image.shape[1], floats, down)
         hit = plans.get(key)
         if hit is None:
             if len(plans) >= 4:
                 plans.pop(next(iter(plans)))[0].close()
-            H, W = key
-            be = DeviceBackend(H, W)
-            img01 = be._alloc(4 * 3 * be.n)  # to_float01: byte / 255
-            for c in range(3):
-                be.store(be.load(PlaneRef(be.d_in, c, 3, "u8")) / 255.0, PlaneRef(img01, 4 * c, 3))
+            H, W = key[:2]
+            be = DeviceBackend(H, W, float_frames=floats)
+            img01 = be._alloc(4 * 3 * be.n)
+            if floats:  # uv_helpers.to_float01 (:15-23): /255 and clip only when the frame's maximum exceeds 1.001
+                y = [be.load(PlaneRef(be.d_in, 4 * c, 3)) for c in range(3)]
+                mx = be.max(be.maximum(be.maximum(y[0], y[1]), y[2]))
+                for c in range(3):
+                    be.store(be.where(mx > 1.001, be.clip01(y[c] / 255.0), y[c]), PlaneRef(img01, 4 * c, 3))
+            else:       # byte / 255
+                for c in range(3):
+                    be.store(be.load(PlaneRef(be.d_in, c, 3, "u8")) / 255.0, PlaneRef(img01, 4 * c, 3))
             be.lin_hwc = img01
             op = self._operator()
-            be.spectral_planes(self.lambdas, op.weights, self.hsi_scale, downsample=True)
+            be.spectral_planes(self.lambdas, op.weights, self.hsi_scale, downsample=down)
             be.flush()
             tail = HoneybeeOp(lambdas=self.lambdas, illuminant=self.E, curves=(self.UV_curve, self.Blue_curve, self.Green_curve),
                               reflectance=self.assume_hsi_is_reflectance, adaptation=self.adaptation, mapping_mode=self.mapping_mode,
@@ -97,12 +108,15 @@ class HoneyBee(Animal):
             tail.weights = np.eye(3, dtype=np.float32)
             tail.desc.bands = 3
             tail.desc.weights_host = tail.weights.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            tail.desc.out_float = 1 if floats else 0
             hit = (be, tail)
             plans[key] = hit
         be, tail = hit
         ctx = be.ctx
-        H, W = key
-        ctx.upload(np.ascontiguousarray(image), be.d_in)
+        H, W = key[:2]
+        dt = np.float32 if floats else np.uint8
+        ctx.upload(np.ascontiguousarray(image, dtype=dt), be.d_in)  # float64 frames: x.astype(float32), the reference's first step
         be.run_device()
         tail.run_device(None, be.d_out, 1, H, W, hsi_ptr=be.last_stack.ptr, hsi_layout=0, hsi_dtype=0)
-        return ctx.download(be.d_out, image.shape, np.uint8)
+        out = ctx.download(be.d_out, image.shape, dt)
+        return out.astype(image.dtype) if out.dtype != image.dtype else out

@@ -484,6 +484,7 @@ struct MapArgs {
     const double* pct;       // device: percentiles (mode-dependent)
     float eps; float M[9]; float alpha; float* mixed;  // mixed: 3 planes (mode 4, pass 1)
     const float* enc_thr; const uint8_t* coarse; uint32_t lo_key; int pass;
+    float* out_f;            // non-NULL: write float32 sRGB values instead of uint8 codes
 };
 
 __device__ __forceinline__ double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
@@ -577,7 +578,14 @@ __global__ __launch_bounds__(kT) void k_map_encode(MapArgs a) {
         }
         // honeybee.py:166-173: clip -> linear_to_srgb -> *255+0.5 -> uint8, as the threshold count
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.out[i * 3 + c] = (uint8_t)quantize_coarse<float, 2>(rgb[c], thr, coarse, a.lo_key);
+        for (int c = 0; c < 3; ++c) {
+            if (a.out_f) {  // float frames (honeybee.py:172-173): linear_to_srgb(clip(rgb_lin, 0, 1)).astype(dtype), uv_helpers.py:40-44
+                const float l = rgb[c] < 0.f ? 0.f : (rgb[c] > 1.f ? 1.f : rgb[c]);
+                a.out_f[i * 3 + c] = l <= 0.0031308f ? l * 12.92f : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f;
+            } else {
+                a.out[i * 3 + c] = (uint8_t)quantize_coarse<float, 2>(rgb[c], thr, coarse, a.lo_key);
+            }
+        }
     }
 }
 
@@ -909,7 +917,8 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
         if (debug_planes) AVX_HIP(ctx, hipMemcpyAsync(debug_planes + (size_t)f * 3 * n, ubg, sizeof(float) * 3 * n, hipMemcpyDeviceToDevice, s));
         // 6) percentiles the mapping needs, then map + encode
         MapArgs m{};
-        m.UBG = ubg; m.n = n; m.out = out; m.mode = d->mapping; m.pct = u.pct; m.eps = d->eps; m.alpha = d->mixed_alpha; m.mixed = aux;
+        m.UBG = ubg; m.n = n; m.out = out; m.mode = d->mapping;
+        m.out_f = d->out_float ? reinterpret_cast<float*>(out_hwc) + (size_t)f * n * 3 : nullptr; m.pct = u.pct; m.eps = d->eps; m.alpha = d->mixed_alpha; m.mixed = aux;
         for (int i = 0; i < 9; ++i) m.M[i] = d->custom_matrix[i];
         m.enc_thr = ctx->d_enc_thr_f32; m.coarse = ctx->d_coarse_f32; m.lo_key = ctx->coarse_lo_key[0]; m.pass = 0;
         if (d->mapping == 2) {

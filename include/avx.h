@@ -157,6 +157,8 @@ typedef struct avx_honeybee_desc {
     int32_t mapping;           /* AVX_MAP_*                                                                       */
     float custom_matrix[9];
     float mixed_alpha;         /* falsecolor_uv_mixed alpha (honeybee.py:162 passes 0.45)                          */
+    int32_t out_float;         /* 1: out_hwc is a float32 HxWx3 buffer receiving linear_to_srgb(clip(rgb_lin)) (the
+                                  reference's output for float frames, honeybee.py:172-173) instead of uint8 codes */
 } avx_honeybee_desc;
 
 /* debug_planes (optional, device, N x 3 x H*W floats): receives U,B,G after adaptation + blur. */

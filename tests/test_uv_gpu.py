@@ -137,6 +137,22 @@ def test_honeybee_downsample_vs_oracle_other_size(uv, oracle):
         _u8_close(out, oracle.honeybee_visualize(f, hsi_downsample=True, hsi_scale=0.1)[1], max_frac=5e-3)
 
 
+def test_honeybee_float_frames_vs_oracle(uv, oracle):
+    """Same-dtype contract: float32 in [0,1], float32 in [0,255], float64 frames."""
+    from animal_vision_amd.animals import HoneyBee
+    from animal_vision_amd.synthetic import structured_frame
+
+    u8 = structured_frame(1, 90, 121)
+    for mode in ("opponent", "falsecolor"):
+        bee = HoneyBee(mapping_mode=mode)
+        for frame in ((u8 / 255.0).astype(np.float32), u8.astype(np.float32), u8 / 255.0):
+            base, out = bee.visualize(frame)
+            want = oracle.honeybee_visualize(frame, mapping_mode=mode)[1]
+            assert base is frame and out.dtype == frame.dtype == want.dtype and out.shape == frame.shape
+            d = np.abs(out.astype(np.float64) - want.astype(np.float64))
+            assert float((d > 4e-3).mean()) <= 2e-3 and float(np.median(d)) < 2e-5, (mode, frame.dtype, float(d.max()))
+
+
 def test_honeybee_planes_and_1080p_vs_oracle(uv, oracle):
     from animal_vision_amd.animals import HoneyBee
     from animal_vision_amd.synthetic import structured_frame
