@@ -114,6 +114,8 @@ class MantisDesc(ctypes.Structure):
         ("yy_host", _fp),
         ("periph_radius", ctypes.c_float),
         ("periph_softness", ctypes.c_float),
+        ("lin_hwc_in", ctypes.c_void_p),
+        ("out_float", ctypes.c_int32),
     ]
 
 

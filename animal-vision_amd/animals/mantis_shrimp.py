@@ -173,10 +173,49 @@ class MantisShrimp(Animal):
         d, _keep = self._desc(H, W)
         ctx._check(lib.avx_mantis_u8(ctx._h, d_in.ptr, d_base.ptr, d_out.ptr, H, W, ctypes.byref(d), ctx._s(stream)))
 
+    def _visualize_float(self, image: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Float frames (same-dtype contract): to_float01's `max > 1.001` rule and srgb_to_linear run as a plane program
+        (a frame-wide reduction decides the /255), the fused stack takes the linear frame and writes float32 sRGB."""
+        from ..planevm import DeviceBackend, PlaneRef
+
+        plans = self.__dict__.setdefault("_float_plans", {})
+        key = image.shape[:2]
+        hit = plans.get(key)
+        if hit is None:
+            if len(plans) >= 4:
+                plans.pop(next(iter(plans)))[0].close()
+            H, W = key
+            be = DeviceBackend(H, W, float_frames=True)
+            lin = be._alloc(4 * 3 * be.n)
+            y = [be.load(PlaneRef(be.d_in, 4 * c, 3)) for c in range(3)]
+            mx = be.max(be.maximum(be.maximum(y[0], y[1]), y[2]))
+            a = 0.055
+            for c in range(3):
+                v = be.where(mx > 1.001, be.clip01(y[c] / 255.0), y[c])
+                be.store(be.where(v <= 0.04045, v / 12.92, ((v + a) / (1 + a)) ** 2.4), PlaneRef(lin, 4 * c, 3))
+            be.flush()
+            d0, keep = self._desc(H, W)
+            d = MantisDesc()  # a byte copy shares the host tables `keep` holds
+            ctypes.memmove(ctypes.byref(d), ctypes.byref(d0), ctypes.sizeof(MantisDesc))
+            d.lin_hwc_in, d.out_float = lin.ptr, 1
+            hit = (be, d, keep)
+            plans[key] = hit
+        be, d, _keep = hit
+        ctx = be.ctx
+        H, W = key
+        ctx.upload(np.ascontiguousarray(image, dtype=np.float32), be.d_in)
+        be.run_device()
+        ctx._check(lib.avx_mantis_u8(ctx._h, None, be.d_base.ptr, be.d_out.ptr, H, W, ctypes.byref(d), ctx._s(None)))
+        base = ctx.download(be.d_base, image.shape, np.float32, sync=False)
+        out = ctx.download(be.d_out, image.shape, np.float32)
+        return base.astype(image.dtype, copy=False), out.astype(image.dtype, copy=False)
+
     def visualize(self, image: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         assert isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] == 3
         if image.dtype != np.uint8:
-            raise NotImplementedError(f"MantisShrimp: device path implemented for uint8 frames, got {image.dtype}")
+            if not np.issubdtype(image.dtype, np.floating):
+                raise NotImplementedError(f"MantisShrimp: device path implemented for uint8 and float frames, got {image.dtype}")
+            return self._visualize_float(image)
         if self.ctx is None:
             self.ctx = get_context()
         ctx = self.ctx

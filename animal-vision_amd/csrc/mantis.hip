@@ -35,15 +35,21 @@ __global__ __launch_bounds__(kMT) void k_decode_lin(const uint8_t* __restrict__ 
 }
 
 // from_float01(linear_to_srgb(clip(x, 0, 1)), uint8) (mantis_shrimp.py:153,278) as the threshold count
+__device__ __forceinline__ float l2s_f(float l) {  // uv_helpers.linear_to_srgb (:40-44) of a value already clipped to [0,1]
+    return l <= 0.0031308f ? l * 12.92f : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f;
+}
+// out_f != NULL (float frames): from_float01(..., float dtype) = the float32 sRGB value itself
 __global__ __launch_bounds__(kMT) void k_encode_hwc(const float* __restrict__ in, size_t n3, const float* __restrict__ thr_g, const uint8_t* __restrict__ coarse_g,
-                                                    uint32_t lo_key, uint8_t* __restrict__ out) {
+                                                    uint32_t lo_key, uint8_t* __restrict__ out, float* __restrict__ out_f = nullptr) {
     __shared__ float thr[256];
     __shared__ uint8_t coarse[1024];
     for (int i = threadIdx.x; i < 256; i += kMT) thr[i] = thr_g[i];
     for (int i = threadIdx.x; i < 1024; i += kMT) coarse[i] = coarse_g[i];
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n3; i += (size_t)gridDim.x * kMT)
-        out[i] = (uint8_t)quantize_coarse<float, 2>(in[i], thr, coarse, lo_key);
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n3; i += (size_t)gridDim.x * kMT) {
+        if (out_f) out_f[i] = l2s_f(clip01f(in[i]));
+        else out[i] = (uint8_t)quantize_coarse<float, 2>(in[i], thr, coarse, lo_key);
+    }
 }
 
 // classic_rgb_to_hsi on an ALREADY-LINEAR float frame (quirk Q6: linearised again) folded with the K band-pass
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(kMT) void k_scan_gain(float* __restrict__ P, const 
 }
 
 struct FinishArgs { const float* P; const float* periph; int H, W; const float* xx; const float* yy; float softness, radius; int do_periph;
-                    const float* thr; const uint8_t* coarse; uint32_t lo_key; uint8_t* out; };
+                    const float* thr; const uint8_t* coarse; uint32_t lo_key; uint8_t* out; float* out_f; };
 // :268-278: radial sigmoid blend with the blurred copy, then encode
 __global__ __launch_bounds__(kMT) void k_finish(FinishArgs a) {
     __shared__ float thr[256];
@@ -213,7 +219,8 @@ __global__ __launch_bounds__(kMT) void k_finish(FinishArgs a) {
         for (int c = 0; c < 3; ++c) {
             float v = a.P[(size_t)c * n + p];
             if (a.do_periph) v = (1.0f - t) * v + t * a.periph[(size_t)c * n + p];
-            a.out[p * 3 + c] = (uint8_t)quantize_coarse<float, 2>(v, thr, coarse, a.lo_key);
+            if (a.out_f) a.out_f[p * 3 + c] = l2s_f(clip01f(v));
+            else a.out[p * 3 + c] = (uint8_t)quantize_coarse<float, 2>(v, thr, coarse, a.lo_key);
         }
     }
 }
@@ -351,7 +358,7 @@ extern "C" int avx_percentile_dev(avx_ctx* ctx, const float* data_dev, size_t n,
 extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_mantis_desc), "avx_mantis_u8: desc is NULL or struct_size mismatch");
-    AVX_REQUIRE(ctx, in_hwc && out_base_hwc && out_hwc && H > 0 && W > 0, "avx_mantis_u8: bad arguments");
+    AVX_REQUIRE(ctx, (in_hwc || d->lin_hwc_in) && out_base_hwc && out_hwc && H > 0 && W > 0, "avx_mantis_u8: bad arguments");
     AVX_REQUIRE(ctx, d->n_bands >= 1 && d->n_bands <= KMAX && d->band_matrix_host && d->band_lut_host, "avx_mantis_u8: bad band tables");
     AVX_REQUIRE(ctx, d->n_wavelengths >= 1 && d->lobe_gains_host && d->band_weights_host && d->lobe_denom > 0.f, "avx_mantis_u8: per-wavelength tables missing");
     AVX_REQUIRE(ctx, d->rows_host && d->xx_host && d->yy_host, "avx_mantis_u8: row/column tables missing");
@@ -389,16 +396,23 @@ extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_b
     AVX_HIP(ctx, hipMemcpyAsync(dxx, d->xx_host, sizeof(float) * W, hipMemcpyHostToDevice, s));
     AVX_HIP(ctx, hipMemcpyAsync(dyy, d->yy_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
     const int g = grid_for(ctx, n);
-    // 1) to_float01 + srgb_to_linear (:148-149)
-    hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, lin0);
+    // 1) to_float01 + srgb_to_linear (:148-149); float frames arrive already linearised (lin_hwc_in, built by the caller's
+    //    plane program: to_float01's max rule needs a frame-wide reduction)
+    const float* lin_src = d->lin_hwc_in;
+    if (!lin_src) {
+        hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, lin0);
+        lin_src = lin0;
+    }
     // 2) panorama warp (:152): INTER_CUBIC widen + centre crop
-    const float* baseline = lin0;
+    const float* baseline = lin_src;
     if (newW != W) {
-        if ((rc = avx_geom_panorama_cubic(ctx, lin0, H, W, newW, (newW - W) / 2, blin, s))) return rc;
+        if ((rc = avx_geom_panorama_cubic(ctx, lin_src, H, W, newW, (newW - W) / 2, blin, s))) return rc;
         baseline = blin;
     }
     (void)wide;
-    hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, baseline, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_base_hwc);
+    float* base_f = d->out_float ? reinterpret_cast<float*>(out_base_hwc) : nullptr;
+    float* out_f = d->out_float ? reinterpret_cast<float*>(out_hwc) : nullptr;
+    hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, baseline, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_base_hwc, base_f);
     // 3-4) RGB->HSI (optionally at reduced size) folded with the band windows -> HxWxK stack, safe_norm per band
     if (hs != H || wsm != W) {
         if ((rc = avx_resize_hwc(ctx, baseline, 0, H, W, 3, small, hs, wsm, 3, s))) return rc;
@@ -439,7 +453,7 @@ extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_b
     // 11-12) periphery + encode
     const int do_periph = d->periph_ksize > 0;
     if (do_periph) { if ((rc = avx_uv_plane_blur_device(ctx, P2, P0, 3, H, W, d->periph_ksize, d->periph_taps_host, s))) return rc; }
-    FinishArgs fa{P2, P0, H, W, dxx, dyy, d->periph_softness, d->periph_radius, do_periph, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_hwc};
+    FinishArgs fa{P2, P0, H, W, dxx, dyy, d->periph_softness, d->periph_radius, do_periph, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_hwc, out_f};
     hipLaunchKernelGGL(k_finish, dim3(g), dim3(kMT), 0, s, fa);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;

@@ -221,6 +221,9 @@ typedef struct avx_mantis_desc {
     int32_t periph_ksize; const double* periph_taps_host;
     const float* xx_host; const float* yy_host; /* W, H: linspace(-1, 1) (:270-271)                              */
     float periph_radius, periph_softness;
+    const float* lin_hwc_in;           /* optional (float frames): device H x W x 3 float32, already srgb_to_linear(to_float01(frame));
+                                          in_hwc is ignored then                                                        */
+    int32_t out_float;                 /* 1: both outputs are float32 H x W x 3 buffers holding the sRGB value (float frames) */
 } avx_mantis_desc;
 
 int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_baseline_hwc, uint8_t* out_hwc, int H, int W,

@@ -52,10 +52,25 @@ def test_mantis_vs_oracle(oracle, shape, kw):
     _check(out, wout, (shape, kw))
 
 
-def test_mantis_rejects_non_uint8_and_bad_panorama():
+def test_mantis_float_frames_vs_oracle(oracle):
+    """Same-dtype contract: float32 in [0,1], float32 in [0,255], float64 frames."""
+    from animal_vision_amd.animals import MantisShrimp
+
+    u8 = load_golden("mantis")["in_s64"]
+    sp = MantisShrimp()
+    for frame in ((u8 / 255.0).astype(np.float32), u8.astype(np.float32), u8 / 255.0):
+        base, out = sp.visualize(frame)
+        wbase, wout = oracle.mantis_visualize(frame)
+        assert base.dtype == out.dtype == frame.dtype == wout.dtype and out.shape == frame.shape
+        np.testing.assert_allclose(base, wbase, rtol=0, atol=2e-5)
+        d = np.abs(out.astype(np.float64) - wout.astype(np.float64))
+        assert float((d > 4e-3).mean()) <= 2e-3 and float(np.median(d)) < 2e-5, (frame.dtype, float(d.max()))
+
+
+def test_mantis_rejects_non_numeric_and_bad_panorama():
     from animal_vision_amd.animals import MantisShrimp
 
     with pytest.raises(NotImplementedError):
-        MantisShrimp().visualize(np.zeros((8, 8, 3), np.float32))
+        MantisShrimp().visualize(np.zeros((8, 8, 3), np.int32))
     with pytest.raises(ValueError):
         MantisShrimp(panorama_scale=0.8).visualize(np.zeros((16, 16, 3), np.uint8))
