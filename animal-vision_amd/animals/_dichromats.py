@@ -28,11 +28,55 @@ class _Dichromat(Animal):
     def visualize(self, image: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         assert check_input_image(image)  # dog.py:33
         if image.dtype != np.uint8:
-            # The reference tolerates float / wider-int frames (animal_utils.py:45-48); its video,
-            # webcam and image renderers only ever produce uint8 (video.py:95).  Not silently
-            # re-routed to a CPU path: say so.
-            raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 frames, got {image.dtype}")
+            # The reference tolerates float / wider-int frames (animal_utils.py:45-48); its video, webcam and image
+            # renderers only ever produce uint8 (video.py:95).  Float frames of the Gaussian / row-gain species run as a
+            # plane program; anything else is not silently re-routed to a CPU path: say so.
+            if np.issubdtype(image.dtype, np.floating) and self.SPEC.post in ("gauss", "scone", "none") and self.SPEC.color == "collapse":
+                return image, self._visualize_float(image)
+            raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 frames (and float frames of the "
+                                      f"Gaussian / row-gain species), got {image.dtype}")
         return image, self._operator()(image)
+
+    def _visualize_float(self, image: np.ndarray) -> np.ndarray:
+        """dog.py:37-59 for a float frame: get_normalized_image's `max > 1` rule (a frame-wide reduction), both transfer
+        functions as expressions, `px @ T.T`, cv2.GaussianBlur((0,0), sigma) or the S-cone row gain; float32 sRGB out."""
+        from ..dichromat import collapse_LMS_matrix, cv_auto_ksize, gaussian_taps, s_cone_row_gain
+        from ..planevm import DeviceBackend, PlaneRef
+
+        plans = self.__dict__.setdefault("_float_plans", {})
+        key = image.shape[:2]
+        be = plans.get(key)
+        if be is None:
+            if len(plans) >= 4:
+                plans.pop(next(iter(plans))).close()
+            H, W = key
+            sp = self.SPEC
+            be = DeviceBackend(H, W, float_frames=True)
+            y = [be.load(PlaneRef(be.d_in, 4 * c, 3)) for c in range(3)]
+            mx = be.max(be.maximum(be.maximum(y[0], y[1]), y[2]))
+            a = 0.055
+            lin = []
+            for c in range(3):  # get_normalized_image (animal_utils.py:41-50) + srgb_to_linear (:5-11)
+                x = be.clip01(be.where(mx > 1.0, y[c] / 255.0, y[c]))
+                lin.append(be.where(x <= 0.04045, x / 12.92, ((x + a) / (1 + a)) ** 2.4))
+            T = collapse_LMS_matrix(sp.alpha, sp.s_scale)  # float32 3x3; out_i = sum_j T[i][j] * in_j (dog.py:47)
+            rgb = [lin[0] * float(T[i, 0]) + lin[1] * float(T[i, 1]) + lin[2] * float(T[i, 2]) for i in range(3)]
+            if sp.post == "gauss":
+                k = cv_auto_ksize(sp.sigma)
+                rgb = be.blur_taps(rgb, k, gaussian_taps(k, sp.sigma))
+            elif sp.post == "scone":
+                s_top, s_bottom, power, boost = sp.scone
+                rgb = [rgb[0], rgb[1], be.clip01(rgb[2] * be.row(s_cone_row_gain(H, s_top, s_bottom, power=power, extra_boost=boost)))]
+            for c in range(3):  # np.clip(linear_to_srgb(np.clip(x, 0, 1)), 0, 1).astype(dtype)  (dog.py:54-59)
+                x = be.clip01(rgb[c])
+                be.store(be.clip01(be.where(x <= 0.0031308, 12.92 * x, (1 + a) * be.power(x, 1 / 2.4) - a)), PlaneRef(be.d_out, 4 * c, 3))
+            be.flush()
+            plans[key] = be
+        ctx = be.ctx
+        ctx.upload(np.ascontiguousarray(image, dtype=np.float32), be.d_in)
+        be.run_device()
+        out = ctx.download(be.d_out, image.shape, np.float32)
+        return out.astype(image.dtype, copy=False)
 
 
 def _mk(cls_name: str, spec: DichromatSpec, doc: str):

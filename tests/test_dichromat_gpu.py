@@ -133,3 +133,21 @@ def test_bad_arguments_raise(av):
         Dog().visualize(np.zeros((4, 4, 4), np.uint8))
     with pytest.raises(NotImplementedError):
         Dog().visualize(np.zeros((4, 4, 3), np.float32))
+
+
+@pytest.mark.parametrize("name", ["dog", "wolf", "rat", "squirrel"])
+def test_float_frames_gaussian_and_rowgain_species(av, oracle, name):
+    """Same-dtype contract for float frames: float32 in [0,1], float32 in [0,255], float64 (float pipeline:
+    1e-4, the transfer functions are evaluated with the device's powf)."""
+    from animal_vision_amd import animals
+    from animal_vision_amd.synthetic import structured_frame
+
+    u8 = structured_frame(3, 72, 100)
+    sp = getattr(animals, name.capitalize())()
+    for frame in ((u8 / 255.0).astype(np.float32), u8.astype(np.float32), u8 / 255.0):
+        base, out = sp.visualize(frame)
+        _, want = oracle.dichromat_visualize(oracle.DICHROMATS[name], frame)
+        assert base is frame and out.dtype == frame.dtype == want.dtype and out.shape == frame.shape
+        np.testing.assert_allclose(out, want, rtol=0, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        animals.Sheep().visualize((u8 / 255.0).astype(np.float32))
