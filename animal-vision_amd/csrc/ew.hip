@@ -5,7 +5,8 @@
 // vectors and of frame-wide scalars (min/max/mean/percentiles), with a Gaussian blur, a resize or a Sobel in
 // between.  Executed literally, every NumPy operator is one HBM round trip (8-12 B/px each, 100-200 of them per
 // frame).  Here a whole chain between two non-elementwise stages is ONE launch: the host lowers the chain to a short
-// register program (<= 384 instructions, 32 float32 registers per pixel), the kernel interprets it per pixel with
+// register program (<= 384 instructions, 32 float32 registers per pixel), the kernel interprets it per pixel (4 or 8
+// pixels per thread: one instruction dispatch serves 256 or 512 pixels per wave) with
 // wave-uniform control flow (the instruction stream lives in the kernel arguments, read through the scalar cache), the
 // per-pixel registers live in LDS ([reg][lane]: conflict-free), and the only HBM traffic is the planes the chain
 // really reads and the planes it really leaves behind.  Frame-wide reductions ride along as accumulator registers
@@ -16,6 +17,7 @@
 // reference's expression (-ffp-contract=off: nothing fuses); transcendental functions are the device's (1-2 ulp
 // from NumPy's): within 1e-4 relative of the reference, the UV path's bar.  uint8 encode = the exact threshold table.
 #include <cmath>
+#include <cstdlib>
 
 #include "dichromat_common.h"
 
@@ -24,7 +26,6 @@ using namespace avxk;
 namespace {
 
 constexpr int kET = 256;
-constexpr int PX = 4;  // pixels per thread: one instruction dispatch serves 4 x 64 pixels per wave
 
 struct EwArgs {
     avx_ew_insn insn[AVX_EW_MAX_INSN];
@@ -47,10 +48,12 @@ __device__ __forceinline__ float acc_merge(int kind, float a, float b) { return 
 // wave-uniform register numbers of the instruction through s_set_gpr_idx (no LDS, no scratch).  NREG = 16 leaves
 // room for 4 waves/SIMD, NREG = 32 for 2; the host picks the smallest that fits the program.
 #define EW_FOR for (int k = 0; k < PX; ++k)
+#define EW_RD(dst, idx) { dst[0] = R0[idx]; dst[1] = R1[idx]; dst[2] = R2[idx]; dst[3] = R3[idx]; if constexpr (PX == 8) { dst[4] = R4[idx]; dst[5] = R5[idx]; dst[6] = R6[idx]; dst[7] = R7[idx]; } }
+#define EW_WR(idx, src) { R0[idx] = src[0]; R1[idx] = src[1]; R2[idx] = src[2]; R3[idx] = src[3]; if constexpr (PX == 8) { R4[idx] = src[4]; R5[idx] = src[5]; R6[idx] = src[6]; R7[idx] = src[7]; } }
 #define EW_UN(expr) { _Pragma("unroll") EW_FOR { const float x = xs[k]; r[k] = (expr); } } break
 #define EW_BIN(expr) { _Pragma("unroll") EW_FOR { const float x = xs[k], y = ys[k]; r[k] = (expr); } } break
 
-template <int NREG>
+template <int NREG, int PX>
 __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
     __shared__ float thr[256];
     __shared__ uint8_t coarse[1024];
@@ -61,13 +64,16 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
         for (int i = tid; i < 1024; i += kET) coarse[i] = a.coarse[i];
         __syncthreads();
     }
-    float R0[NREG], R1[NREG], R2[NREG], R3[NREG];
+    float R0[NREG], R1[NREG], R2[NREG], R3[NREG], R4[NREG], R5[NREG], R6[NREG], R7[NREG];  // R4..R7 vanish when PX == 4
 #pragma unroll
-    for (int i = 0; i < NREG; ++i) { R0[i] = 0.f; R1[i] = 0.f; R2[i] = 0.f; R3[i] = 0.f; }
+    for (int i = 0; i < NREG; ++i) { R0[i] = 0.f; R1[i] = 0.f; R2[i] = 0.f; R3[i] = 0.f; R4[i] = 0.f; R5[i] = 0.f; R6[i] = 0.f; R7[i] = 0.f; }
     for (int k = 0; k < a.n_acc; ++k) {
         const float v = acc_init(a.acc_kind[k]);
         const int reg = a.acc_reg[k] & (NREG - 1);
-        R0[reg] = v; R1[reg] = v; R2[reg] = v; R3[reg] = v;
+        float vv[PX];
+#pragma unroll
+        EW_FOR vv[k] = v;
+        EW_WR(reg, vv);
     }
     const uint32_t n = (uint32_t)a.n, W = (uint32_t)a.W;  // the host checks H*W < 2^31
     for (uint32_t base = blockIdx.x * (kET * PX); base < n; base += gridDim.x * (kET * PX)) {
@@ -89,8 +95,11 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
             const int ra = in.a & (NREG - 1), rb = in.b & (NREG - 1), rd = in.dst & (NREG - 1);
             const float imm = __uint_as_float(in.imm);
             const bool ia = in.op & AVX_EW_IMM_A, ib = in.op & AVX_EW_IMM_B;  // an operand is the immediate constant
-            const float xs[PX] = {ia ? imm : R0[ra], ia ? imm : R1[ra], ia ? imm : R2[ra], ia ? imm : R3[ra]};
-            const float ys[PX] = {ib ? imm : R0[rb], ib ? imm : R1[rb], ib ? imm : R2[rb], ib ? imm : R3[rb]};
+            float xs[PX], ys[PX];
+            EW_RD(xs, ra);
+            EW_RD(ys, rb);
+#pragma unroll
+            EW_FOR { xs[k] = ia ? imm : xs[k]; ys[k] = ib ? imm : ys[k]; }
             float r[PX];
             switch (in.op & AVX_EW_OPCODE_MASK) {
                 case AVX_EW_CONST: { const float c = __uint_as_float(in.imm); _Pragma("unroll") EW_FOR r[k] = c; } break;
@@ -144,7 +153,8 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
                 case AVX_EW_NOT: EW_UN(x != 0.f ? 0.f : 1.f);
                 case AVX_EW_SELECT: {
                     const int rc = in.imm & (NREG - 1);
-                    const float zs[PX] = {R0[rc], R1[rc], R2[rc], R3[rc]};
+                    float zs[PX];
+                    EW_RD(zs, rc);
 #pragma unroll
                     EW_FOR r[k] = xs[k] != 0.f ? ys[k] : zs[k];
                     break;
@@ -152,14 +162,15 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
                 case AVX_EW_ACCMIN: case AVX_EW_ACCMAX: case AVX_EW_ACCSUM: {
                     const int opc = in.op & AVX_EW_OPCODE_MASK;
                     const int kind = opc == AVX_EW_ACCMIN ? AVX_EW_ACC_MIN : (opc == AVX_EW_ACCMAX ? AVX_EW_ACC_MAX : AVX_EW_ACC_SUM);
-                    const float cur[PX] = {R0[rd], R1[rd], R2[rd], R3[rd]};
+                    float cur[PX];
+                    EW_RD(cur, rd);
 #pragma unroll
                     EW_FOR r[k] = valid[k] ? acc_merge(kind, cur[k], xs[k]) : cur[k];
                     break;
                 }
                 default: { _Pragma("unroll") EW_FOR r[k] = 0.f; } break;
             }
-            R0[rd] = r[0]; R1[rd] = r[1]; R2[rd] = r[2]; R3[rd] = r[3];
+            EW_WR(rd, r);
         }
     }
     // block-level reduction of the accumulators -> partial[block][k]; the last workgroup to finish (ticket) folds the
@@ -171,7 +182,11 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
     __shared__ int is_last;
     for (int k = 0; k < a.n_acc; ++k) {
         const int kind = a.acc_kind[k], reg = a.acc_reg[k] & (NREG - 1);
-        float v = acc_merge(kind, acc_merge(kind, R0[reg], R1[reg]), acc_merge(kind, R2[reg], R3[reg]));
+        float fin[PX];
+        EW_RD(fin, reg);
+        float v = fin[0];
+#pragma unroll
+        for (int q = 1; q < PX; ++q) v = acc_merge(kind, v, fin[q]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = acc_merge(kind, v, __shfl_xor(v, o));
         __syncthreads();
@@ -279,7 +294,8 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
         a.acc_out_kind[k] = (uint8_t)kind; a.acc_slot[k] = slot;
     }
     // programs with reductions: fewer, fatter workgroups (the last one folds gridDim partials per accumulator)
-    const size_t want = (a.n + kET * PX - 1) / (kET * PX), cap = (size_t)ctx->num_cus * (p->n_acc ? 4 : 8);
+    const int px = (max_reg < 16 && a.n >= (size_t)1 << 20 && !getenv("AVX_EW_PX4")) ? 8 : 4;  // big frames, small programs: 8 pixels per thread
+    const size_t want = (a.n + (size_t)kET * px - 1) / ((size_t)kET * px), cap = (size_t)ctx->num_cus * (p->n_acc ? 4 : 8);
     const int grid = (int)(want < cap ? want : cap);
     if (p->n_acc && ws->d_ew == nullptr) {  // per-block partials + the ticket (zero at rest)
         const size_t full = (size_t)ctx->num_cus * 8 * AVX_EW_MAX_ACC * sizeof(float) + 256;
@@ -289,8 +305,9 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
     }
     a.scalars = p->scalars_dev; a.partial = (float*)ws->d_ew + 64; a.ticket = (uint32_t*)ws->d_ew; a.scalars_out = p->scalars_dev;
     a.lut = ctx->d_decode_lut; a.thr = ctx->d_enc_thr_f32; a.coarse = ctx->d_coarse_f32; a.lo_key = ctx->coarse_lo_key[0];
-    if (max_reg < 16) hipLaunchKernelGGL(k_ew<16>, dim3(grid), dim3(kET), 0, s, a);
-    else hipLaunchKernelGGL(k_ew<32>, dim3(grid), dim3(kET), 0, s, a);
+    if (max_reg < 16 && px == 8) hipLaunchKernelGGL((k_ew<16, 8>), dim3(grid), dim3(kET), 0, s, a);
+    else if (max_reg < 16) hipLaunchKernelGGL((k_ew<16, 4>), dim3(grid), dim3(kET), 0, s, a);
+    else hipLaunchKernelGGL((k_ew<32, 4>), dim3(grid), dim3(kET), 0, s, a);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
