@@ -131,8 +131,12 @@ def test_bad_arguments_raise(av):
         Dog().visualize(np.zeros((4, 4), np.uint8))
     with pytest.raises(AssertionError):
         Dog().visualize(np.zeros((4, 4, 4), np.uint8))
-    with pytest.raises(NotImplementedError):
-        Dog().visualize(np.zeros((4, 4, 3), np.float32))
+    with pytest.raises(NotImplementedError):  # wider integers: not a device path (the reference's renderers never produce them)
+        Dog().visualize(np.zeros((4, 4, 3), np.int32))
+    from animal_vision_amd.animals import Cat
+
+    with pytest.raises(NotImplementedError):  # float frames: Gaussian / row-gain species only
+        Cat().visualize(np.zeros((4, 4, 3), np.float32))
 
 
 @pytest.mark.parametrize("name", ["dog", "wolf", "rat", "squirrel"])
