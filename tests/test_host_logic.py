@@ -91,6 +91,26 @@ def test_reference_module_names_importable():
         assert hasattr(inst, "visualize")
 
 
+def test_uv_species_modules_and_constructors_match_reference_registry():
+    """Module and class names of the 16 UV species (animals/__init__.py:22-32 plus the modules utils.py imports), all
+    constructible without arguments and exposing the reference's constructor attributes."""
+    import importlib
+
+    from animal_vision_amd import animals
+
+    names = {"honeybee": "HoneyBee", "mantis_shrimp": "MantisShrimp", "reindeer": "Reindeer", "rat_uv": "RatUV", "goldfish": "Goldfish",
+             "damselfish": "Damselfish", "anableps": "Anableps", "anchovy": "Anchovy", "guppy": "Guppy", "morpho": "Morpho",
+             "heliconius": "Heliconius", "pieris": "Pieris", "hummingbird": "Hummingbird", "kestrel": "Kestrel",
+             "jumping_spider": "JumpingSpider", "dragonfly": "Dragonfly"}
+    for mod, cls in names.items():
+        m = importlib.import_module(f"animal_vision_amd.animals.{mod}")
+        inst = getattr(m, cls)()
+        assert getattr(animals, cls) is getattr(m, cls) and hasattr(inst, "visualize")
+        if mod not in ("honeybee",):
+            assert hasattr(inst, "hsi_scale") and hasattr(inst, "panorama_scale") and inst.lambdas.ndim == 1
+    assert set(animals.UV_CLASS) == set(names) - {"honeybee", "mantis_shrimp"}
+
+
 # ---- UV / spectral host tables (product code in animal_vision_amd/uv.py) vs reference goldens ----------
 def test_uv_host_tables_match_reference():
     from animal_vision_amd import uv
