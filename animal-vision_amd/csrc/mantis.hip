@@ -374,14 +374,14 @@ extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_b
     // scratch layout (floats)
     size_t off = 0;
     auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 63) & ~(size_t)63; return o; };
-    const size_t o_lin0 = take(3 * n), o_wide = take(3 * (size_t)H * newW), o_base = take(3 * n), o_small = take(3 * nsmall), o_sstack = take(nsmall * K),
+    const size_t o_lin0 = take(3 * n), o_base = take(3 * n), o_small = take(3 * nsmall), o_sstack = take(nsmall * K),
                  o_stack = take(n * K), o_bar = take(3 * n), o_broad = take(n), o_gx = take(n), o_gy = take(n), o_gain = take(n), o_P0 = take(3 * n),
                  o_P1 = take(3 * n), o_P2 = take(3 * n), o_rows = take(n), o_rowsb = take(n), o_tab = take((size_t)K * 3 + H + W + H + (size_t)d->n_wavelengths * (3 + K) + 64),
                  o_part = take((size_t)ctx->num_cus * 16 * K * 2 + 64), o_mm = take(2 * KMAX + 64), o_pct = take(64);
     int rc = avx_ensure_scratch(ctx, ws, off * sizeof(float));
     if (rc) return rc;
     float* base = (float*)ws->d_scratch;
-    float *lin0 = base + o_lin0, *wide = base + o_wide, *blin = base + o_base, *small = base + o_small, *sstack = base + o_sstack, *stack = base + o_stack,
+    float *lin0 = base + o_lin0, *blin = base + o_base, *small = base + o_small, *sstack = base + o_sstack, *stack = base + o_stack,
           *bar = base + o_bar, *broad = base + o_broad, *gx = base + o_gx, *gy = base + o_gy, *gain = base + o_gain, *P0 = base + o_P0, *P1 = base + o_P1,
           *P2 = base + o_P2, *rowsp = base + o_rows, *rowsb = base + o_rowsb, *tab = base + o_tab;
     float2* part = (float2*)(base + o_part);
@@ -409,7 +409,6 @@ extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_b
         if ((rc = avx_geom_panorama_cubic(ctx, lin_src, H, W, newW, (newW - W) / 2, blin, s))) return rc;
         baseline = blin;
     }
-    (void)wide;
     float* base_f = d->out_float ? reinterpret_cast<float*>(out_base_hwc) : nullptr;
     float* out_f = d->out_float ? reinterpret_cast<float*>(out_hwc) : nullptr;
     hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, baseline, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_base_hwc, base_f);
