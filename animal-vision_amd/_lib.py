@@ -227,6 +227,7 @@ _SIGS = {
     "avx_spectral_integrate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "avx_plane_stats": (_i, [_vp, _vp, _i, _sz, _i, ctypes.c_float, _vp, _vp]),
     "avx_planes_gaussian_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "avx_streak_planes_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "avx_rgb_to_hsi_lobes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_float, _vp, _vp]),
     "avx_honeybee_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(HoneybeeDesc), _vp, _vp]),
     "avx_uv_front_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -31,10 +31,10 @@ class _Dichromat(Animal):
             # The reference tolerates float / wider-int frames (animal_utils.py:45-48); its video, webcam and image
             # renderers only ever produce uint8 (video.py:95).  Float frames of the Gaussian / row-gain species run as a
             # plane program; anything else is not silently re-routed to a CPU path: say so.
-            if np.issubdtype(image.dtype, np.floating) and self.SPEC.post in ("gauss", "scone", "none") and self.SPEC.color == "collapse":
+            if np.issubdtype(image.dtype, np.floating) and self.SPEC.color == "collapse":
                 return image, self._visualize_float(image)
             raise NotImplementedError(f"{type(self).__name__}: device path implemented for uint8 frames (and float frames of the "
-                                      f"Gaussian / row-gain species), got {image.dtype}")
+                                      f"collapse-matrix species), got {image.dtype}")
         return image, self._operator()(image)
 
     def _visualize_float(self, image: np.ndarray) -> np.ndarray:
@@ -67,6 +67,12 @@ class _Dichromat(Animal):
             elif sp.post == "scone":
                 s_top, s_bottom, power, boost = sp.scone
                 rgb = [rgb[0], rgb[1], be.clip01(rgb[2] * be.row(s_cone_row_gain(H, s_top, s_bottom, power=power, extra_boost=boost)))]
+            elif sp.post == "streak":  # animal_utils.py:147-172 as coded (Q3); the float32 frame is blurred in place (Q4)
+                rgb = be.streak(rgb, sp.streak)
+            if sp.chroma is not None:  # apply_chroma_compression (animal_utils.py:174-181), where its result is used
+                gray = ((rgb[0] + rgb[1]) + rgb[2]) / 3.0
+                keep = float(np.float32(1.0 - sp.chroma))
+                rgb = [gray + (v - gray) * keep for v in rgb]
             for c in range(3):  # np.clip(linear_to_srgb(np.clip(x, 0, 1)), 0, 1).astype(dtype)  (dog.py:54-59)
                 x = be.clip01(rgb[c])
                 be.store(be.clip01(be.where(x <= 0.0031308, 12.92 * x, (1 + a) * be.power(x, 1 / 2.4) - a)), PlaneRef(be.d_out, 4 * c, 3))

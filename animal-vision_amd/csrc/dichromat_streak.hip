@@ -26,6 +26,8 @@ constexpr int kST = 256;
 struct StreakArgs {
     const float* rows;  // device: H x stride floats: [0]=k1, [1]=k2, [2..2+13) taps1, [15..15+33) taps2
     int stride;
+    const float* pin;   // PLANES instantiation: 3 x H x W float32 planes in / out (linear light, after the colour stage)
+    float* pout;
 };
 
 // v2 schedule (the arithmetic is unchanged: same FMA chains, same order).  One workgroup per image row:
@@ -71,7 +73,9 @@ __device__ __forceinline__ void streak_fill_halo(float* buf, int W, int PW, int 
     }
 }
 
-template <bool DARK>
+// PLANES = true is the float-frame form (avx_streak_planes_f32): the same row passes between float32 planes, with the
+// transfer functions and the chroma step left to the caller's plane program.
+template <bool DARK, bool PLANES = false>
 __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, StreakArgs st, QuantCoarse qc) {
     extern __shared__ __align__(16) float smem_f[];
     const int W = a.W, n3 = a.W * 3;
@@ -85,14 +89,18 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
     __shared__ float t1[16], td1[20], td2[20];
     __shared__ int idx1[3][16];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 256; i += kST) { lut[i] = a.decode_lut[i]; thr[i] = reinterpret_cast<const float*>(a.enc_thr)[i]; }
-    for (int i = tid; i < 1024; i += kST) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
+    if constexpr (!PLANES) {
+        for (int i = tid; i < 256; i += kST) { lut[i] = a.decode_lut[i]; thr[i] = reinterpret_cast<const float*>(a.enc_thr)[i]; }
+        for (int i = tid; i < 1024; i += kST) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
+    }
     const size_t frame_bytes = (size_t)a.H * a.W * 3;
     const int total_rows = a.n_frames * a.H;
     for (int gr = blockIdx.x; gr < total_rows; gr += gridDim.x) {
         const int f = gr / a.H, y = gr - f * a.H;
         __syncthreads();  // tables and buffers of the previous row are no longer read
-        if (DARK && a.flags[f] != 0u) continue;
+        if constexpr (!PLANES) {
+            if (DARK && a.flags[f] != 0u) continue;
+        }
         const float* rt = st.rows + (size_t)y * st.stride;
         const int k1 = (int)rt[0], k2 = (int)rt[1];
         const int r1 = k1 / 2, r2 = k2 / 2;
@@ -103,6 +111,13 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
         uint8_t* dst = a.out + frame_bytes * f + (size_t)y * n3;
         // ---- decode + colour stage -> buf0 planes -----------------------------------------------------
         uint32_t seen = 0;
+        if constexpr (PLANES) {
+            const size_t plane = (size_t)a.H * W;
+            for (int x = tid; x < W; x += kST) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) buf0[(size_t)c * PW + kPad + x] = st.pin[c * plane + (size_t)y * W + x];
+            }
+        } else
         for (int x = tid; x < W; x += kST) {
             const uint32_t b0 = src[3 * x], b1 = src[3 * x + 1], b2 = src[3 * x + 2];
             seen |= (b0 | b1 | b2) >> 1;
@@ -113,7 +128,9 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
             buf0[PW + kPad + x] = fma_t(c2, a.M[5], fma_t(c1, a.M[4], c0 * a.M[3]));
             buf0[2 * PW + kPad + x] = fma_t(c2, a.M[8], fma_t(c1, a.M[7], c0 * a.M[6]));
         }
-        if (!DARK && seen) a.flags[f] = 1u;
+        if constexpr (!PLANES) {
+            if (!DARK && seen) a.flags[f] = 1u;
+        }
         __syncthreads();
         // ---- pass 1, "row" direction = across the 3 channels (width 3, reflect-101) -> buf1 planes --------
         for (int x = tid; x < W; x += kST) {
@@ -142,6 +159,14 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
         else if (r2 <= 12) streak_along_row<12>(buf0, buf1, W, PW, td2, tid);
         else streak_along_row<16>(buf0, buf1, W, PW, td2, tid);
         __syncthreads();
+        if constexpr (PLANES) {
+            const size_t plane = (size_t)a.H * W;
+            for (int x = tid; x < W; x += kST) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st.pout[c * plane + (size_t)y * W + x] = buf1[(size_t)c * PW + kPad + x];
+            }
+            continue;
+        }
         // ---- chroma compression (rabbit, panda), quantise -> staged bytes -----------------------------------
         for (int x = tid; x < W; x += kST) {
             float v[3] = {buf1[kPad + x], buf1[PW + kPad + x], buf1[2 * PW + kPad + x]};
@@ -181,7 +206,7 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
         ws->row_gain_cap = tbytes / sizeof(float);
     }
     AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, d->streak_rows_host, tbytes, hipMemcpyHostToDevice, s));
-    StreakArgs st{ws->d_row_gain, d->streak_stride};
+    StreakArgs st{ws->d_row_gain, d->streak_stride, nullptr, nullptr};
     auto kmain = dichromat_streak_kernel<false>;
     auto kdark = dichromat_streak_kernel<true>;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kmain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -193,6 +218,38 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
     hipLaunchKernelGGL(kmain, dim3(grid), dim3(kST), lds, s, a, st, qc);
     AVX_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(kdark, dim3(grid), dim3(kST), lds, s, a, st, qc);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+// The streak blur alone, between float32 planes (float frames of the streak species; same row kernels and FMA order).
+extern "C" int avx_streak_planes_f32(avx_ctx* ctx, const float* src_planes, float* dst_planes, int H, int W, const float* rows_host,
+                                     int stride, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, src_planes && dst_planes && rows_host && H > 0 && W > 0 && stride >= 48, "avx_streak_planes_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    avx_ws* ws = avx_workspace(ctx, s);
+    AVX_REQUIRE(ctx, ws != nullptr, "avx_streak_planes_f32: no workspace for this stream");
+    const int PW = ((W + 3) / 4 * 4) + 2 * 16;
+    const size_t lds = sizeof(float) * (size_t)PW * 6 + (((size_t)W * 3 + 15) & ~(size_t)15);
+    AVX_REQUIRE(ctx, lds <= 150 * 1024, "avx_streak_planes_f32: frame width %d too large (a row must fit LDS)", W);
+    const size_t tbytes = sizeof(float) * (size_t)H * stride;
+    if (tbytes > ws->row_gain_cap * sizeof(float)) {
+        if (ws->d_row_gain) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_row_gain)); }
+        ws->d_row_gain = nullptr;
+        ws->row_gain_cap = 0;
+        AVX_HIP(ctx, hipMalloc((void**)&ws->d_row_gain, tbytes));
+        ws->row_gain_cap = tbytes / sizeof(float);
+    }
+    AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, rows_host, tbytes, hipMemcpyHostToDevice, s));
+    DichromatArgs a{};
+    a.H = H; a.W = W; a.n_frames = 1;
+    StreakArgs st{ws->d_row_gain, stride, src_planes, dst_planes};
+    QuantCoarse qc{};
+    auto k = dichromat_streak_kernel<false, true>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long cap = (long)ctx->num_cus * 4;
+    hipLaunchKernelGGL(k, dim3((unsigned)(H < cap ? H : cap)), dim3(kST), lds, s, a, st, qc);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -503,6 +503,21 @@ class DeviceBackend:
         self._call(lambda s: ctx._check(lib.avx_planes_gaussian_blur(ctx._h, src, dst, K, H, W, int(ksize), tp, 0, s)))
         return [self.load(r) for r in out]
 
+    def streak(self, vals: Sequence, params) -> List[Val]:
+        """apply_anisotropic_acuity_blur_with_streak(stack(vals), *params) (animal_utils.py:147-172, quirk Q3) on the three
+        planes of a linear-light frame; params = (y_center, sigma_streak, sigma_far, falloff)."""
+        from .dichromat import STREAK_STRIDE, streak_row_tables
+
+        assert len(vals) == 3
+        src, _ = self._contiguous(vals)
+        out = self.new_planes(3)
+        rows = np.ascontiguousarray(streak_row_tables(self.H, *params), dtype=np.float32)
+        self._keep.append(rows)
+        ctx, H, W, dst = self.ctx, self.H, self.W, out[0].ptr
+        rp = rows.ctypes.data_as(ctypes.c_void_p)
+        self._call(lambda s: ctx._check(lib.avx_streak_planes_f32(ctx._h, src, dst, H, W, rp, STREAK_STRIDE, s)))
+        return [self.load(r) for r in out]
+
     def blur(self, vals: Sequence, sigma: float) -> List[Val]:
         """uv_helpers.gaussian_blur (:66-73) per plane: identity for sigma <= 0, ksize = 2*ceil(3 sigma)+1."""
         if sigma <= 0:

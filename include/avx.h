@@ -133,6 +133,12 @@ int avx_plane_stats(avx_ctx* ctx, const float* planes, int K, size_t n, int adap
 int avx_planes_gaussian_blur(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize,
                              const double* taps_host, int scale_mode, void* stream);
 
+/* apply_anisotropic_acuity_blur_with_streak (animals/animal_utils.py:147-172, as coded: quirk Q3) on three float32
+ * planes of linear light (3 x H x W in, 3 x H x W out): the float-frame form of the streak species; uint8 frames take
+ * the fused avx_dichromat_u8.  rows_host: H x stride floats per image row [k1, k2, 13 taps(sigma_x), 33 taps(sigma_y)]. */
+int avx_streak_planes_f32(avx_ctx* ctx, const float* src_planes, float* dst_planes, int H, int W, const float* rows_host,
+                          int stride, void* stream);
+
 /* classic_rgb_to_hsi analytic branch (ml/classic_rgb_to_hsi/classic_rgb_to_hsi.py:47-82): HxWx3 frame (uint8, or
  * float32 that is linearised as coded) -> HxWxB float32 cube.  gains_host: B x 3 lobe gains in input-channel
  * order (quirk Q5), denom: mean lobe sum + 1e-8. */

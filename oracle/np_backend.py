@@ -84,6 +84,12 @@ class NumpyBackend:
         return out
 
     @staticmethod
+    def streak(vals: Sequence, params):
+        img = np.ascontiguousarray(np.stack(vals, axis=-1), dtype=np.float32)
+        out = O.apply_anisotropic_acuity_blur_with_streak(img, *params)
+        return [out[..., c] for c in range(3)]
+
+    @staticmethod
     def sobel(v):
         v = np.ascontiguousarray(v, dtype=np.float32)
         return O.cv_sobel3(v, 1, 0), O.cv_sobel3(v, 0, 1)

@@ -135,14 +135,14 @@ def test_bad_arguments_raise(av):
         Dog().visualize(np.zeros((4, 4, 3), np.int32))
     from animal_vision_amd.animals import Cat
 
-    with pytest.raises(NotImplementedError):  # float frames: Gaussian / row-gain species only
+    with pytest.raises(NotImplementedError):  # float frames: the collapse-matrix species only (Cat's tail is float64)
         Cat().visualize(np.zeros((4, 4, 3), np.float32))
 
 
-@pytest.mark.parametrize("name", ["dog", "wolf", "rat", "squirrel"])
-def test_float_frames_gaussian_and_rowgain_species(av, oracle, name):
+@pytest.mark.parametrize("name", ["dog", "wolf", "rat", "squirrel", "sheep", "pig", "rabbit", "panda", "kangaroo"])
+def test_float_frames_collapse_matrix_species(av, oracle, name):
     """Same-dtype contract for float frames: float32 in [0,1], float32 in [0,255], float64 (float pipeline:
-    1e-4, the transfer functions are evaluated with the device's powf)."""
+    1e-4, the transfer functions are evaluated with the device's powf).  Gaussian, row-gain and streak species."""
     from animal_vision_amd import animals
     from animal_vision_amd.synthetic import structured_frame
 
@@ -153,5 +153,3 @@ def test_float_frames_gaussian_and_rowgain_species(av, oracle, name):
         _, want = oracle.dichromat_visualize(oracle.DICHROMATS[name], frame)
         assert base is frame and out.dtype == frame.dtype == want.dtype and out.shape == frame.shape
         np.testing.assert_allclose(out, want, rtol=0, atol=1e-4)
-    with pytest.raises(NotImplementedError):
-        animals.Sheep().visualize((u8 / 255.0).astype(np.float32))
