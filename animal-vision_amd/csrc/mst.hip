@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kMT) void k_dwconv3x3(const T* __restrict__ x, cons
 // loads + 36 LDS weight reads for 4 channels).  float32 accumulation, exact-erf GELU.
 constexpr int kDwR = 4;
 __global__ __launch_bounds__(kMT) void k_dwconv3x3_h8(const __half* __restrict__ x, const float* __restrict__ w_g /*[C][9]*/, __half* __restrict__ y, int B, int H,
-                                                     int W, int C, int gelu) {
+                                                     int W, int C, int gelu, const __half* __restrict__ res /*same shape as y, or NULL*/,
+                                                     const float* __restrict__ bias /*[C] or NULL*/) {
     const int CV = C / 8;
     const int cg = (int)(((size_t)blockIdx.x * kMT + threadIdx.x) % CV);  // fixed per thread: grid stride is a multiple of CV
     float wt[9][8];
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(kMT) void k_dwconv3x3_h8(const __half* __restrict__
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int v = 0; v < 8; ++v) wt[t][v] = w_g[(size_t)(cg * 8 + v) * 9 + t];
+    float bs[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) bs[v] = bias ? bias[cg * 8 + v] : 0.f;
     const int strips = (H + kDwR - 1) / kDwR;
     const size_t total = (size_t)B * strips * W * CV;
     for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < total; i += (size_t)gridDim.x * kMT) {
@@ -249,13 +253,18 @@ __global__ __launch_bounds__(kMT) void k_dwconv3x3_h8(const __half* __restrict__
             const int yo = y0 + r;
             if (yo >= H) break;
             __half2 o[4];
+            const size_t off = ((b * H + yo) * (size_t)W + xw) * C + (size_t)cg * 8;
+            uint4 rraw = make_uint4(0, 0, 0, 0);
+            if (res) rraw = *reinterpret_cast<const uint4*>(res + off);
+            const __half2* rp = reinterpret_cast<const __half2*>(&rraw);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float a0 = acc[r][2 * q], a1 = acc[r][2 * q + 1];
                 if (gelu) { a0 = gelu_erf_h(a0); a1 = gelu_erf_h(a1); }
-                o[q] = __floats2half2_rn(a0, a1);
+                const float2 rr = __half22float2(rp[q]);  // epilogue: + residual + per-channel bias (both optional, zero when absent)
+                o[q] = __floats2half2_rn(a0 + rr.x + bs[2 * q], a1 + rr.y + bs[2 * q + 1]);
             }
-            *reinterpret_cast<uint4*>(y + ((b * H + yo) * (size_t)W + xw) * C + (size_t)cg * 8) = *reinterpret_cast<const uint4*>(o);
+            *reinterpret_cast<uint4*>(y + off) = *reinterpret_cast<const uint4*>(o);
         }
     }
 }
@@ -335,7 +344,20 @@ int avx_mst_gram(avx_ctx* ctx, const void* qkv, int dtype, size_t n_pix, int C, 
     return AVX_OK;
 }
 
+static int dwconv_impl(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, const void* res,
+                       const float* bias, void* stream);
+
 int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, void* stream) {
+    return dwconv_impl(ctx, x, w_c9, y, dtype, B, H, W, C, gelu_out, nullptr, nullptr, stream);
+}
+
+int avx_dwconv3x3_nhwc_add(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int B, int H, int W, int C, int gelu_out, const void* residual,
+                           const float* bias, void* stream) {
+    return dwconv_impl(ctx, x, w_c9, y, 1, B, H, W, C, gelu_out, residual, bias, stream);
+}
+
+static int dwconv_impl(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, const void* res,
+                       const float* bias, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, x && w_c9 && y && x != y && B > 0 && H > 0 && W > 0 && C > 0 && C <= 1024, "avx_dwconv3x3_nhwc: bad arguments");
     AVX_REQUIRE(ctx, dtype == 0 || dtype == 1, "avx_dwconv3x3_nhwc: dtype");
@@ -347,15 +369,16 @@ int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, 
     size_t g = (items + kMT - 1) / kMT;
     const size_t cap = (size_t)ctx->num_cus * 16;
     if (g > cap) g = cap;
-    const bool vec8 = dtype == 1 && (C % 8 == 0) && (kMT % (C / 8) == 0) && (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
+    const bool vec8 = dtype == 1 && (C % 8 == 0) && (kMT % (C / 8) == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15u) == 0;
     if (vec8) {
         const size_t it8 = (size_t)B * ((H + kDwR - 1) / kDwR) * W * (C / 8);
         size_t g8 = (it8 + kMT - 1) / kMT;
         if (g8 > cap) g8 = cap;
-        hipLaunchKernelGGL(k_dwconv3x3_h8, dim3((unsigned)g8), dim3(kMT), 0, s, (const __half*)x, w_c9, (__half*)y, B, H, W, C, gelu_out);
+        hipLaunchKernelGGL(k_dwconv3x3_h8, dim3((unsigned)g8), dim3(kMT), 0, s, (const __half*)x, w_c9, (__half*)y, B, H, W, C, gelu_out, (const __half*)res, bias);
         AVX_HIP(ctx, hipGetLastError());
         return AVX_OK;
     }
+    AVX_REQUIRE(ctx, !res && !bias, "avx_dwconv3x3_nhwc_add: the fused epilogue needs float16, C %% 8 == 0 and 16-byte aligned tensors");
     if (dtype == 0) hipLaunchKernelGGL((k_dwconv3x3<float, 1>), dim3((unsigned)g), dim3(kMT), lds, s, (const float*)x, w_c9, (float*)y, B, H, W, C, gelu_out);
     else if (vec4) hipLaunchKernelGGL((k_dwconv3x3<__half, 4>), dim3((unsigned)g), dim3(kMT), lds, s, (const __half*)x, w_c9, (__half*)y, B, H, W, C, gelu_out);
     else hipLaunchKernelGGL((k_dwconv3x3<__half, 1>), dim3((unsigned)g), dim3(kMT), lds, s, (const __half*)x, w_c9, (__half*)y, B, H, W, C, gelu_out);

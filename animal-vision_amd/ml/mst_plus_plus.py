@@ -56,6 +56,26 @@ def pad_channels(t: torch.Tensor, dims) -> torch.Tensor:
     return t
 
 
+def pack_fragments(w_kn: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """(K x N) float16 weight of `y = x @ w` -> v_mfma_f32_32x32x8_f16 fragment order [N/32][K/8][64 lanes][4]
+    (csrc/mst_mfma.hip): MFMA step s, lane half h, element j carries input channel h*K/2 + 4s + j (the order in which a
+    lane holds its contiguous half row of x).  transposed=False: tile column = lane % 32 ("pixels x channels" results);
+    transposed=True: the weight is the A operand and its 32 rows are permuted so a result lane ends up with 16
+    CONTIGUOUS output channels (row m <-> channel 16*((m % 8) // 4) + 4*(m // 8) + m % 4)."""
+    K, N = w_kn.shape
+    assert K % 32 == 0 and N % 32 == 0
+    dev = w_kn.device
+    lane = torch.arange(64, device=dev)
+    c, h = lane % 32, lane // 32
+    if transposed:
+        c = 16 * ((c % 8) // 4) + 4 * (c // 8) + c % 4
+    s = torch.arange(K // 8, device=dev)
+    j = torch.arange(4, device=dev)
+    k = (h[None, :, None] * (K // 2) + 4 * s[:, None, None] + j[None, None, :])[None]              # (1, K/8, 64, 4)
+    col = 32 * torch.arange(N // 32, device=dev)[:, None, None, None] + c[None, None, :, None]       # (N/32, 1, 64, 1)
+    return w_kn[k.expand(N // 32, -1, -1, -1), col.expand(-1, K // 8, -1, 4)].contiguous()
+
+
 class _AvxOps:
     """Binds the hand-written gfx950 kernels of csrc/mst.hip for CUDA tensors (data_ptr hand-off on torch's
     current stream).  AVX_MST_TORCH_ONLY=1 keeps every op in torch (A/B and debugging)."""
@@ -64,6 +84,7 @@ class _AvxOps:
         import os
 
         self.enabled = os.environ.get("AVX_MST_TORCH_ONLY", "") == ""
+        self._mfma = os.environ.get("AVX_MST_NO_MFMA", "") == ""  # A/B: the fused matrix-core kernels of csrc/mst_mfma.hip
         self._ctx = {}
 
     def ctx(self, device: torch.device):
@@ -100,13 +121,52 @@ class _AvxOps:
             ctx._check(lib.avx_mst_gram(ctx._h, qkv[i].data_ptr(), self._dt(qkv), n, c, heads, g[i].data_ptr(), nq[i].data_ptr(), nk[i].data_ptr(), st))
         return g[:, :, :d, :d], nq, nk
 
-    def dwconv(self, x: torch.Tensor, w_c9: torch.Tensor, gelu: bool) -> torch.Tensor:
+    def fused_ok(self, x: torch.Tensor) -> bool:
+        """The matrix-core kernels take float16 rows of 32, 64 or 128 channels."""
+        return self.enabled and x.is_cuda and x.dtype == torch.float16 and x.shape[-1] in (32, 64, 128) and self._mfma
+
+    def qkv_gram(self, x2: torch.Tensor, wpack: torch.Tensor, heads: int):
+        """x2 (b, n, c) float16 -> v (b, n, c), gram (b, heads, 32, 32), nq (b, c), nk (b, c) (csrc/mst_mfma.hip)."""
+        from .._lib import lib
+
+        b, n, c = x2.shape
+        x2 = x2.contiguous()
+        ctx = self.ctx(x2.device)
+        v = torch.empty_like(x2)
+        g = torch.empty((b, heads, 32, 32), dtype=torch.float32, device=x2.device)
+        nq = torch.empty((b, c), dtype=torch.float32, device=x2.device)
+        nk = torch.empty((b, c), dtype=torch.float32, device=x2.device)
+        st = torch.cuda.current_stream(x2.device).cuda_stream
+        for i in range(b):
+            ctx._check(lib.avx_mst_qkv_gram(ctx._h, x2[i].data_ptr(), wpack.data_ptr(), n, c, v[i].data_ptr(), g[i].data_ptr(), nq[i].data_ptr(),
+                                            nk[i].data_ptr(), st))
+        return v, g, nq, nk
+
+    def ln_gemm_gelu(self, x2: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wpack: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+        """x2 (rows, c) float16 -> gelu(layernorm(x2) @ w1) (rows, 4c) float16 (csrc/mst_mfma.hip)."""
+        from .._lib import lib
+
+        rows, c = x2.shape
+        x2 = x2.contiguous()
+        ctx = self.ctx(x2.device)
+        out = torch.empty((rows, 4 * c), dtype=torch.float16, device=x2.device)
+        ctx._check(lib.avx_mst_ln_gemm_gelu(ctx._h, x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, wpack.data_ptr(), rows, c, out.data_ptr(),
+                                            torch.cuda.current_stream(x2.device).cuda_stream))
+        return out
+
+    def dwconv(self, x: torch.Tensor, w_c9: torch.Tensor, gelu: bool, residual: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
         from .._lib import lib
 
         b, h, w, c = x.shape
         x = x.contiguous()
         y = torch.empty_like(x)
         ctx = self.ctx(x.device)
+        if residual is not None or bias is not None:  # fused epilogue: + residual + bias (float16 kernels only)
+            residual = residual.contiguous() if residual is not None else None
+            ctx._check(lib.avx_dwconv3x3_nhwc_add(ctx._h, x.data_ptr(), w_c9.data_ptr(), y.data_ptr(), b, h, w, c, 1 if gelu else 0,
+                                                  residual.data_ptr() if residual is not None else None, bias.data_ptr() if bias is not None else None,
+                                                  torch.cuda.current_stream(x.device).cuda_stream))
+            return y
         ctx._check(lib.avx_dwconv3x3_nhwc(ctx._h, x.data_ptr(), w_c9.data_ptr(), y.data_ptr(), self._dt(x), b, h, w, c, 1 if gelu else 0,
                                           torch.cuda.current_stream(x.device).cuda_stream))
         return y
@@ -244,11 +304,20 @@ class MSTPlusPlus(torch.nn.Module):
         x2 = x.reshape(b, n, c)
         wqkv = self._prep(p + ".qkv", lambda: torch.cat([self._w(p + ".to_q.weight", (0, 1)), self._w(p + ".to_k.weight", (0, 1)),
                                                          self._w(p + ".to_v.weight", (0, 1))], 0).t().contiguous())
-        qkv = x2 @ wqkv  # (b, n, 3c): one GEMM, one pass over x
-        q, k, v = qkv[..., :c], qkv[..., c : 2 * c], qkv[..., 2 * c :]
         d = c // heads  # 32: 31 real channels + the zero padding
+        fused = _AVX.fused_ok(x)
+        if fused:  # one pass over x: q, k live only in MFMA accumulators, v is the only tensor written
+            wpk = self._prep(p + ".qkv.frag", lambda: torch.cat([pack_fragments(wqkv[:, : 2 * c], False), pack_fragments(wqkv[:, 2 * c :], True)], 0).contiguous())
+            v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads)
+            nq = nq.reshape(b, heads, 1, d).clamp_min(1e-12)  # F.normalize eps
+            nk = nk.reshape(b, heads, d, 1).clamp_min(1e-12)
+        else:
+            qkv = x2 @ wqkv  # (b, n, 3c): one GEMM, one pass over x
+            q, k, v = qkv[..., :c], qkv[..., c : 2 * c], qkv[..., 2 * c :]
         # Gram matrix per head over ALL pixels (the global contraction of :129), fp32 accumulate
-        if x.is_cuda and _AVX.enabled:
+        if fused:
+            pass
+        elif x.is_cuda and _AVX.enabled:
             gram, nq, nk = _AVX.gram(qkv, heads)  # one pass over qkv: k^T q and every column norm (csrc/mst.hip)
             nq = nq.reshape(b, heads, 1, d).clamp_min(1e-12)  # F.normalize eps
             nk = nk.reshape(b, heads, d, 1).clamp_min(1e-12)
@@ -266,24 +335,38 @@ class MSTPlusPlus(torch.nn.Module):
         wp = self._w(p + ".proj.weight", (0, 1))  # (c_out, c_in)
         wp_h = wp.t().reshape(heads, d, c).float()  # rows of W_proj^T grouped by head (padding rows are zero)
         M = torch.matmul(attn.transpose(-2, -1), wp_h.unsqueeze(0)).reshape(b, c, c).to(x.dtype)  # (b, c, c)
-        out_c = torch.baddbmm(self._w(p + ".proj.bias", (0,)).to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
         vi = v.reshape(b, h, w, c)
+        if fused and c % 8 == 0:  # the block's `msa(x) + x` (:183) in two launches: pos_emb's second conv adds x and the bias, the GEMM adds onto it
+            bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
+            pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False, residual=x, bias=bias32)
+            return pe.reshape(b, n, c).baddbmm_(v, M).reshape(b, h, w, c)  # in place: pe is this block's own buffer (beta = 1, no staging copy)
+        out_c = torch.baddbmm(self._w(p + ".proj.bias", (0,)).to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
         pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False)
-        return out_c + pe
+        return out_c + pe + x
 
-    def _dw(self, x: torch.Tensor, key: str, gelu: bool) -> torch.Tensor:
-        """Depthwise 3x3 (+ GELU) on an NHWC tensor: csrc/mst.hip on the GPU, torch ops otherwise."""
+    def _dw(self, x: torch.Tensor, key: str, gelu: bool, residual: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
+        """Depthwise 3x3 (+ GELU) (+ residual + per-channel bias) on an NHWC tensor: csrc/mst.hip on the GPU, torch ops otherwise."""
         c = x.shape[-1]
         if x.is_cuda and _AVX.enabled:
             w9 = self._prep(key + ".c9f32", lambda: self._w(key, (0,)).reshape(c, 9).float().contiguous())
-            return _AVX.dwconv(x, w9, gelu)
+            return _AVX.dwconv(x, w9, gelu, residual, bias)
         y = self._conv_nhwc(x, self._w(key, (0,)), padding=1, groups=c)
-        return F.gelu(y) if gelu else y
+        y = F.gelu(y) if gelu else y
+        if residual is not None:
+            y = y + residual
+        return y + bias.to(y.dtype) if bias is not None else y
 
     def _ffn(self, x: torch.Tensor, p: str) -> torch.Tensor:
         b, h, w, c = x.shape
         g32 = self._prep(p + ".g32", lambda: self._w(p + ".norm.weight", (0,)).float().contiguous())
         b32 = self._prep(p + ".b32", lambda: self._w(p + ".norm.bias", (0,)).float().contiguous())
+        w2 = self._prep(p + ".w2", lambda: self._w(p + ".fn.net.4.weight", (0, 1)).reshape(c, 4 * c).t().contiguous())
+        if _AVX.fused_ok(x):  # LayerNorm -> 1x1 conv -> GELU on the matrix cores, the hidden tensor is written once
+            w1p = self._prep(p + ".w1.frag", lambda: pack_fragments(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous(), True))
+            y = _AVX.ln_gemm_gelu(x.reshape(b * h * w, c), g32, b32, w1p).reshape(b, h, w, 4 * c)
+            y = self._dw(y, p + ".fn.net.2.weight", gelu=True)
+            # `ffn(x) + x` (:184) inside the GEMM, in place: x is the MSA half's own output buffer, nobody else holds it
+            return x.reshape(b * h * w, c).addmm_(y.reshape(b * h * w, 4 * c), w2).reshape(b, h, w, c)
         if x.is_cuda and _AVX.enabled:
             y = _AVX.layernorm(x, g32, b32, group=PAD, real=DIM)
         else:  # LayerNorm over the real channels only; the padding channels stay zero
@@ -291,14 +374,14 @@ class MSTPlusPlus(torch.nn.Module):
             yr = F.layer_norm(x.float().index_select(-1, real), (real.numel(),), g32.index_select(0, real), b32.index_select(0, real))
             y = torch.zeros_like(x, dtype=torch.float32).index_copy_(-1, real, yr).to(x.dtype)
         w1 = self._prep(p + ".w1", lambda: self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous())
-        w2 = self._prep(p + ".w2", lambda: self._w(p + ".fn.net.4.weight", (0, 1)).reshape(c, 4 * c).t().contiguous())
         y = F.gelu(y.reshape(b, h * w, c) @ w1).reshape(b, h, w, 4 * c)
         y = self._dw(y, p + ".fn.net.2.weight", gelu=True)
-        return (y.reshape(b, h * w, 4 * c) @ w2).reshape(b, h, w, c)
+        return (y.reshape(b, h * w, 4 * c) @ w2).reshape(b, h, w, c) + x
 
     def _msab(self, x: torch.Tensor, p: str, heads: int) -> torch.Tensor:
-        x = self._ms_msa(x, p + ".blocks.0.0", heads) + x
-        return self._ffn(x, p + ".blocks.0.1") + x
+        """MSAB :176-186; both residual adds happen inside _ms_msa / _ffn (fused into their last launch on the GPU)."""
+        x = self._ms_msa(x, p + ".blocks.0.0", heads)
+        return self._ffn(x, p + ".blocks.0.1")
 
     def _mst(self, x: torch.Tensor, p: str) -> torch.Tensor:
         fea = self._conv_nhwc(x, self._w(p + ".embedding.weight", (0, 1)), padding=1)

@@ -314,9 +314,27 @@ int avx_ew_run(avx_ctx* ctx, const avx_ew_program* program, void* stream);
  *   nq[c] = ||q[:,c]||_2, nk[c] = ||k[:,c]||_2        (what F.normalize(dim=-1) divides by) */
 int avx_mst_gram(avx_ctx* ctx, const void* qkv, int dtype, size_t n_pix, int C, int heads, float* gram, float* nq, float* nk, void* stream);
 
+/* Fused matrix-core kernels for an MSAB block (csrc/mst_mfma.hip), float16 activations, channel groups 32 wide
+ * (C = 32, 64 or 128).  wpack: the weights in MFMA fragment order, built by ml/mst_plus_plus.py::pack_fragments.
+ *
+ * avx_mst_qkv_gram: MS_MSA to_q/to_k/to_v (MST_Plus_Plus.py:118-120) + the Gram matrix k^T q over all n_pix pixels per
+ * head and the L2 norm of every q / k column (:127-129) in one pass over x (n_pix x C); only v (n_pix x C) is
+ * written.  gram: heads x 32 x 32 float32 ([i][j] = k_i . q_j), nq / nk: C float32.
+ *
+ * avx_mst_ln_gemm_gelu: PreNorm LayerNorm (:57-65; statistics over the 31 real channels of each group) -> FeedForward's
+ * first 1x1 conv (:145, C -> 4C) -> GELU (:146); out: rows x 4C float16. */
+int avx_mst_qkv_gram(avx_ctx* ctx, const void* x, const void* wpack, size_t n_pix, int C, void* v_out, float* gram, float* nq, float* nk,
+                     void* stream);
+int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* wpack, size_t rows, int C,
+                         void* out, void* stream);
+
 /* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
  * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
 int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, void* stream);
+/* The same with a fused epilogue (float16 only, C % 8 == 0): y = dwconv(x) [GELU] + residual + bias[c]; residual (same
+ * shape as y) and bias (C float32) may be NULL.  MS_MSA's `out_c + pos_emb(v)` and the block's `+ x` (:137, :183). */
+int avx_dwconv3x3_nhwc_add(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int B, int H, int W, int C, int gelu_out,
+                           const void* residual, const float* bias, void* stream);
 
 /* nn.LayerNorm(C) (PreNorm :57-65) over the last dim of (rows x C): biased variance, float32 statistics. */
 int avx_layernorm_rows(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int dtype, size_t rows, int C, float eps, void* stream);
