@@ -225,17 +225,32 @@ __global__ __launch_bounds__(kMT) void k_dwconv3x3_h8(const __half* __restrict__
         for (int r = 0; r < kDwR; ++r)
 #pragma unroll
             for (int v = 0; v < 8; ++v) acc[r][v] = 0.f;
+        // Branch-free loads: every tap reads a CLAMPED (always valid) address and out-of-image taps are zeroed with a select
+        // afterwards, so the 18 loads of an item are in flight together (a guarded load per tap made each wait for the last).
+        uint4 raw[kDwR + 2][3];
 #pragma unroll
         for (int rr = 0; rr < kDwR + 2; ++rr) {  // input row y0 - 1 + rr
             const int yy = y0 - 1 + rr;
-            if (yy < 0 || yy >= H) continue;
-            const __half* rowp = x + ((b * H + yy) * (size_t)W) * C + (size_t)cg * 8;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            const __half* rowp = x + ((b * H + yc) * (size_t)W) * C + (size_t)cg * 8;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int xx = xw + kx - 1;
-                if (xx < 0 || xx >= W) continue;
-                const uint4 raw = *reinterpret_cast<const uint4*>(rowp + (size_t)xx * C);
-                const __half2* hp = reinterpret_cast<const __half2*>(&raw);
+                const int xxc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                raw[rr][kx] = *reinterpret_cast<const uint4*>(rowp + (size_t)xxc * C);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < kDwR + 2; ++rr) {
+            const int yy = y0 - 1 + rr;
+            const bool yok = yy >= 0 && yy < H;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = xw + kx - 1;
+                const bool ok = yok && xx >= 0 && xx < W;
+                uint4 rw = raw[rr][kx];
+                rw.x = ok ? rw.x : 0u; rw.y = ok ? rw.y : 0u; rw.z = ok ? rw.z : 0u; rw.w = ok ? rw.w : 0u;
+                const __half2* hp = reinterpret_cast<const __half2*>(&rw);
                 float f[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const float2 t2 = __half22float2(hp[q]); f[2 * q] = t2.x; f[2 * q + 1] = t2.y; }

@@ -238,6 +238,163 @@ __global__ __launch_bounds__(kT) void k_mst_ffn1(const __half* __restrict__ x, c
     }
 }
 
+// ---- depthwise 3x3 -> GELU -> 1x1 conv (4C -> C) -> + residual -------------------------------------------------------
+// FeedForward :147-149 and the block's `+ x` (:184).  A workgroup owns a tile of ROWS rows x 32 pixels:
+//   phase 1 (all 256 threads, thread = one group of 8 hidden channels x a few pixels, its 72 taps in registers for the
+//            whole launch): depthwise 3x3 on ROWS-row strips straight from global memory (each input row of a strip is
+//            loaded once and feeds up to three output rows), packed float32 FMAs, exact-erf GELU, float16 result into an
+//            LDS tile [ROWS][32 px][4C] (row pitch padded by 16 B: the fragment reads below are conflict-free);
+//   phase 2 (one (row, 32-channel output tile) per wave): the tile is operand B of "channels x pixels" MFMAs against
+//            the pre-packed W2 fragments, then + residual, float16, 32 contiguous bytes per lane.
+// The (N x 4C) GELU output never reaches memory.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// Exact-erf GELU on a pair, for a float16 result: erf by Abramowitz-Stegun 7.1.28, 1 - (1 + a1 z + ... + a6 z^6)^-16
+// (|error| <= 3e-7, far below half a float16 ulp of the output): packed multiplies / FMAs and ONE transcendental (v_rcp)
+// per element -- 7.1.26 (csrc/mst.hip) needs a v_rcp and a v_exp, and quarter-rate transcendentals are what bound this kernel.
+__device__ __forceinline__ float2_t gelu_erf_h2(float2_t x) {
+    const float2_t z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+    auto c2 = [](float v) { return float2_t{v, v}; };
+    float2_t pz = __builtin_elementwise_fma(z, c2(0.0000430638f), c2(0.0002765672f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0001520143f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0092705272f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0422820123f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0705230784f));
+    pz = __builtin_elementwise_fma(pz, z, c2(1.0f));
+    pz = pz * pz; pz = pz * pz; pz = pz * pz; pz = pz * pz;  // ^16 (overflows to +inf for |x| > ~17: 1/inf = 0, erf = 1)
+    const float2_t r = float2_t{__frcp_rn(pz.x), __frcp_rn(pz.y)};
+    const float2_t e = c2(1.0f) - r;                                   // erf(|x| / sqrt 2)
+    const float2_t se = float2_t{x.x < 0.f ? -e.x : e.x, x.y < 0.f ? -e.y : e.y};
+    return (x * 0.5f) * (se + 1.0f);
+}
+
+template <int C, int ROWS, int PXT>
+__global__ __launch_bounds__(kT, 3) void k_mst_ffn2(const __half* __restrict__ hid /*[B][H][W][4C]*/, const float* __restrict__ w9 /*[4C][9]*/,
+                                                    const uint2* __restrict__ w2pack /*[C/32][4C/8][64]*/, const __half* res /*[B][H][W][C]*/,
+                                                    __half* out /*may alias res*/, int B, int H, int W) {
+    constexpr int C4 = 4 * C, CV = C4 / 8, PXS = kT / CV, TW = 32 * PXT, IPT = TW / PXS, KS2 = C4 / 8, NT = C / 32;
+    constexpr int PITCH = C4 * 2 + 16;  // bytes per pixel of the LDS tile
+    static_assert(ROWS * PXT * NT == 4, "one (row, 32-pixel group, output tile) per wave");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2* wl = reinterpret_cast<uint2*>(smem);
+    float* w9l = reinterpret_cast<float*>(smem + (size_t)NT * KS2 * 64 * sizeof(uint2));  // [9][4C] depthwise taps, tap-major
+    unsigned char* tileb = reinterpret_cast<unsigned char*>(w9l + 9 * C4);                 // [ROWS][TW][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < NT * KS2 * 64; i += kT) wl[i] = w2pack[i];
+    for (int i = tid; i < 9 * C4; i += kT) { const int c = i / 9, t = i - 9 * c; w9l[t * C4 + c] = w9[i]; }
+    const int cg = tid % CV, pslot = tid / CV;
+    const int xt = (W + TW - 1) / TW, strips = (H + ROWS - 1) / ROWS;
+    const long total = (long)B * strips * xt;
+    const int p = lane & 31, h = lane >> 5;
+    const int mr = wave / (PXT * NT), mp = (wave / NT) % PXT, mt = wave % NT;  // phase 2: this wave's row, 32-pixel group and output-channel tile
+    struct Pos { int x0, y0; long b; };
+    auto pos_of = [&](long tile) { return Pos{(int)(tile % xt) * TW, (int)((tile / xt) % strips) * ROWS, tile / ((long)xt * strips)}; };
+    // Branch-free loads: every tap reads a CLAMPED (always valid) address and out-of-image taps are zeroed with a select when
+    // they are consumed, so all 3 * (ROWS + 2) loads of an item are in flight together (a guarded load per tap made each one
+    // wait for the previous).  Latency is hidden by occupancy: the taps live in LDS, not in 72 registers per thread.
+    auto issue = [&](const Pos& t, int i, uint4 (&raw)[ROWS + 2][3]) {
+        const int xw = t.x0 + pslot + PXS * i, xc = xw < W ? xw : W - 1;
+#pragma unroll
+        for (int rr = 0; rr < ROWS + 2; ++rr) {  // input row y0 - 1 + rr
+            const int yy = t.y0 - 1 + rr;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            const __half* rowp = hid + ((t.b * H + yc) * (size_t)W) * C4 + (size_t)cg * 8;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = xc + kx - 1;
+                const int xxc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                raw[rr][kx] = *reinterpret_cast<const uint4*>(rowp + (size_t)xxc * C4);
+            }
+        }
+    };
+    auto consume = [&](const Pos& t, int i, const uint4 (&raw)[ROWS + 2][3]) {
+        const int px = pslot + PXS * i, xw = t.x0 + px, xc = xw < W ? xw : W - 1;
+        const bool interior = t.x0 > 0 && t.x0 + TW < W && t.y0 > 0 && t.y0 + ROWS < H;  // uniform: no tap leaves the image
+        float2_t acc[ROWS][4];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] = float2_t{0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float2_t wt[3][4];  // this tap column's weights (LDS; lanes of one channel group read the same 32 bytes)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float4 a = *reinterpret_cast<const float4*>(w9l + (ky * 3 + kx) * C4 + cg * 8);
+                const float4 c = *reinterpret_cast<const float4*>(w9l + (ky * 3 + kx) * C4 + cg * 8 + 4);
+                wt[ky][0] = float2_t{a.x, a.y}; wt[ky][1] = float2_t{a.z, a.w}; wt[ky][2] = float2_t{c.x, c.y}; wt[ky][3] = float2_t{c.z, c.w};
+            }
+            const int xx = xc + kx - 1;
+            const bool xok = xx >= 0 && xx < W;
+#pragma unroll
+            for (int rr = 0; rr < ROWS + 2; ++rr) {
+                const int yy = t.y0 - 1 + rr;
+                uint4 rw = raw[rr][kx];
+                if (!interior) {
+                    const bool ok = xok && yy >= 0 && yy < H;
+                    rw.x = ok ? rw.x : 0u; rw.y = ok ? rw.y : 0u; rw.z = ok ? rw.z : 0u; rw.w = ok ? rw.w : 0u;
+                }
+                const half8_t h8 = __builtin_bit_cast(half8_t, rw);
+                float2_t f[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[q] = float2_t{(float)h8[2 * q], (float)h8[2 * q + 1]};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {  // this input row is tap row ky of output row r = rr - ky
+                    const int r = rr - ky;
+                    if (r < 0 || r >= ROWS) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[r][q] = __builtin_elementwise_fma(f[q], wt[ky][q], acc[r][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            half8_t o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2_t g = gelu_erf_h2(acc[r][q]);
+                o[2 * q] = (_Float16)g.x;
+                o[2 * q + 1] = (_Float16)g.y;
+            }
+            *reinterpret_cast<uint4*>(tileb + ((size_t)r * TW + px) * PITCH + cg * 16) = __builtin_bit_cast(uint4, o);
+        }
+    };
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const Pos t = pos_of(tile);
+        __syncthreads();  // phase 2 of the previous tile is done with the LDS tile (and the tables are loaded, first time round)
+#pragma unroll 1
+        for (int i = 0; i < IPT; ++i) {
+            uint4 raw[ROWS + 2][3];
+            issue(t, i, raw);
+            consume(t, i, raw);
+        }
+        __syncthreads();
+        {
+            float16_t d;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[v] = 0.f;
+            const unsigned char* src = tileb + ((size_t)mr * TW + mp * 32 + p) * PITCH + h * (C4 / 2) * 2;  // this lane's 2C contiguous hidden channels
+#pragma unroll
+            for (int s2 = 0; s2 < KS2 / 2; ++s2) {
+                const half8_t h8 = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(src + 16 * s2));
+                const half4_t b0 = half4_t{h8[0], h8[1], h8[2], h8[3]}, b1 = half4_t{h8[4], h8[5], h8[6], h8[7]};
+                d = mfma(__builtin_bit_cast(half4_t, wl[(mt * KS2 + 2 * s2) * 64 + lane]), b0, d);
+                d = mfma(__builtin_bit_cast(half4_t, wl[(mt * KS2 + 2 * s2 + 1) * 64 + lane]), b1, d);
+            }
+            const int yo = t.y0 + mr, xw = t.x0 + mp * 32 + p;
+            if (yo < H && xw < W) {
+                const size_t off = ((t.b * H + yo) * (size_t)W + xw) * C + 32 * mt + 16 * h;
+                const half8_t r0 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(res + off)[0]);
+                const half8_t r1 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(res + off)[1]);
+                _Float16 o[16];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) { o[v] = (_Float16)(d[v] + (float)r0[v]); o[8 + v] = (_Float16)(d[8 + v] + (float)r1[v]); }
+                store_tile16(out + off, o);
+            }
+        }
+    }
+}
+
 template <int C>
 int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
     constexpr int KS = C / 8, HD = C / 32;
@@ -275,6 +432,20 @@ int launch_ffn1(avx_ctx* ctx, const void* x, const float* gamma, const float* be
     return AVX_OK;
 }
 
+template <int C, int ROWS, int PXT>
+int launch_ffn2(avx_ctx* ctx, const void* hid, const float* w9, const void* w2pack, const void* res, void* out, int B, int H, int W, hipStream_t s) {
+    constexpr int C4 = 4 * C, KS2 = C4 / 8, NT = C / 32, PITCH = C4 * 2 + 16;
+    const size_t lds = (size_t)NT * KS2 * 64 * sizeof(uint2) + sizeof(float) * 9 * C4 + (size_t)ROWS * 32 * PXT * PITCH;
+    const long total = (long)B * ((H + ROWS - 1) / ROWS) * ((W + 32 * PXT - 1) / (32 * PXT));
+    const long cap = (long)ctx->num_cus * 3;  // 3 workgroups per CU (LDS and registers)
+    auto k = k_mst_ffn2<C, ROWS, PXT>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kT), lds, s, (const __half*)hid, w9, (const uint2*)w2pack, (const __half*)res,
+                       (__half*)out, B, H, W);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -304,6 +475,20 @@ int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const 
     if (C == 32) return launch_ffn1<32>(ctx, x, gamma, beta, eps, wpack, rows, out, s);
     if (C == 64) return launch_ffn1<64>(ctx, x, gamma, beta, eps, wpack, rows, out, s);
     return launch_ffn1<128>(ctx, x, gamma, beta, eps, wpack, rows, out, s);
+}
+
+int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, const void* w2pack, const void* residual, void* out, int B, int H, int W,
+                        int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, hidden && w_c9 && w2pack && residual && out && B > 0 && H > 0 && W > 0, "avx_mst_dw_gemm_add: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_dw_gemm_add: C=%d (32 or 64)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)hidden | (uintptr_t)w2pack | (uintptr_t)residual | (uintptr_t)out)) & 15u) == 0,
+                "avx_mst_dw_gemm_add: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, hidden != out, "avx_mst_dw_gemm_add: the hidden tensor cannot be the output (the residual can)");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    if (C == 32) return launch_ffn2<32, 2, 2>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
+    return launch_ffn2<64, 2, 1>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
 }
 
 }  // extern "C"

@@ -85,6 +85,7 @@ class _AvxOps:
 
         self.enabled = os.environ.get("AVX_MST_TORCH_ONLY", "") == ""
         self._mfma = os.environ.get("AVX_MST_NO_MFMA", "") == ""  # A/B: the fused matrix-core kernels of csrc/mst_mfma.hip
+        self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
         self._ctx = {}
 
     def ctx(self, device: torch.device):
@@ -153,6 +154,17 @@ class _AvxOps:
         ctx._check(lib.avx_mst_ln_gemm_gelu(ctx._h, x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, wpack.data_ptr(), rows, c, out.data_ptr(),
                                             torch.cuda.current_stream(x2.device).cuda_stream))
         return out
+
+    def dw_gemm_add(self, hidden: torch.Tensor, w_c9: torch.Tensor, w2pack: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """x += gelu(dwconv3x3(hidden)) @ w2, in place (hidden (b, h, w, 4c), x (b, h, w, c), float16; csrc/mst_mfma.hip)."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        assert hidden.is_contiguous() and x.is_contiguous() and hidden.shape == (b, h, w, 4 * c)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_dw_gemm_add(ctx._h, hidden.data_ptr(), w_c9.data_ptr(), w2pack.data_ptr(), x.data_ptr(), x.data_ptr(), b, h, w, c,
+                                           torch.cuda.current_stream(x.device).cuda_stream))
+        return x
 
     def dwconv(self, x: torch.Tensor, w_c9: torch.Tensor, gelu: bool, residual: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
         from .._lib import lib
@@ -364,6 +376,11 @@ class MSTPlusPlus(torch.nn.Module):
         if _AVX.fused_ok(x):  # LayerNorm -> 1x1 conv -> GELU on the matrix cores, the hidden tensor is written once
             w1p = self._prep(p + ".w1.frag", lambda: pack_fragments(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous(), True))
             y = _AVX.ln_gemm_gelu(x.reshape(b * h * w, c), g32, b32, w1p).reshape(b, h, w, 4 * c)
+            if c in (32, 64) and x.is_contiguous() and _AVX._ffn2:  # depthwise 3x3 -> GELU -> 1x1 conv -> + x in one kernel, in place on x
+                key = p + ".fn.net.2.weight"
+                w9 = self._prep(key + ".c9f32", lambda: self._w(key, (0,)).reshape(4 * c, 9).float().contiguous())
+                w2p = self._prep(p + ".w2.frag", lambda: pack_fragments(w2, True))
+                return _AVX.dw_gemm_add(y, w9, w2p, x)
             y = self._dw(y, p + ".fn.net.2.weight", gelu=True)
             # `ffn(x) + x` (:184) inside the GEMM, in place: x is the MSA half's own output buffer, nobody else holds it
             return x.reshape(b * h * w, c).addmm_(y.reshape(b * h * w, 4 * c), w2).reshape(b, h, w, c)

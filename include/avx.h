@@ -328,6 +328,12 @@ int avx_mst_qkv_gram(avx_ctx* ctx, const void* x, const void* wpack, size_t n_pi
 int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* wpack, size_t rows, int C,
                          void* out, void* stream);
 
+/* FeedForward's depthwise 3x3 -> GELU -> second 1x1 conv (4C -> C) (:147-149) plus the block's residual (:184):
+ * out = residual + gelu(dwconv3x3(hidden)) @ W2, hidden B x H x W x 4C float16 (never rewritten), residual / out
+ * B x H x W x C float16 (out may alias residual).  C = 32 or 64. */
+int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, const void* w2pack, const void* residual, void* out, int B, int H,
+                        int W, int C, void* stream);
+
 /* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
  * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
 int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, void* stream);
