@@ -43,6 +43,27 @@ __device__ __forceinline__ float gelu_erf_h(float x) {  // exact-erf GELU for a 
     return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
 }
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// Exact-erf GELU on a pair, for a float16 result: erf by Abramowitz-Stegun 7.1.28, 1 - (1 + a1 z + ... + a6 z^6)^-16
+// (|error| <= 3e-7, far below half a float16 ulp of the output): packed multiplies / FMAs and ONE transcendental (v_rcp)
+// per element -- 7.1.26 (csrc/mst.hip) needs a v_rcp and a v_exp, and quarter-rate transcendentals are what bound this kernel.
+__device__ __forceinline__ float2_t gelu_erf_h2(float2_t x) {
+    const float2_t z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+    auto c2 = [](float v) { return float2_t{v, v}; };
+    float2_t pz = __builtin_elementwise_fma(z, c2(0.0000430638f), c2(0.0002765672f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0001520143f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0092705272f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0422820123f));
+    pz = __builtin_elementwise_fma(pz, z, c2(0.0705230784f));
+    pz = __builtin_elementwise_fma(pz, z, c2(1.0f));
+    pz = pz * pz; pz = pz * pz; pz = pz * pz; pz = pz * pz;  // ^16 (overflows to +inf for |x| > ~17: 1/inf = 0, erf = 1)
+    const float2_t r = float2_t{__frcp_rn(pz.x), __frcp_rn(pz.y)};
+    const float2_t e = c2(1.0f) - r;                                   // erf(|x| / sqrt 2)
+    const float2_t se = float2_t{x.x < 0.f ? -e.x : e.x, x.y < 0.f ? -e.y : e.y};
+    return (x * 0.5f) * (se + 1.0f);
+}
+
 // lane (p = lane & 31, h = lane >> 5) loads channels [h*C/2, (h+1)*C/2) of pixel tile*32 + p; rows past n read as zero
 template <int C>
 __device__ __forceinline__ void load_x(const __half* __restrict__ x, size_t tile, size_t n, int lane, half4_t (&xf)[C / 8]) {
@@ -232,7 +253,11 @@ __global__ __launch_bounds__(kT) void k_mst_ffn1(const __half* __restrict__ x, c
             for (int s = 0; s < KS; ++s) d = mfma(W(t, s), yf[s], d);  // D[hidden channel (permuted)][pixel]
             _Float16 o[16];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) o[v] = (_Float16)gelu_erf_h((float)(_Float16)d[v]);
+            for (int v = 0; v < 16; v += 2) {
+                const float2_t g = gelu_erf_h2(float2_t{(float)(_Float16)d[v], (float)(_Float16)d[v + 1]});
+                o[v] = (_Float16)g.x;
+                o[v + 1] = (_Float16)g.y;
+            }
             if (row < n) store_tile16(orow + 32 * t, o);
         }
     }
@@ -247,26 +272,6 @@ __global__ __launch_bounds__(kT) void k_mst_ffn1(const __half* __restrict__ x, c
 //   phase 2 (one (row, 32-channel output tile) per wave): the tile is operand B of "channels x pixels" MFMAs against
 //            the pre-packed W2 fragments, then + residual, float16, 32 contiguous bytes per lane.
 // The (N x 4C) GELU output never reaches memory.
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-// Exact-erf GELU on a pair, for a float16 result: erf by Abramowitz-Stegun 7.1.28, 1 - (1 + a1 z + ... + a6 z^6)^-16
-// (|error| <= 3e-7, far below half a float16 ulp of the output): packed multiplies / FMAs and ONE transcendental (v_rcp)
-// per element -- 7.1.26 (csrc/mst.hip) needs a v_rcp and a v_exp, and quarter-rate transcendentals are what bound this kernel.
-__device__ __forceinline__ float2_t gelu_erf_h2(float2_t x) {
-    const float2_t z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
-    auto c2 = [](float v) { return float2_t{v, v}; };
-    float2_t pz = __builtin_elementwise_fma(z, c2(0.0000430638f), c2(0.0002765672f));
-    pz = __builtin_elementwise_fma(pz, z, c2(0.0001520143f));
-    pz = __builtin_elementwise_fma(pz, z, c2(0.0092705272f));
-    pz = __builtin_elementwise_fma(pz, z, c2(0.0422820123f));
-    pz = __builtin_elementwise_fma(pz, z, c2(0.0705230784f));
-    pz = __builtin_elementwise_fma(pz, z, c2(1.0f));
-    pz = pz * pz; pz = pz * pz; pz = pz * pz; pz = pz * pz;  // ^16 (overflows to +inf for |x| > ~17: 1/inf = 0, erf = 1)
-    const float2_t r = float2_t{__frcp_rn(pz.x), __frcp_rn(pz.y)};
-    const float2_t e = c2(1.0f) - r;                                   // erf(|x| / sqrt 2)
-    const float2_t se = float2_t{x.x < 0.f ? -e.x : e.x, x.y < 0.f ? -e.y : e.y};
-    return (x * 0.5f) * (se + 1.0f);
-}
 
 template <int C, int ROWS, int PXT>
 __global__ __launch_bounds__(kT, 3) void k_mst_ffn2(const __half* __restrict__ hid /*[B][H][W][4C]*/, const float* __restrict__ w9 /*[4C][9]*/,
@@ -395,6 +400,59 @@ __global__ __launch_bounds__(kT, 3) void k_mst_ffn2(const __half* __restrict__ h
     }
 }
 
+// ---- out = add + a @ W (C -> C): MS_MSA's fused `attn @ v -> proj` (one C x C matrix per frame) + pos_emb + x ---------
+template <int C>
+__global__ __launch_bounds__(kT) void k_mst_rowgemm_add(const __half* __restrict__ a, const uint2* __restrict__ wpack /*[C/32][KS][64]*/, const __half* add,
+                                                        __half* out /*may alias add*/, size_t n) {
+    constexpr int KS = C / 8, NT = C / 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2* wl = reinterpret_cast<uint2*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < NT * KS * 64; i += kT) wl[i] = wpack[i];
+    __syncthreads();
+    const size_t ntiles = (n + 31) / 32;
+    const int p = lane & 31, h = lane >> 5;
+    for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (size_t)gridDim.x * 4) {
+        half4_t xf[KS];
+        load_x<C>(a, tile, n, lane, xf);
+        const size_t row = tile * 32 + p;
+        if constexpr (C > 32) asm volatile("" ::: "memory");  // weight fragments stay in LDS (see k_mst_qkv)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const size_t off = row * (size_t)C + 32 * t + 16 * h;
+            half8_t r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0;
+            if (row < n) {
+                r0 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(add + off)[0]);
+                r1 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(add + off)[1]);
+            }
+            float16_t d;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[v] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) d = mfma(__builtin_bit_cast(half4_t, wl[(t * KS + s) * 64 + lane]), xf[s], d);
+            _Float16 o[16];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { o[v] = (_Float16)(d[v] + (float)r0[v]); o[8 + v] = (_Float16)(d[8 + v] + (float)r1[v]); }
+            if (row < n) store_tile16(out + off, o);
+        }
+    }
+}
+
+template <int C>
+int launch_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* add, void* out, size_t n, hipStream_t s) {
+    constexpr int KS = C / 8, NT = C / 32;
+    const size_t lds = (size_t)NT * KS * 64 * sizeof(uint2);
+    const size_t ntiles = (n + 31) / 32;
+    long blocks = (long)((ntiles + 3) / 4);
+    const long cap = (long)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    auto k = k_mst_rowgemm_add<C>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)a, (const uint2*)wpack, (const __half*)add, (__half*)out, n);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 template <int C>
 int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
     constexpr int KS = C / 8, HD = C / 32;
@@ -489,6 +547,19 @@ int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, con
     hipStream_t s = avx_pick_stream(ctx, stream);
     if (C == 32) return launch_ffn2<32, 2, 2>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
     return launch_ffn2<64, 2, 1>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
+}
+
+int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* add, void* out, size_t rows, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, a && wpack && add && out && rows > 0, "avx_mst_rowgemm_add: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_rowgemm_add: C=%d (32, 64 or 128)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)a | (uintptr_t)wpack | (uintptr_t)add | (uintptr_t)out)) & 15u) == 0, "avx_mst_rowgemm_add: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, a != out, "avx_mst_rowgemm_add: the GEMM operand cannot be the output (the addend can)");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    if (C == 32) return launch_rowgemm_add<32>(ctx, a, wpack, add, out, rows, s);
+    if (C == 64) return launch_rowgemm_add<64>(ctx, a, wpack, add, out, rows, s);
+    return launch_rowgemm_add<128>(ctx, a, wpack, add, out, rows, s);
 }
 
 }  // extern "C"

@@ -65,15 +65,23 @@ def pack_fragments(w_kn: torch.Tensor, transposed: bool) -> torch.Tensor:
     K, N = w_kn.shape
     assert K % 32 == 0 and N % 32 == 0
     dev = w_kn.device
-    lane = torch.arange(64, device=dev)
-    c, h = lane % 32, lane // 32
-    if transposed:
-        c = 16 * ((c % 8) // 4) + 4 * (c // 8) + c % 4
-    s = torch.arange(K // 8, device=dev)
-    j = torch.arange(4, device=dev)
-    k = (h[None, :, None] * (K // 2) + 4 * s[:, None, None] + j[None, None, :])[None]              # (1, K/8, 64, 4)
-    col = 32 * torch.arange(N // 32, device=dev)[:, None, None, None] + c[None, None, :, None]       # (N/32, 1, 64, 1)
-    return w_kn[k.expand(N // 32, -1, -1, -1), col.expand(-1, K // 8, -1, 4)].contiguous()
+    key = (K, N, transposed, str(dev))
+    idx = _FRAG_INDEX.get(key)
+    if idx is None:  # flat gather index, cached: packing a per-frame matrix is then ONE take() launch
+        lane = torch.arange(64, device=dev)
+        c, h = lane % 32, lane // 32
+        if transposed:
+            c = 16 * ((c % 8) // 4) + 4 * (c // 8) + c % 4
+        s = torch.arange(K // 8, device=dev)
+        j = torch.arange(4, device=dev)
+        k = (h[None, :, None] * (K // 2) + 4 * s[:, None, None] + j[None, None, :])[None]              # (1, K/8, 64, 4)
+        col = 32 * torch.arange(N // 32, device=dev)[:, None, None, None] + c[None, None, :, None]       # (N/32, 1, 64, 1)
+        idx = (k * N + col).contiguous()                                                                 # (N/32, K/8, 64, 4)
+        _FRAG_INDEX[key] = idx
+    return torch.take(w_kn.contiguous(), idx)
+
+
+_FRAG_INDEX: Dict[tuple, torch.Tensor] = {}
 
 
 class _AvxOps:
@@ -154,6 +162,17 @@ class _AvxOps:
         ctx._check(lib.avx_mst_ln_gemm_gelu(ctx._h, x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, wpack.data_ptr(), rows, c, out.data_ptr(),
                                             torch.cuda.current_stream(x2.device).cuda_stream))
         return out
+
+    def rowgemm_add(self, a: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor) -> torch.Tensor:
+        """add += a @ W in place ((rows, c) float16, W in fragment order; csrc/mst_mfma.hip)."""
+        from .._lib import lib
+
+        rows, c = a.shape
+        assert a.is_contiguous() and add.is_contiguous() and add.shape == a.shape
+        ctx = self.ctx(a.device)
+        ctx._check(lib.avx_mst_rowgemm_add(ctx._h, a.data_ptr(), wpack.data_ptr(), add.data_ptr(), add.data_ptr(), rows, c,
+                                           torch.cuda.current_stream(a.device).cuda_stream))
+        return add
 
     def dw_gemm_add(self, hidden: torch.Tensor, w_c9: torch.Tensor, w2pack: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         """x += gelu(dwconv3x3(hidden)) @ w2, in place (hidden (b, h, w, 4c), x (b, h, w, c), float16; csrc/mst_mfma.hip)."""
@@ -351,7 +370,9 @@ class MSTPlusPlus(torch.nn.Module):
         if fused and c % 8 == 0:  # the block's `msa(x) + x` (:183) in two launches: pos_emb's second conv adds x and the bias, the GEMM adds onto it
             bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
             pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False, residual=x, bias=bias32)
-            return pe.reshape(b, n, c).baddbmm_(v, M).reshape(b, h, w, c)  # in place: pe is this block's own buffer (beta = 1, no staging copy)
+            for i in range(b):  # pe += v @ M on the matrix cores, in place: pe is this block's own buffer
+                _AVX.rowgemm_add(v[i], pack_fragments(M[i], True), pe[i].reshape(n, c))
+            return pe
         out_c = torch.baddbmm(self._w(p + ".proj.bias", (0,)).to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
         pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False)
         return out_c + pe + x
