@@ -400,28 +400,33 @@ __global__ __launch_bounds__(kT, 3) void k_mst_ffn2(const __half* __restrict__ h
     }
 }
 
-// ---- out = add + a @ W (C -> C): MS_MSA's fused `attn @ v -> proj` (one C x C matrix per frame) + pos_emb + x ---------
+// ---- out = [add +] a @ W [+ a2 @ W2] (C -> C) --------------------------------------------------------------------
+// MS_MSA's fused `attn @ v -> proj` (one C x C matrix per frame) accumulated onto pos_emb + x, and the decoder's 1x1
+// fusion conv over [up | skip] (:257) as two half-K products (the concatenated tensor is never built).
 template <int C>
-__global__ __launch_bounds__(kT) void k_mst_rowgemm_add(const __half* __restrict__ a, const uint2* __restrict__ wpack /*[C/32][KS][64]*/, const __half* add,
+__global__ __launch_bounds__(kT) void k_mst_rowgemm_add(const __half* __restrict__ a, const uint2* __restrict__ wpack /*[C/32][KS][64]*/,
+                                                        const __half* __restrict__ a2 /*or NULL*/, const uint2* __restrict__ wpack2, const __half* add /*or NULL*/,
                                                         __half* out /*may alias add*/, size_t n) {
     constexpr int KS = C / 8, NT = C / 32;
     extern __shared__ __align__(16) unsigned char smem[];
     uint2* wl = reinterpret_cast<uint2*>(smem);
+    uint2* wl2 = wl + NT * KS * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < NT * KS * 64; i += kT) wl[i] = wpack[i];
+    for (int i = tid; i < NT * KS * 64; i += kT) { wl[i] = wpack[i]; if (a2) wl2[i] = wpack2[i]; }
     __syncthreads();
     const size_t ntiles = (n + 31) / 32;
     const int p = lane & 31, h = lane >> 5;
     for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (size_t)gridDim.x * 4) {
-        half4_t xf[KS];
+        half4_t xf[KS], xg[KS];
         load_x<C>(a, tile, n, lane, xf);
+        if (a2) load_x<C>(a2, tile, n, lane, xg);
         const size_t row = tile * 32 + p;
         if constexpr (C > 32) asm volatile("" ::: "memory");  // weight fragments stay in LDS (see k_mst_qkv)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const size_t off = row * (size_t)C + 32 * t + 16 * h;
             half8_t r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0;
-            if (row < n) {
+            if (add && row < n) {
                 r0 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(add + off)[0]);
                 r1 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(add + off)[1]);
             }
@@ -430,6 +435,10 @@ __global__ __launch_bounds__(kT) void k_mst_rowgemm_add(const __half* __restrict
             for (int v = 0; v < 16; ++v) d[v] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) d = mfma(__builtin_bit_cast(half4_t, wl[(t * KS + s) * 64 + lane]), xf[s], d);
+            if (a2) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d = mfma(__builtin_bit_cast(half4_t, wl2[(t * KS + s) * 64 + lane]), xg[s], d);
+            }
             _Float16 o[16];
 #pragma unroll
             for (int v = 0; v < 8; ++v) { o[v] = (_Float16)(d[v] + (float)r0[v]); o[8 + v] = (_Float16)(d[8 + v] + (float)r1[v]); }
@@ -439,16 +448,17 @@ __global__ __launch_bounds__(kT) void k_mst_rowgemm_add(const __half* __restrict
 }
 
 template <int C>
-int launch_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* add, void* out, size_t n, hipStream_t s) {
+int launch_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* a2, const void* wpack2, const void* add, void* out, size_t n, hipStream_t s) {
     constexpr int KS = C / 8, NT = C / 32;
-    const size_t lds = (size_t)NT * KS * 64 * sizeof(uint2);
+    const size_t lds = (size_t)2 * NT * KS * 64 * sizeof(uint2);
     const size_t ntiles = (n + 31) / 32;
     long blocks = (long)((ntiles + 3) / 4);
-    const long cap = (long)ctx->num_cus * 8;
+    const long cap = (long)ctx->num_cus * (C == 128 ? 2 : 8);
     if (blocks > cap) blocks = cap;
     auto k = k_mst_rowgemm_add<C>;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)a, (const uint2*)wpack, (const __half*)add, (__half*)out, n);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)a, (const uint2*)wpack, (const __half*)a2, (const uint2*)wpack2,
+                       (const __half*)add, (__half*)out, n);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
@@ -549,17 +559,19 @@ int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, con
     return launch_ffn2<64, 2, 1>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
 }
 
-int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* add, void* out, size_t rows, int C, void* stream) {
+int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* a2, const void* wpack2, const void* add, void* out, size_t rows, int C,
+                        void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
-    AVX_REQUIRE(ctx, a && wpack && add && out && rows > 0, "avx_mst_rowgemm_add: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, a && wpack && out && rows > 0 && (!a2 == !wpack2), "avx_mst_rowgemm_add: NULL pointer or empty tensor");
     AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_rowgemm_add: C=%d (32, 64 or 128)", C);
-    AVX_REQUIRE(ctx, ((((uintptr_t)a | (uintptr_t)wpack | (uintptr_t)add | (uintptr_t)out)) & 15u) == 0, "avx_mst_rowgemm_add: pointers must be 16-byte aligned");
-    AVX_REQUIRE(ctx, a != out, "avx_mst_rowgemm_add: the GEMM operand cannot be the output (the addend can)");
+    AVX_REQUIRE(ctx, ((((uintptr_t)a | (uintptr_t)wpack | (uintptr_t)a2 | (uintptr_t)wpack2 | (uintptr_t)add | (uintptr_t)out)) & 15u) == 0,
+                "avx_mst_rowgemm_add: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, a != out && a2 != out, "avx_mst_rowgemm_add: a GEMM operand cannot be the output (the addend can)");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
-    if (C == 32) return launch_rowgemm_add<32>(ctx, a, wpack, add, out, rows, s);
-    if (C == 64) return launch_rowgemm_add<64>(ctx, a, wpack, add, out, rows, s);
-    return launch_rowgemm_add<128>(ctx, a, wpack, add, out, rows, s);
+    if (C == 32) return launch_rowgemm_add<32>(ctx, a, wpack, a2, wpack2, add, out, rows, s);
+    if (C == 64) return launch_rowgemm_add<64>(ctx, a, wpack, a2, wpack2, add, out, rows, s);
+    return launch_rowgemm_add<128>(ctx, a, wpack, a2, wpack2, add, out, rows, s);
 }
 
 }  // extern "C"

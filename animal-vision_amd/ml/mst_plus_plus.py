@@ -163,16 +163,19 @@ class _AvxOps:
                                             torch.cuda.current_stream(x2.device).cuda_stream))
         return out
 
-    def rowgemm_add(self, a: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor) -> torch.Tensor:
-        """add += a @ W in place ((rows, c) float16, W in fragment order; csrc/mst_mfma.hip)."""
+    def rowgemm_add(self, a: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor = None, a2: torch.Tensor = None, wpack2: torch.Tensor = None) -> torch.Tensor:
+        """[add +] a @ W [+ a2 @ W2] ((rows, c) float16, weights in fragment order; csrc/mst_mfma.hip); in place on `add`
+        when it is given, else a new tensor."""
         from .._lib import lib
 
         rows, c = a.shape
-        assert a.is_contiguous() and add.is_contiguous() and add.shape == a.shape
+        assert a.is_contiguous() and (add is None or (add.is_contiguous() and add.shape == a.shape)) and (a2 is None or (a2.is_contiguous() and a2.shape == a.shape))
+        out = add if add is not None else torch.empty_like(a)
         ctx = self.ctx(a.device)
-        ctx._check(lib.avx_mst_rowgemm_add(ctx._h, a.data_ptr(), wpack.data_ptr(), add.data_ptr(), add.data_ptr(), rows, c,
+        ctx._check(lib.avx_mst_rowgemm_add(ctx._h, a.data_ptr(), wpack.data_ptr(), a2.data_ptr() if a2 is not None else None,
+                                           wpack2.data_ptr() if a2 is not None else None, add.data_ptr() if add is not None else None, out.data_ptr(), rows, c,
                                            torch.cuda.current_stream(a.device).cuda_stream))
-        return add
+        return out
 
     def dw_gemm_add(self, hidden: torch.Tensor, w_c9: torch.Tensor, w2pack: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         """x += gelu(dwconv3x3(hidden)) @ w2, in place (hidden (b, h, w, 4c), x (b, h, w, c), float16; csrc/mst_mfma.hip)."""
@@ -435,10 +438,19 @@ class MSTPlusPlus(torch.nn.Module):
             up = F.conv_transpose2d(fea.permute(0, 3, 1, 2), self._w(f"{p}.decoder_layers.{i}.0.weight", (0, 1)),
                                     self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)), stride=2).permute(0, 2, 3, 1)
             heads //= 2
-            cat = torch.cat([up, skips[1 - i]], dim=-1)  # [up | skip]: the group-wise padding of the 2c input channels of the fusion conv
-            b, h, w, c2 = cat.shape
+            skip = skips[1 - i]
+            b, h, w, ch = up.shape
+            c2 = 2 * ch
+            # the fusion conv's 2c input channels are [up | skip], each half group-wise padded
             wf = self._prep(f"{p}.fuse{i}", lambda: self._w(f"{p}.decoder_layers.{i}.1.weight", (0, 1)).reshape(c2 // 2, c2).t().contiguous())
-            fea = (cat.reshape(b, h * w, c2) @ wf).reshape(b, h, w, c2 // 2)
+            if _AVX.fused_ok(skip):  # two half-K products, the concatenation is never built
+                up, skip = up.contiguous(), skip.contiguous()
+                wtop = self._prep(f"{p}.fuse{i}.top", lambda: pack_fragments(wf[:ch].contiguous(), True))
+                wbot = self._prep(f"{p}.fuse{i}.bot", lambda: pack_fragments(wf[ch:].contiguous(), True))
+                fea = _AVX.rowgemm_add(up.reshape(b * h * w, ch), wtop, None, skip.reshape(b * h * w, ch), wbot).reshape(b, h, w, ch)
+            else:
+                cat = torch.cat([up, skip], dim=-1)
+                fea = (cat.reshape(b, h * w, c2) @ wf).reshape(b, h, w, c2 // 2)
             fea = self._msab(fea, f"{p}.decoder_layers.{i}.2", heads)
         return self._conv_nhwc(fea, self._w(p + ".mapping.weight", (0, 1)), padding=1) + x
 

@@ -334,9 +334,11 @@ int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const 
 int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, const void* w2pack, const void* residual, void* out, int B, int H,
                         int W, int C, void* stream);
 
-/* out = add + a @ W for (rows x C) float16 tensors and a C x C weight in fragment order (out may alias add): MS_MSA's
- * `proj(attn @ v)` collapsed to one matrix per frame (:132-135) accumulated onto pos_emb(v) + x. */
-int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* add, void* out, size_t rows, int C, void* stream);
+/* out = [add +] a @ W [+ a2 @ W2] for (rows x C) float16 tensors and C x C weights in fragment order (out may alias
+ * add; a2 / W2 and add may be NULL): MS_MSA's `proj(attn @ v)` collapsed to one matrix per frame (:132-135)
+ * accumulated onto pos_emb(v) + x, and the decoder's 1x1 fusion conv over [up | skip] (:257) without the concatenation. */
+int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* a2, const void* wpack2, const void* add, void* out, size_t rows,
+                        int C, void* stream);
 
 /* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
  * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
