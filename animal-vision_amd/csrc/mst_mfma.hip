@@ -463,6 +463,45 @@ int launch_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const voi
     return AVX_OK;
 }
 
+// ---- attention matrix -> fused projection weight, in fragment order -----------------------------------------------------
+// MS_MSA :127-135 after the Gram pass: attn = softmax_j((k_i . q_j) / (|k_i| |q_j|) * rescale) per head (F.normalize's
+// eps = 1e-12 on the norms; the padding column 31 takes no part), then M = blockdiag(attn_h^T) @ W_proj^T so that
+// proj(attn @ v) == v @ M.  One small launch instead of a dozen elementwise ones; M leaves already packed for
+// k_mst_rowgemm_add ("channels x pixels" fragments, see the header).
+__global__ __launch_bounds__(256) void k_mst_attn_pack(const float* __restrict__ gram /*[HD][32][32]*/, const float* __restrict__ nq, const float* __restrict__ nk,
+                                                       const float* __restrict__ rescale /*[HD]*/, const float* __restrict__ wpt /*[C][C] = W_proj^T*/, int C,
+                                                       __half* __restrict__ mpack /*[C/32][C/8][64][4]*/) {
+    __shared__ float A[4][32][33];
+    const int HD = C / 32, KS = C / 8, tid = threadIdx.x;
+    for (int idx = tid; idx < HD * 1024; idx += 256) {
+        const int hd = idx >> 10, i = (idx >> 5) & 31, j = idx & 31;
+        A[hd][i][j] = gram[idx] / (fmaxf(nk[hd * 32 + i], 1e-12f) * fmaxf(nq[hd * 32 + j], 1e-12f)) * rescale[hd];
+    }
+    __syncthreads();
+    if (tid < HD * 32) {
+        float* row = A[tid >> 5][tid & 31];
+        float m = row[0];
+        for (int j = 1; j < 31; ++j) m = fmaxf(m, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < 31; ++j) { const float e = __expf(row[j] - m); row[j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < 31; ++j) row[j] *= inv;
+        row[31] = 0.f;
+    }
+    __syncthreads();
+    {  // every block repeats the (tiny) softmax above and then packs its own 256 entries of M
+        const int idx = blockIdx.x * 256 + tid;
+        const int e = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % KS, t = (idx >> 8) / KS;
+        const int hh = lane >> 5, m = lane & 31;
+        const int k = hh * (C / 2) + 4 * s + e;                                    // input channel (row of M)
+        const int n = 32 * t + 16 * ((m & 7) >> 2) + 4 * (m >> 3) + (m & 3);       // output channel (column of M)
+        const int hd = k >> 5, j = k & 31;
+        float acc = 0.f;
+        for (int i = 0; i < 32; ++i) acc = __builtin_fmaf(A[hd][i][j], wpt[(size_t)(hd * 32 + i) * C + n], acc);
+        mpack[idx] = __float2half(acc);
+    }
+}
+
 template <int C>
 int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
     constexpr int KS = C / 8, HD = C / 32;
@@ -572,6 +611,18 @@ int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const vo
     if (C == 32) return launch_rowgemm_add<32>(ctx, a, wpack, a2, wpack2, add, out, rows, s);
     if (C == 64) return launch_rowgemm_add<64>(ctx, a, wpack, a2, wpack2, add, out, rows, s);
     return launch_rowgemm_add<128>(ctx, a, wpack, a2, wpack2, add, out, rows, s);
+}
+
+int avx_mst_attn_pack(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
+                      void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, gram && nq && nk && rescale && wproj_t && mpack, "avx_mst_attn_pack: NULL pointer");
+    AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_attn_pack: C=%d (32, 64 or 128)", C);
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    hipLaunchKernelGGL(k_mst_attn_pack, dim3((unsigned)(C * C / 256)), dim3(256), 0, s, gram, nq, nk, rescale, wproj_t, C, (__half*)mpack);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
 }
 
 }  // extern "C"

@@ -163,6 +163,18 @@ class _AvxOps:
                                             torch.cuda.current_stream(x2.device).cuda_stream))
         return out
 
+    def attn_pack(self, gram: torch.Tensor, nq: torch.Tensor, nk: torch.Tensor, rescale: torch.Tensor, wproj_t: torch.Tensor) -> torch.Tensor:
+        """gram (heads, 32, 32), nq / nk (c,), rescale (heads,), W_proj^T (c, c), all float32 -> the fused attention @ projection
+        matrix M (c x c) as float16 MFMA fragments (csrc/mst_mfma.hip::k_mst_attn_pack)."""
+        from .._lib import lib
+
+        c = nq.numel()
+        ctx = self.ctx(gram.device)
+        out = torch.empty((c // 32, c // 8, 64, 4), dtype=torch.float16, device=gram.device)
+        ctx._check(lib.avx_mst_attn_pack(ctx._h, gram.data_ptr(), nq.data_ptr(), nk.data_ptr(), rescale.data_ptr(), wproj_t.data_ptr(), c, out.data_ptr(),
+                                         torch.cuda.current_stream(gram.device).cuda_stream))
+        return out
+
     def rowgemm_add(self, a: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor = None, a2: torch.Tensor = None, wpack2: torch.Tensor = None) -> torch.Tensor:
         """[add +] a @ W [+ a2 @ W2] ((rows, c) float16, weights in fragment order; csrc/mst_mfma.hip); in place on `add`
         when it is given, else a new tensor."""
@@ -339,19 +351,23 @@ class MSTPlusPlus(torch.nn.Module):
         wqkv = self._prep(p + ".qkv", lambda: torch.cat([self._w(p + ".to_q.weight", (0, 1)), self._w(p + ".to_k.weight", (0, 1)),
                                                          self._w(p + ".to_v.weight", (0, 1))], 0).t().contiguous())
         d = c // heads  # 32: 31 real channels + the zero padding
-        fused = _AVX.fused_ok(x)
-        if fused:  # one pass over x: q, k live only in MFMA accumulators, v is the only tensor written
+        if _AVX.fused_ok(x):  # one pass over x: q, k live only in MFMA accumulators, v is the only tensor written
             wpk = self._prep(p + ".qkv.frag", lambda: torch.cat([pack_fragments(wqkv[:, : 2 * c], False), pack_fragments(wqkv[:, 2 * c :], True)], 0).contiguous())
             v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads)
-            nq = nq.reshape(b, heads, 1, d).clamp_min(1e-12)  # F.normalize eps
-            nk = nk.reshape(b, heads, d, 1).clamp_min(1e-12)
-        else:
-            qkv = x2 @ wqkv  # (b, n, 3c): one GEMM, one pass over x
-            q, k, v = qkv[..., :c], qkv[..., c : 2 * c], qkv[..., 2 * c :]
+            # softmax(gram / (nk nq^T) * rescale) and M = blockdiag(attn_h^T) @ W_proj^T in one small launch, M already in fragment order
+            resc = self._prep(p + ".rescale32", lambda: self._p(p + ".rescale").float().reshape(heads).contiguous())
+            wpt = self._prep(p + ".proj.t32", lambda: self._w(p + ".proj.weight", (0, 1)).t().float().contiguous())
+            bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
+            vi = v.reshape(b, h, w, c)
+            # the block's `msa(x) + x` (:183): pos_emb's second conv adds x and the bias, the projection GEMM accumulates onto it in place
+            pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False, residual=x, bias=bias32)
+            for i in range(b):
+                _AVX.rowgemm_add(v[i], _AVX.attn_pack(gram[i], nq[i], nk[i], resc, wpt), pe[i].reshape(n, c))
+            return pe
+        qkv = x2 @ wqkv  # (b, n, 3c): one GEMM, one pass over x
+        q, k, v = qkv[..., :c], qkv[..., c : 2 * c], qkv[..., 2 * c :]
         # Gram matrix per head over ALL pixels (the global contraction of :129), fp32 accumulate
-        if fused:
-            pass
-        elif x.is_cuda and _AVX.enabled:
+        if x.is_cuda and _AVX.enabled:
             gram, nq, nk = _AVX.gram(qkv, heads)  # one pass over qkv: k^T q and every column norm (csrc/mst.hip)
             nq = nq.reshape(b, heads, 1, d).clamp_min(1e-12)  # F.normalize eps
             nk = nk.reshape(b, heads, d, 1).clamp_min(1e-12)
@@ -370,12 +386,6 @@ class MSTPlusPlus(torch.nn.Module):
         wp_h = wp.t().reshape(heads, d, c).float()  # rows of W_proj^T grouped by head (padding rows are zero)
         M = torch.matmul(attn.transpose(-2, -1), wp_h.unsqueeze(0)).reshape(b, c, c).to(x.dtype)  # (b, c, c)
         vi = v.reshape(b, h, w, c)
-        if fused and c % 8 == 0:  # the block's `msa(x) + x` (:183) in two launches: pos_emb's second conv adds x and the bias, the GEMM adds onto it
-            bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
-            pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False, residual=x, bias=bias32)
-            for i in range(b):  # pe += v @ M on the matrix cores, in place: pe is this block's own buffer
-                _AVX.rowgemm_add(v[i], pack_fragments(M[i], True), pe[i].reshape(n, c))
-            return pe
         out_c = torch.baddbmm(self._w(p + ".proj.bias", (0,)).to(x.dtype).reshape(1, 1, c), v, M).reshape(b, h, w, c)
         pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False)
         return out_c + pe + x

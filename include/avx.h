@@ -340,6 +340,12 @@ int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, con
 int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* a2, const void* wpack2, const void* add, void* out, size_t rows,
                         int C, void* stream);
 
+/* MS_MSA :127-135 after avx_mst_qkv_gram: attn = softmax over the 31 real columns of gram / (nk nq^T) * rescale per
+ * head, M = blockdiag(attn_h^T) @ W_proj^T (wproj_t: C x C float32, row = input channel), written as float16 in the
+ * fragment order avx_mst_rowgemm_add takes. */
+int avx_mst_attn_pack(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C,
+                      void* mpack, void* stream);
+
 /* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
  * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
 int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, void* stream);
