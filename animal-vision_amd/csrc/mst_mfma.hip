@@ -502,6 +502,66 @@ __global__ __launch_bounds__(256) void k_mst_attn_pack(const float* __restrict__
     }
 }
 
+// ---- dense 3x3 conv (C -> C, zero padding 1) [+ add]: MST.embedding / mapping (:199, :228), conv_out (:277) ----------------
+// Implicit GEMM with K = 9 taps x C: a wave owns 32 consecutive pixels of one image row; for every tap its x fragment is
+// the (clamped, then zero-masked) neighbour row chunk, multiplied against that tap's pre-packed C x C weight.
+template <int C>
+__global__ __launch_bounds__(kT) void k_mst_conv3x3(const __half* __restrict__ x /*[B][H][W][C]*/, const uint2* __restrict__ wpack /*[9][C/32][KS][64]*/,
+                                                    const __half* __restrict__ add /*or NULL*/, __half* __restrict__ out, int B, int H, int W) {
+    constexpr int KS = C / 8, NT = C / 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2* wl = reinterpret_cast<uint2*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 9 * NT * KS * 64; i += kT) wl[i] = wpack[i];
+    __syncthreads();
+    const int xt = (W + 31) / 32;
+    const long total = (long)B * H * xt;
+    const int p = lane & 31, h = lane >> 5;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < total; tile += (long)gridDim.x * 4) {
+        const int x0 = (int)(tile % xt) * 32, y = (int)((tile / xt) % H);
+        const long b = tile / ((long)xt * H);
+        const int xw = x0 + p, xc = xw < W ? xw : W - 1;
+        half4_t xf[9][KS];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = xc + tap % 3 - 1;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xxc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const uint4* src = reinterpret_cast<const uint4*>(x + ((b * H + yc) * (size_t)W + xxc) * C + h * (C / 2));
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) {
+                uint4 v = src[q];
+                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+                const half8_t h8 = __builtin_bit_cast(half8_t, v);
+                xf[tap][2 * q] = half4_t{h8[0], h8[1], h8[2], h8[3]};
+                xf[tap][2 * q + 1] = half4_t{h8[4], h8[5], h8[6], h8[7]};
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float16_t d;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[v] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d = mfma(__builtin_bit_cast(half4_t, wl[((tap * NT + t) * KS + s) * 64 + lane]), xf[tap][s], d);
+            if (xw < W) {
+                const size_t off = ((b * H + y) * (size_t)W + xw) * C + 32 * t + 16 * h;
+                half8_t r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0;
+                if (add) {
+                    r0 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(add + off)[0]);
+                    r1 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(add + off)[1]);
+                }
+                _Float16 o[16];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) { o[v] = (_Float16)(d[v] + (float)r0[v]); o[8 + v] = (_Float16)(d[8 + v] + (float)r1[v]); }
+                store_tile16(out + off, o);
+            }
+        }
+    }
+}
+
 template <int C>
 int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
     constexpr int KS = C / 8, HD = C / 32;
@@ -621,6 +681,27 @@ int avx_mst_attn_pack(avx_ctx* ctx, const float* gram, const float* nq, const fl
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     hipLaunchKernelGGL(k_mst_attn_pack, dim3((unsigned)(C * C / 256)), dim3(256), 0, s, gram, nq, nk, rescale, wproj_t, C, (__half*)mpack);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+int avx_mst_conv3x3_add(avx_ctx* ctx, const void* x, const void* wpack, const void* add, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack && out && B > 0 && H > 0 && W > 0, "avx_mst_conv3x3_add: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32, "avx_mst_conv3x3_add: C=%d (32: the 31-channel full-resolution convs)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)add | (uintptr_t)out)) & 15u) == 0, "avx_mst_conv3x3_add: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, x != out, "avx_mst_conv3x3_add: in-place convolution is not possible");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    constexpr int KS = 4, NT = 1;
+    const size_t lds = (size_t)9 * NT * KS * 64 * sizeof(uint2);
+    const long total = (long)B * H * ((W + 31) / 32);
+    long blocks = (total + 3) / 4;
+    const long cap = (long)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    auto k = k_mst_conv3x3<32>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, (const __half*)add, (__half*)out, B, H, W);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -163,6 +163,19 @@ class _AvxOps:
                                             torch.cuda.current_stream(x2.device).cuda_stream))
         return out
 
+    def conv3x3(self, x: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:
+        """Dense 3x3 conv (padding 1) [+ add] on a (b, h, w, 32) float16 tensor (csrc/mst_mfma.hip, implicit GEMM on MFMA)."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        x = x.contiguous()
+        add = add.contiguous() if add is not None else None
+        out = torch.empty_like(x)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_conv3x3_add(ctx._h, x.data_ptr(), wpack.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), b, h, w, c,
+                                           torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
     def attn_pack(self, gram: torch.Tensor, nq: torch.Tensor, nk: torch.Tensor, rescale: torch.Tensor, wproj_t: torch.Tensor) -> torch.Tensor:
         """gram (heads, 32, 32), nq / nk (c,), rescale (heads,), W_proj^T (c, c), all float32 -> the fused attention @ projection
         matrix M (c x c) as float16 MFMA fragments (csrc/mst_mfma.hip::k_mst_attn_pack)."""
@@ -340,6 +353,14 @@ class MSTPlusPlus(torch.nn.Module):
         return self._prep(k + ".pad" + "".join(map(str, dims)), lambda: pad_channels(self._p(k), dims).contiguous())
 
     # ---- blocks (x is NHWC, channel groups 32 wide) -------------------------------------------------
+    def _conv3(self, x: torch.Tensor, key: str, add: torch.Tensor = None) -> torch.Tensor:
+        """31 -> 31 channel 3x3 conv (padding 1) [+ add]: MFMA implicit GEMM for float16 on the GPU, F.conv2d otherwise."""
+        if _AVX.fused_ok(x) and x.shape[-1] == 32:
+            wp = self._prep(key + ".frag9", lambda: torch.stack([pack_fragments(self._w(key, (0, 1))[:, :, t // 3, t % 3].t().contiguous(), True) for t in range(9)]).contiguous())
+            return _AVX.conv3x3(x, wp, add)
+        y = self._conv_nhwc(x, self._w(key, (0, 1)), padding=1)
+        return y + add if add is not None else y
+
     def _conv_nhwc(self, x: torch.Tensor, w: torch.Tensor, **kw) -> torch.Tensor:
         y = F.conv2d(x.permute(0, 3, 1, 2), w, **kw)  # NCHW view of channels-last memory: no copy
         return y.permute(0, 2, 3, 1)
@@ -435,7 +456,7 @@ class MSTPlusPlus(torch.nn.Module):
         return self._ffn(x, p + ".blocks.0.1")
 
     def _mst(self, x: torch.Tensor, p: str) -> torch.Tensor:
-        fea = self._conv_nhwc(x, self._w(p + ".embedding.weight", (0, 1)), padding=1)
+        fea = self._conv3(x, p + ".embedding.weight")
         skips: List[torch.Tensor] = []
         heads = 1
         for i in range(2):
@@ -462,7 +483,7 @@ class MSTPlusPlus(torch.nn.Module):
                 cat = torch.cat([up, skip], dim=-1)
                 fea = (cat.reshape(b, h * w, c2) @ wf).reshape(b, h, w, c2 // 2)
             fea = self._msab(fea, f"{p}.decoder_layers.{i}.2", heads)
-        return self._conv_nhwc(fea, self._w(p + ".mapping.weight", (0, 1)), padding=1) + x
+        return self._conv3(fea, p + ".mapping.weight", add=x)
 
     @torch.no_grad()
     def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
@@ -477,7 +498,7 @@ class MSTPlusPlus(torch.nn.Module):
         hfe = x
         for s in range(self.stage):
             hfe = self._mst(hfe, f"body.{s}")
-        hfe = self._conv_nhwc(hfe, self._w("conv_out.weight", (0, 1)), padding=1) + x
+        hfe = self._conv3(hfe, "conv_out.weight", add=x)
         return hfe[:, :h_inp, :w_inp, :]
 
     @torch.no_grad()
