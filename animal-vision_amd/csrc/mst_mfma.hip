@@ -61,6 +61,8 @@ __device__ __forceinline__ float2_t gelu_erf_h2(float2_t x) {
     const float2_t r = float2_t{__frcp_rn(pz.x), __frcp_rn(pz.y)};
     const float2_t e = c2(1.0f) - r;                                   // erf(|x| / sqrt 2)
     const float2_t se = float2_t{x.x < 0.f ? -e.x : e.x, x.y < 0.f ? -e.y : e.y};
+    // (1 + se, not "x < 0 ? r : 2 - r": that form is more accurate in the far negative tail but feeds subnormal products
+    //  to the packed multiplies, which measured 10-27 % slower across the three kernels that use this function)
     return (x * 0.5f) * (se + 1.0f);
 }
 
