@@ -582,6 +582,131 @@ __global__ __launch_bounds__(kT) void k_mst_conv3x3(const __half* __restrict__ x
     }
 }
 
+// ---- pos_emb: depthwise 3x3 -> GELU -> depthwise 3x3 (+ x + bias) in one pass (MS_MSA :104-106, :136-137) ------------------
+// A workgroup owns a TH x TW pixel tile: phase 1 evaluates the first conv + GELU on the (TH+2) x (TW+2) halo region into LDS
+// (float16, zero outside the image: the second conv's zero padding applies to THIS map), phase 2 runs the second conv from
+// LDS and adds the residual and the projection bias.  The intermediate map never reaches memory (2 of the 5 passes saved).
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(kT) void k_mst_posemb(const __half* __restrict__ v, const float* __restrict__ w1 /*[C][9]*/, const float* __restrict__ w2 /*[C][9]*/,
+                                                   const __half* __restrict__ res, const float* __restrict__ bias /*[C]*/, __half* __restrict__ out, int B, int H,
+                                                   int W) {
+    constexpr int CV = C / 8, PH = TH + 2, PW = TW + 2;
+    static_assert(PH % 2 == 0 && kT % CV == 0, "row pairs in phase 1; fixed channel group per thread");
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                                     // [2][9][C] taps, tap-major
+    float* bl = wl + 2 * 9 * C;                                                     // [C] bias
+    unsigned char* mid = reinterpret_cast<unsigned char*>(bl + C);                  // [PH][PW][C] float16
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * C; i += kT) { const int c = i / 9, t = i - 9 * c; wl[t * C + c] = w1[i]; wl[9 * C + t * C + c] = w2[i]; }
+    for (int i = tid; i < C; i += kT) bl[i] = bias ? bias[i] : 0.f;
+    const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+    const long total = (long)B * ty * tx;
+    auto taps = [&](const float* wbase, int t, int cg, float2_t (&wt)[4]) {
+        const float4 a = *reinterpret_cast<const float4*>(wbase + t * C + cg * 8);
+        const float4 c = *reinterpret_cast<const float4*>(wbase + t * C + cg * 8 + 4);
+        wt[0] = float2_t{a.x, a.y}; wt[1] = float2_t{a.z, a.w}; wt[2] = float2_t{c.x, c.y}; wt[3] = float2_t{c.z, c.w};
+    };
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int x0 = (int)(tile % tx) * TW, y0 = (int)((tile / tx) % ty) * TH;
+        const long b = tile / ((long)tx * ty);
+        __syncthreads();  // the previous tile's phase 2 is done with `mid` (and the tables are loaded, first time round)
+        const int cg = tid % CV;  // kT % CV == 0: a thread keeps its channel group, so each phase holds its 72 taps in registers
+        float2_t wt[9][4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) taps(wl, t, cg, wt[t]);
+#pragma unroll 1
+        for (int it = tid; it < (PH / 2) * PW * CV; it += kT) {  // one item = two vertically adjacent pixels of the halo region
+            const int pp = it / CV, c = pp % PW, r = 2 * (pp / PW);
+            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            uint4 raw[4][3];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)  // branch-free: clamped addresses, out-of-image taps zeroed below
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y2 = yy - 1 + rr, x2 = xx + kx - 1;
+                    const int yc = y2 < 0 ? 0 : (y2 >= H ? H - 1 : y2), xc = x2 < 0 ? 0 : (x2 >= W ? W - 1 : x2);
+                    raw[rr][kx] = *reinterpret_cast<const uint4*>(v + ((b * H + yc) * (size_t)W + xc) * C + cg * 8);
+                }
+            float2_t acc[2][4];
+#pragma unroll
+            for (int o2 = 0; o2 < 2; ++o2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[o2][q] = float2_t{0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y2 = yy - 1 + rr, x2 = xx + kx - 1;
+                    const bool ok = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+                    uint4 rw = raw[rr][kx];
+                    rw.x = ok ? rw.x : 0u; rw.y = ok ? rw.y : 0u; rw.z = ok ? rw.z : 0u; rw.w = ok ? rw.w : 0u;
+                    const half8_t h8 = __builtin_bit_cast(half8_t, rw);
+                    float2_t f[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f[q] = float2_t{(float)h8[2 * q], (float)h8[2 * q + 1]};
+#pragma unroll
+                    for (int o2 = 0; o2 < 2; ++o2) {  // input row rr is tap row ky = rr - o2 of output o2
+                        const int ky = rr - o2;
+                        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[o2][q] = __builtin_elementwise_fma(f[q], wt[ky * 3 + kx][q], acc[o2][q]);
+                    }
+                }
+#pragma unroll
+            for (int o2 = 0; o2 < 2; ++o2) {
+                const int ym = yy + o2;
+                const bool inside = ym >= 0 && ym < H && xx >= 0 && xx < W;
+                half8_t o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float2_t g = gelu_erf_h2(acc[o2][q]);
+                    o[2 * q] = inside ? (_Float16)g.x : (_Float16)0.f;
+                    o[2 * q + 1] = inside ? (_Float16)g.y : (_Float16)0.f;
+                }
+                *reinterpret_cast<uint4*>(mid + (((size_t)(r + o2) * PW + c) * C + cg * 8) * 2) = __builtin_bit_cast(uint4, o);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) taps(wl + 9 * C, t, cg, wt[t]);
+        __syncthreads();
+#pragma unroll 1
+        for (int it = tid; it < TH * TW * CV; it += kT) {
+            const int pp = it / CV, c = pp % TW, r = pp / TW;
+            const int yo = y0 + r, xo = x0 + c;
+            if (yo >= H || xo >= W) continue;
+            float2_t acc[4] = {float2_t{0.f, 0.f}, float2_t{0.f, 0.f}, float2_t{0.f, 0.f}, float2_t{0.f, 0.f}};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const half8_t h8 = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(mid + (((size_t)(r + t / 3) * PW + c + t % 3) * C + cg * 8) * 2));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_elementwise_fma(float2_t{(float)h8[2 * q], (float)h8[2 * q + 1]}, wt[t][q], acc[q]);
+            }
+            const size_t off = ((b * H + yo) * (size_t)W + xo) * C + cg * 8;
+            half8_t rr = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (res) rr = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(res + off));
+            half8_t o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[2 * q] = (_Float16)(acc[q].x + (float)rr[2 * q] + bl[cg * 8 + 2 * q]);
+                o[2 * q + 1] = (_Float16)(acc[q].y + (float)rr[2 * q + 1] + bl[cg * 8 + 2 * q + 1]);
+            }
+            *reinterpret_cast<uint4*>(out + off) = __builtin_bit_cast(uint4, o);
+        }
+    }
+}
+
+template <int C, int TH, int TW>
+int launch_posemb(avx_ctx* ctx, const void* v, const float* w1, const float* w2, const void* res, const float* bias, void* out, int B, int H, int W, hipStream_t s) {
+    const size_t lds = sizeof(float) * (2 * 9 * C + C) + (size_t)(TH + 2) * (TW + 2) * C * 2;
+    const long total = (long)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const long cap = (long)ctx->num_cus * (lds > 40 * 1024 ? 3 : 5);
+    auto k = k_mst_posemb<C, TH, TW>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kT), lds, s, (const __half*)v, w1, w2, (const __half*)res, bias, (__half*)out, B, H, W);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 template <int C>
 int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
     constexpr int KS = C / 8, HD = C / 32;
@@ -724,6 +849,20 @@ int avx_mst_conv3x3_add(avx_ctx* ctx, const void* x, const void* wpack, const vo
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, (const __half*)add, (__half*)out, B, H, W);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
+}
+
+int avx_mst_posemb(avx_ctx* ctx, const void* v, const float* w1_c9, const float* w2_c9, const void* residual, const float* bias, void* out, int B, int H, int W,
+                   int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, v && w1_c9 && w2_c9 && out && B > 0 && H > 0 && W > 0, "avx_mst_posemb: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_posemb: C=%d (32, 64 or 128)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)v | (uintptr_t)residual | (uintptr_t)out)) & 15u) == 0, "avx_mst_posemb: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, v != out, "avx_mst_posemb: in-place convolution is not possible");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    if (C == 32) return launch_posemb<32, 8, 32>(ctx, v, w1_c9, w2_c9, residual, bias, out, B, H, W, s);
+    if (C == 64) return launch_posemb<64, 8, 16>(ctx, v, w1_c9, w2_c9, residual, bias, out, B, H, W, s);
+    return launch_posemb<128, 4, 16>(ctx, v, w1_c9, w2_c9, residual, bias, out, B, H, W, s);
 }
 
 }  // extern "C"

@@ -94,6 +94,7 @@ class _AvxOps:
         self.enabled = os.environ.get("AVX_MST_TORCH_ONLY", "") == ""
         self._mfma = os.environ.get("AVX_MST_NO_MFMA", "") == ""  # A/B: the fused matrix-core kernels of csrc/mst_mfma.hip
         self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
+        self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
         self._ctx = {}
 
     def ctx(self, device: torch.device):
@@ -161,6 +162,19 @@ class _AvxOps:
         out = torch.empty((rows, 4 * c), dtype=torch.float16, device=x2.device)
         ctx._check(lib.avx_mst_ln_gemm_gelu(ctx._h, x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, wpack.data_ptr(), rows, c, out.data_ptr(),
                                             torch.cuda.current_stream(x2.device).cuda_stream))
+        return out
+
+    def posemb(self, v: torch.Tensor, w1_c9: torch.Tensor, w2_c9: torch.Tensor, residual: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
+        """dw3x3(gelu(dw3x3(v))) + residual + bias on (b, h, w, c) float16 in one pass (csrc/mst_mfma.hip::k_mst_posemb)."""
+        from .._lib import lib
+
+        b, h, w, c = v.shape
+        v = v.contiguous()
+        residual = residual.contiguous() if residual is not None else None
+        out = torch.empty_like(v)
+        ctx = self.ctx(v.device)
+        ctx._check(lib.avx_mst_posemb(ctx._h, v.data_ptr(), w1_c9.data_ptr(), w2_c9.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                      bias.data_ptr() if bias is not None else None, out.data_ptr(), b, h, w, c, torch.cuda.current_stream(v.device).cuda_stream))
         return out
 
     def conv3x3(self, x: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:
@@ -381,7 +395,13 @@ class MSTPlusPlus(torch.nn.Module):
             bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
             vi = v.reshape(b, h, w, c)
             # the block's `msa(x) + x` (:183): pos_emb's second conv adds x and the bias, the projection GEMM accumulates onto it in place
-            pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False, residual=x, bias=bias32)
+            if _AVX._posemb:
+                k1, k2 = p + ".pos_emb.0.weight", p + ".pos_emb.2.weight"
+                w91 = self._prep(k1 + ".c9f32", lambda: self._w(k1, (0,)).reshape(c, 9).float().contiguous())
+                w92 = self._prep(k2 + ".c9f32", lambda: self._w(k2, (0,)).reshape(c, 9).float().contiguous())
+                pe = _AVX.posemb(vi, w91, w92, x, bias32)
+            else:
+                pe = self._dw(self._dw(vi, p + ".pos_emb.0.weight", gelu=True), p + ".pos_emb.2.weight", gelu=False, residual=x, bias=bias32)
             for i in range(b):
                 _AVX.rowgemm_add(v[i], _AVX.attn_pack(gram[i], nq[i], nk[i], resc, wpt), pe[i].reshape(n, c))
             return pe

@@ -350,6 +350,11 @@ int avx_mst_attn_pack(avx_ctx* ctx, const float* gram, const float* nq, const fl
  * (:199, :228 with its `+ x`) and conv_out (:277, :291).  wpack: 9 taps x (C x C) in fragment order. */
 int avx_mst_conv3x3_add(avx_ctx* ctx, const void* x, const void* wpack, const void* add, void* out, int B, int H, int W, int C, void* stream);
 
+/* MS_MSA's pos_emb (:104-106: depthwise 3x3 -> GELU -> depthwise 3x3) in one pass, + residual + bias[c] (both optional):
+ * out = dw2(gelu(dw1(v))) + residual + bias on B x H x W x C float16 (C = 32, 64, 128); taps C x 9 float32. */
+int avx_mst_posemb(avx_ctx* ctx, const void* v, const float* w1_c9, const float* w2_c9, const void* residual, const float* bias, void* out, int B,
+                   int H, int W, int C, void* stream);
+
 /* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
  * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
 int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, void* stream);
