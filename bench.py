@@ -213,7 +213,7 @@ def main():
     achieved = alg_bytes / launch_s / 1e9
     if mst is not None:
         roof = {"bound": "mfma", "achieved": round(MSTPP_FLOP_PER_PX * B * H * W / launch_s / 1e12, 2), "peak": MFMA_FP16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "traffic": None, "kernel": "MST++ forward (torch, fp16) + honeybee tail, per step",
+                "unit": "TFLOP/s", "traffic": None, "kernel": "MST++ forward (fused MFMA block kernels, fp16) + honeybee tail, per step",
                 "us_per_launch": round(launch_s * 1e6, 2)}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 5)
     else:
@@ -306,6 +306,21 @@ def main():
             _, want = cpu_fn(None)
             err = np.abs(got.transpose(1, 2, 0) - want)
             result["parity_checked"] = bool(err.max() <= 1e-4 * max(1.0, float(np.abs(want).max())))
+        elif mst is not None:
+            # the tail after the network, checked on the network's own cube (the forward pass itself is pinned against the
+            # reference module's outputs in tests/test_mstpp.py): one more frame, cube downloaded, oracle tail on the CPU
+            import torch
+
+            cube = mst.predict_device_nhwc(t_in[0])
+            op32.run_device(None, DeviceBuffer(ctx, t_out[0].data_ptr(), t_out[0].numel(), owned=False), 1, H, W,
+                            hsi_ptr=cube.data_ptr(), hsi_layout=0, hsi_dtype=1, stream=stream)
+            torch.cuda.synchronize()
+            hsi = cube[..., :31].float().cpu().numpy().reshape(H, W, 31)
+            lam = np.linspace(400.0, 700.0, 31, dtype=np.float32)
+            want, _ = cpu_ref.honeybee_tail(*cpu_ref.honeybee_catches(hsi, lam), np.uint8)
+            dd = np.abs(t_out[0].cpu().numpy().astype(np.int16) - want.astype(np.int16))
+            result["parity_checked"] = bool(dd.max() <= 1 and (dd > 0).mean() < 5e-3)
+            result["parity_stats"] = {"max": int(dd.max()), "frac_ne": float((dd > 0).mean()), "what": "honeybee tail on the device's own MST++ cube vs oracle tail"}
         elif mst is None:
             if uvsp and species != "mantis":
                 got = ctx.download(plan.d_out, pool[0].shape, np.uint8)[None]
