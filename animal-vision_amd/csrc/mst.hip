@@ -128,7 +128,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // an fp16 ulp of the output), one v_exp + one v_rcp instead of libm's erff polynomial ladder
 __device__ __forceinline__ float gelu_erf_h(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float e = 1.0f - poly * __expf(-z * z);
     return 0.5f * x * (1.0f + (x < 0.f ? -e : e));

@@ -1,0 +1,43 @@
+#!/bin/bash
+# PMC passes over the MST++ route (separate runs per counter group; --pmc only, no trace domains): per-kernel means.
+set -o pipefail
+export TMPDIR=/tmp
+mkdir -p gpurun_out/pmc_mst
+i=0
+while read -r group; do
+  [ -z "$group" ] && continue
+  i=$((i+1))
+  rm -rf gpurun_out/pmc_mst/p$i
+  timeout -k 10 300 rocprofv3 --pmc $group --output-format csv -d gpurun_out/pmc_mst/p$i -- python bench.py --workload ${WL:-honeybee_mst_1080p} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc_mst/p$i.out 2> gpurun_out/pmc_mst/p$i.err || { tail -3 gpurun_out/pmc_mst/p$i.err; }
+done <<GROUPS
+SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_INST_ANY
+SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS
+TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TA_BUSY TA_FLAT_READ_WAVEFRONTS TA_FLAT_WRITE_WAVEFRONTS
+GROUPS
+python - <<'PY' | tee gpurun_out/pmc_mst/summary.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    # steady state: keep the last third of the dispatches of each kernel
+    byk = collections.defaultdict(list)
+    for r in rows:
+        byk[r["Kernel_Name"]].append(r)
+    for k, rs in byk.items():
+        if "k_mst_" not in k and "k_dwconv" not in k:
+            continue
+        ids = sorted({int(r["Dispatch_Id"]) for r in rs})
+        keep = set(ids[len(ids) * 2 // 3:])
+        name = k.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        for r in rs:
+            if int(r["Dispatch_Id"]) in keep:
+                agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(agg):
+    d = agg[k]
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    print("==", k)
+    print("   " + "  ".join(f"{c}={m[c]:.4g}" for c in sorted(m)))
+    if "SQ_BUSY_CYCLES" in m and "SQ_ACTIVE_INST_VALU" in m:
+        print(f"   VALU active / wave-cycles-per-SIMD: {m['SQ_ACTIVE_INST_VALU'] / max(m.get('SQ_WAVE_CYCLES', 1), 1):.3f}")
+PY
