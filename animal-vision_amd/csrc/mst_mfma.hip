@@ -281,8 +281,8 @@ __global__ __launch_bounds__(kT) void k_mst_ffn1(const __half* __restrict__ x, c
 //            the pre-packed W2 fragments, then + residual, float16, 32 contiguous bytes per lane.
 // The (N x 4C) GELU output never reaches memory.
 
-template <int C, int ROWS, int PXT, bool PF>
-__global__ __launch_bounds__(kT, PF ? 2 : 3) void k_mst_ffn2(const __half* __restrict__ hid /*[B][H][W][4C]*/, const float* __restrict__ w9 /*[4C][9]*/,
+template <int C, int ROWS, int PXT, bool PF, int MINW>
+__global__ __launch_bounds__(kT, MINW) void k_mst_ffn2(const __half* __restrict__ hid /*[B][H][W][4C]*/, const float* __restrict__ w9 /*[4C][9]*/,
                                                     const uint2* __restrict__ w2pack /*[C/32][4C/8][64]*/, const __half* res /*[B][H][W][C]*/,
                                                     __half* out /*may alias res*/, int B, int H, int W) {
     constexpr int C4 = 4 * C, CV = C4 / 8, PXS = kT / CV, TW = 32 * PXT, IPT = TW / PXS, KS2 = C4 / 8, NT = C / 32;
@@ -750,13 +750,13 @@ int launch_ffn1(avx_ctx* ctx, const void* x, const float* gamma, const float* be
     return AVX_OK;
 }
 
-template <int C, int ROWS, int PXT, bool PF>
+template <int C, int ROWS, int PXT, bool PF, int MINW>
 int launch_ffn2(avx_ctx* ctx, const void* hid, const float* w9, const void* w2pack, const void* res, void* out, int B, int H, int W, hipStream_t s) {
     constexpr int C4 = 4 * C, KS2 = C4 / 8, NT = C / 32, PITCH = C4 * 2 + 16;
     const size_t lds = (size_t)NT * KS2 * 64 * sizeof(uint2) + sizeof(float) * 9 * C4 + (size_t)ROWS * 32 * PXT * PITCH;
     const long total = (long)B * ((H + ROWS - 1) / ROWS) * ((W + 32 * PXT - 1) / (32 * PXT));
-    const long cap = (long)ctx->num_cus * (PF ? 2 : 3);  // resident workgroups per CU (registers / LDS)
-    auto k = k_mst_ffn2<C, ROWS, PXT, PF>;
+    const long cap = (long)ctx->num_cus * MINW;  // resident workgroups per CU (registers / LDS)
+    auto k = k_mst_ffn2<C, ROWS, PXT, PF, MINW>;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kT), lds, s, (const __half*)hid, w9, (const uint2*)w2pack, (const __half*)res,
                        (__half*)out, B, H, W);
@@ -805,8 +805,8 @@ int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, con
     AVX_REQUIRE(ctx, hidden != out, "avx_mst_dw_gemm_add: the hidden tensor cannot be the output (the residual can)");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
-    if (C == 32) return launch_ffn2<32, 2, 2, false>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
-    return launch_ffn2<64, 2, 1, true>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
+    if (C == 32) return launch_ffn2<32, 2, 2, false, 3>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
+    return launch_ffn2<64, 2, 1, true, 2>(ctx, hidden, w_c9, w2pack, residual, out, B, H, W, s);
 }
 
 int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const void* a2, const void* wpack2, const void* add, void* out, size_t rows, int C,
