@@ -121,7 +121,6 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
     const size_t frame_bytes = (size_t)a.H * a.W * 3;
     const uint8_t* fin = a.in + frame_bytes * f;
     uint8_t* fout = a.out + frame_bytes * f;
-    const uint8_t* const in_end = a.in + frame_bytes * a.n_frames;
     const int gx0 = xs - R > 0 ? xs - R : 0;
     const int gx1 = xs + vw + R < a.W ? xs + vw + R : a.W;
     const int row_bytes = (gx1 - gx0) * 3;
@@ -135,6 +134,14 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
     }
     for (int i = tid; i < 1024; i += kMarchThreads) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
     if (tid <= R) ktab[tid] = taps.k[R + tid];  // symmetric taps, by distance from the centre
+    // The colour constants live in LDS (read per decode item), not in 30 SGPRs for the whole kernel: the scalar register file
+    // was spilling through v_readlane (90 spilled SGPRs, 22 % of the main loop's VALU instructions were v_readlane_b32).
+    float* cmf = reinterpret_cast<float*>(smem_raw + C::off_ktab + 16 * sizeof(T));         // [12]: M[9], alpha, 1 - alpha
+    double* cbk = reinterpret_cast<double*>(smem_raw + C::off_ktab + 16 * sizeof(T) + 64);  // [9] (cat only)
+    if (tid < 9) cmf[tid] = a.M[tid];
+    if (tid == 9) cmf[9] = a.alpha;
+    if (tid == 10) cmf[10] = a.one_minus_alpha;
+    if constexpr (COLOR != AVX_COLOR_MATRIX) { if (tid < 9) cbk[tid] = a.Bk[tid]; }
     __syncthreads();
     P kk[R + 1];  // taps, splat into both halves, in VGPRs (via LDS: as SGPRs they spill through v_readlane)
 #pragma unroll
@@ -147,9 +154,9 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
     // ---- raw row loads: (row, 64-dword segment) units dealt to waves; row math is scalar ---------
     constexpr int NSEG = (C::DPR + 63) / 64;
     constexpr int NLD = (SY * NSEG + NWAVES - 1) / NWAVES;
-    // aligned dwords that contain a valid byte never cross the end of the batch when the batch size is a
-    // multiple of 4 bytes (every standard video size): no tail guard needed then (uniform for the launch)
-    const bool tail_safe = (((frame_bytes * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) == 0;
+    // The host only launches this kernel on batches whose byte size and base address are multiples of 4 (every standard
+    // video size): aligned dwords that contain a valid byte then never cross the end of the batch, and no tail guard is
+    // needed.  (The guarded path used to live here too; its scalar bookkeeping alone spilled 14 SGPRs through v_readlane.)
     uint8_t* rowshift = smem_raw + C::off_ktab + 48 * sizeof(T);  // [2][SY] raw-row misalignments, by iteration parity
     auto row_base = [&](int t, int s, uint32_t& shift) -> const uint8_t* {
         int y = ys - R + t * SY + s;
@@ -171,26 +178,10 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
             const uint8_t* base = row_base(t, s < SY ? s : 0, shift);
             const int d = seg * 64 + lane;
             ptr[n] = base + (size_t)d * 4;
-            ok[n] = s < SY && d * 4 < (int)shift + row_bytes && (tail_safe || ptr[n] + 4 <= in_end);
+            ok[n] = s < SY && d * 4 < (int)shift + row_bytes;
         }
 #pragma unroll
         for (int n = 0; n < NLD; ++n) rv[n] = ok[n] ? *reinterpret_cast<const uint32_t*>(ptr[n]) : 0u;
-        if (!tail_safe) {  // the one dword that straddles the end of the batch: assemble its valid bytes
-#pragma unroll
-            for (int n = 0; n < NLD; ++n) {
-                const int u = wave + n * NWAVES;
-                const int s = u / NSEG, seg = u - s * NSEG;
-                uint32_t shift;
-                (void)row_base(t, s < SY ? s : 0, shift);
-                const int d = seg * 64 + lane;
-                if (s < SY && d * 4 < (int)shift + row_bytes && ptr[n] + 4 > in_end) {
-                    uint32_t v = 0;
-                    for (int bb = 0; bb < 4; ++bb)
-                        if (ptr[n] + bb < in_end) v |= (uint32_t)ptr[n][bb] << (8 * bb);
-                    rv[n] = v;
-                }
-            }
-        }
     };
     auto write_raw = [&](int t, const uint32_t (&rv)[NLD]) {
         uint8_t* RAW = RAW_of(t);
@@ -281,6 +272,11 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
             }
             P o[3][4];
             using F2 = typename Pair<float>::type;
+            float M[12];
+            {
+                const float4 m0 = reinterpret_cast<const float4*>(cmf)[0], m1 = reinterpret_cast<const float4*>(cmf)[1], m2 = reinterpret_cast<const float4*>(cmf)[2];
+                M[0] = m0.x; M[1] = m0.y; M[2] = m0.z; M[3] = m0.w; M[4] = m1.x; M[5] = m1.y; M[6] = m1.z; M[7] = m1.w; M[8] = m2.x; M[9] = m2.y; M[10] = m2.z; M[11] = m2.w;
+            }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 F2 c0, c1, c2;
@@ -294,21 +290,21 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
                     c2 = F2{lut[code[0][p][2]], lut[code[1][p][2]]};
                 }
                 // out_i = fma(c2, M[i][2], fma(c1, M[i][1], c0*M[i][0]))   (dog.py:47 as an FMA chain)
-                const F2 l = pfma(c2, F2{a.M[2], a.M[2]}, pfma(c1, F2{a.M[1], a.M[1]}, c0 * F2{a.M[0], a.M[0]}));
-                const F2 m = pfma(c2, F2{a.M[5], a.M[5]}, pfma(c1, F2{a.M[4], a.M[4]}, c0 * F2{a.M[3], a.M[3]}));
-                const F2 sv = pfma(c2, F2{a.M[8], a.M[8]}, pfma(c1, F2{a.M[7], a.M[7]}, c0 * F2{a.M[6], a.M[6]}));
+                const F2 l = pfma(c2, F2{M[2], M[2]}, pfma(c1, F2{M[1], M[1]}, c0 * F2{M[0], M[0]}));
+                const F2 m = pfma(c2, F2{M[5], M[5]}, pfma(c1, F2{M[4], M[4]}, c0 * F2{M[3], M[3]}));
+                const F2 sv = pfma(c2, F2{M[8], M[8]}, pfma(c1, F2{M[7], M[7]}, c0 * F2{M[6], M[6]}));
                 if constexpr (COLOR == AVX_COLOR_MATRIX) {
                     o[0][p] = P{(T)l.x, (T)l.y};
                     o[1][p] = P{(T)m.x, (T)m.y};
                     o[2][p] = P{(T)sv.x, (T)sv.y};
                 } else {
-                    const F2 lm = F2{a.alpha, a.alpha} * l + F2{a.one_minus_alpha, a.one_minus_alpha} * m;  // mul, mul, add (cat.py:99)
+                    const F2 lm = F2{M[9], M[9]} * l + F2{M[10], M[10]} * m;  // mul, mul, add (cat.py:99)
                     using D2 = typename Pair<double>::type;
                     const D2 dlm = D2{(double)lm.x, (double)lm.y}, ds = D2{(double)sv.x, (double)sv.y};
 #pragma unroll
                     for (int cc = 0; cc < 3; ++cc) {
-                        const D2 r = pfma(ds, D2{a.Bk[3 * cc + 2], a.Bk[3 * cc + 2]},
-                                          pfma(dlm, D2{a.Bk[3 * cc + 1], a.Bk[3 * cc + 1]}, dlm * D2{a.Bk[3 * cc], a.Bk[3 * cc]}));
+                        const double b0 = cbk[3 * cc], b1 = cbk[3 * cc + 1], b2 = cbk[3 * cc + 2];
+                        const D2 r = pfma(ds, D2{b2, b2}, pfma(dlm, D2{b1, b1}, dlm * D2{b0, b0}));
                         o[cc][p] = P{(T)r.x, (T)r.y};
                     }
                 }
@@ -600,6 +596,9 @@ static int march_dispatch(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_de
 }
 
 int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, hipStream_t s) {
+    // The kernel reads rows as aligned dwords without a tail guard: batches whose byte size or base address is not a multiple
+    // of 4 (no standard video size) take the 2-D tiled / reference kernels instead.
+    if (((((size_t)a.H * a.W * 3 * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) != 0) return AVX_ERR_UNSUPPORTED;
     // Workgroup width: 192 threads (NG = 64) or 384 (NG = 128).  Which is faster depends on the radius, the element type
     // and the batch geometry (cat: 64; dog: 128; wolf at 1080p: 64 by 13 %), so like the row split it is measured on the
     // first call per (radius, type, batch, frame size) and remembered.  AVX_MARCH_NG=64|128 pins it.
