@@ -2,6 +2,7 @@
 // Nothing here exists in the reference (pure Python, no device runtime: SURVEY.md 2.1); it is the
 // plumbing under the C ABI of include/avx.h.
 #include "avx_internal.h"
+#include "dichromat_common.h"
 #include "srgb_tables.h"
 
 static char g_init_err[512] = "";
@@ -101,17 +102,17 @@ int avx_init(int device, avx_ctx** out_ctx) {
     // Bucket tables for the quantiser: pure bit logic on the threshold tables above.
     for (int which = 0; which < 2; ++which) {
         uint64_t tb[255];
-        const int shift = which == 0 ? 17 : 46;
+        const int shift = which == 0 ? avxk::kCoarseShiftF32 : avxk::kCoarseShiftF64;
         for (int i = 0; i < 255; ++i) tb[i] = which == 0 ? (uint64_t)kEncThrF32Bits[i] : kEncThrF64Bits[i];
         const uint64_t one_bits = which == 0 ? 0x3f800000ull : 0x3ff0000000000000ull;
         const uint32_t lo = (uint32_t)(tb[0] >> shift), hi = (uint32_t)(one_bits >> shift);
         const uint32_t n = hi - lo + 1;
-        if (n > 1024) {
+        if (n > (uint32_t)avxk::kCoarseTableBytes) {
             avx_fail(nullptr, AVX_ERR_INVALID, "avx_init: quantiser bucket table too large (%u)", n);
             delete ctx;
             return AVX_ERR_INVALID;
         }
-        uint8_t table[1024];
+        uint8_t table[avxk::kCoarseTableBytes];
         int n_fix = 0;
         for (uint32_t k = 0; k < n; ++k) {
             // non-negative IEEE floats order like their bit patterns
@@ -125,8 +126,8 @@ int avx_init(int device, avx_ctx** out_ctx) {
             if (inside > n_fix) n_fix = inside;
         }
         uint8_t** dst = which == 0 ? &ctx->d_coarse_f32 : &ctx->d_coarse_f64;
-        INIT_HIP(hipMalloc((void**)dst, 1024));
-        INIT_HIP(hipMemset(*dst, 0, 1024));
+        INIT_HIP(hipMalloc((void**)dst, avxk::kCoarseTableBytes));
+        INIT_HIP(hipMemset(*dst, 0, avxk::kCoarseTableBytes));
         INIT_HIP(hipMemcpy(*dst, table, n, hipMemcpyHostToDevice));
         ctx->coarse_lo_key[which] = lo;
         ctx->coarse_n_keys[which] = n;

@@ -39,7 +39,7 @@ struct avx_ctx {
     // bucketed quantiser (csrc/dichromat.hip quantize_coarse): per top-bits bucket, #thresholds <= bucket start
     uint8_t* d_coarse_f32 = nullptr;
     uint8_t* d_coarse_f64 = nullptr;
-    uint32_t coarse_lo_key[2] = {0, 0};  // [0] f32 (bits >> 17), [1] f64 (bits >> 46)
+    uint32_t coarse_lo_key[2] = {0, 0};  // [0] f32 (bits >> 16), [1] f64 (bits >> 45): dichromat_common.h
     uint32_t coarse_n_keys[2] = {0, 0};
     int coarse_n_fix[2] = {0, 0};
     // Per-stream workspaces: launches on different streams may be in flight together (pipeline.py keeps

@@ -229,8 +229,8 @@ struct TileCfg {
     static constexpr int COL_UNITS = (TW / CX) * (TH / SY);
     static constexpr size_t off_thr = 0;                                   // T[256]
     static constexpr size_t off_lut = off_thr + 256 * sizeof(T);           // float[256]
-    static constexpr size_t off_coarse = off_lut + 256 * sizeof(float);    // uint8[1024]
-    static constexpr size_t off_ktab = off_coarse + 1024;                  // T[64]: taps by distance from the centre
+    static constexpr size_t off_coarse = off_lut + 256 * sizeof(float);    // uint8[kCoarseTableBytes]
+    static constexpr size_t off_ktab = off_coarse + kCoarseTableBytes;                  // T[64]: taps by distance from the centre
     static constexpr size_t off_A = off_ktab + 64 * sizeof(T);
     static constexpr size_t off_B = off_A + (size_t)3 * AH * PA * sizeof(T);
     static constexpr size_t off_raw = off_B + (size_t)AH * PB * sizeof(T) + 64;  // +64: window overrun of the last B/A row
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT) void dichromat_tiled_kernel(DichromatArgs a, Ta
         thr[i] = reinterpret_cast<const T*>(a.enc_thr)[i];
         lut[i] = a.decode_lut[i];
     }
-    for (int i = tid; i < 1024; i += NT) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
+    for (int i = tid; i < kCoarseTableBytes; i += NT) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
     T* ktab = reinterpret_cast<T*>(smem_raw + C::off_ktab);
     if (tid <= R) ktab[tid] = taps.k[R + tid];  // Gaussian taps are symmetric: k[R-d] == k[R+d] bit for bit
     __syncthreads();
@@ -668,7 +668,7 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
         const int rc = avx_launch_dichromat_march(ctx, a, d, cat, s);
         if (rc != AVX_ERR_UNSUPPORTED) return rc;
     }
-    constexpr int NF = 2;
+    constexpr int NF = kCoarseNFix;
     if (!cat) {
         if (use_tiled) {
             AVX_REQUIRE(ctx, ctx->coarse_n_fix[0] <= NF, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[0], NF);

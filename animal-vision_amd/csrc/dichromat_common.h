@@ -64,8 +64,11 @@ struct QuantCoarse {
     int n_fix;             // max thresholds strictly inside one bucket (refinement steps)
 };
 
-__device__ __forceinline__ uint32_t key_of(float v) { return __float_as_uint(v) >> 17; }
-__device__ __forceinline__ uint32_t key_of(double v) { return (uint32_t)(__double_as_longlong(v) >> 46); }
+// Bucket key = sign/exponent + the top 7 mantissa bits: 1,634 buckets between the first threshold and 1.0 (a 2 KiB table in
+// LDS), at most ONE encode threshold strictly inside a bucket, so one refinement compare suffices (6 bits: 818 buckets, two).
+constexpr int kCoarseShiftF32 = 16, kCoarseShiftF64 = 45, kCoarseTableBytes = 2048, kCoarseNFix = 1;
+__device__ __forceinline__ uint32_t key_of(float v) { return __float_as_uint(v) >> kCoarseShiftF32; }
+__device__ __forceinline__ uint32_t key_of(double v) { return (uint32_t)(__double_as_longlong(v) >> kCoarseShiftF64); }
 
 // out = #{k : thr[k] <= clip(v,0,1)} via a bucket table on the float's top bits + <= NFIX refinements.
 template <typename T, int NFIX>

@@ -56,7 +56,7 @@ struct MarchCfg {
     static constexpr size_t off_thr = 0;
     static constexpr size_t off_lut = off_thr + 256 * sizeof(T);
     static constexpr size_t off_coarse = off_lut + 256 * sizeof(float);
-    static constexpr size_t off_ktab = off_coarse + 1024;
+    static constexpr size_t off_ktab = off_coarse + kCoarseTableBytes;
     static constexpr size_t off_A = off_ktab + 64 * sizeof(T);
     // Every row buffer exists twice: one barrier per iteration (see the main loop).
     static constexpr size_t A_bytes = (size_t)SY * 3 * PA * sizeof(T) + 64;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
         thr[i] = reinterpret_cast<const T*>(a.enc_thr)[i];
         lut[i] = a.decode_lut[i];
     }
-    for (int i = tid; i < 1024; i += kMarchThreads) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
+    for (int i = tid; i < kCoarseTableBytes; i += kMarchThreads) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
     if (tid <= R) ktab[tid] = taps.k[R + tid];  // symmetric taps, by distance from the centre
     // The colour constants live in LDS (read per decode item), not in 30 SGPRs for the whole kernel: the scalar register file
     // was spilling through v_readlane (90 spilled SGPRs, 22 % of the main loop's VALU instructions were v_readlane_b32).
@@ -572,7 +572,7 @@ void avx_march_seed_tuned(avx_ctx* ctx) {
 }
 
 static int march_dispatch(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, bool f64_cat, bool ng64, hipStream_t s) {
-    constexpr int NF = 2;
+    constexpr int NF = kCoarseNFix;
     const int w = f64_cat ? 1 : 0;
     AVX_REQUIRE(ctx, ctx->coarse_n_fix[w] <= NF, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[w], NF);
     QuantCoarse qc{f64_cat ? ctx->d_coarse_f64 : ctx->d_coarse_f32, ctx->coarse_lo_key[w], ctx->coarse_n_keys[w], ctx->coarse_n_fix[w]};

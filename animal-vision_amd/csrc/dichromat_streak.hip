@@ -85,13 +85,13 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
     uint8_t* outb = reinterpret_cast<uint8_t*>(smem_f + (size_t)6 * PW);  // W*3 bytes (+ pad)
     __shared__ float lut[256];
     __shared__ float thr[256];
-    __shared__ uint8_t coarse[1024];
+    __shared__ uint8_t coarse[kCoarseTableBytes];
     __shared__ float t1[16], td1[20], td2[20];
     __shared__ int idx1[3][16];
     const int tid = threadIdx.x;
     if constexpr (!PLANES) {
         for (int i = tid; i < 256; i += kST) { lut[i] = a.decode_lut[i]; thr[i] = reinterpret_cast<const float*>(a.enc_thr)[i]; }
-        for (int i = tid; i < 1024; i += kST) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
+        for (int i = tid; i < kCoarseTableBytes; i += kST) coarse[i] = i < (int)qc.n_keys ? qc.table[i] : (uint8_t)0;
     }
     const size_t frame_bytes = (size_t)a.H * a.W * 3;
     const int total_rows = a.n_frames * a.H;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
                 v[2] = gray + (v[2] - gray) * a.chroma_keep;
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) outb[3 * x + c] = (uint8_t)quantize_coarse<float, 2>(v[c], thr, coarse, qc.lo_key);
+            for (int c = 0; c < 3; ++c) outb[3 * x + c] = (uint8_t)quantize_coarse<float, kCoarseNFix>(v[c], thr, coarse, qc.lo_key);
         }
         __syncthreads();
         if ((((uintptr_t)dst | (uintptr_t)n3) & 3u) == 0) {
@@ -194,7 +194,7 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
     AVX_REQUIRE(ctx, d->streak_rows_host != nullptr && d->streak_stride >= 48, "avx_dichromat_u8: streak tables missing (stride >= 48)");
     const int PW = ((a.W + 3) / 4 * 4) + 2 * 16;
     const size_t lds = sizeof(float) * (size_t)PW * 6 + (((size_t)a.W * 3 + 15) & ~(size_t)15);
-    AVX_REQUIRE(ctx, ctx->coarse_n_fix[0] <= 2, "quantiser needs %d refinements, kernel built for 2", ctx->coarse_n_fix[0]);
+    AVX_REQUIRE(ctx, ctx->coarse_n_fix[0] <= kCoarseNFix, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[0], kCoarseNFix);
     QuantCoarse qc{ctx->d_coarse_f32, ctx->coarse_lo_key[0], ctx->coarse_n_keys[0], ctx->coarse_n_fix[0]};
     AVX_REQUIRE(ctx, lds <= 150 * 1024, "avx_dichromat_u8: frame width %d too large for the streak kernel (row must fit LDS)", a.W);
     const size_t tbytes = sizeof(float) * (size_t)a.H * d->streak_stride;

@@ -56,12 +56,12 @@ __device__ __forceinline__ float acc_merge(int kind, float a, float b) { return 
 template <int NREG, int PX>
 __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
     __shared__ float thr[256];
-    __shared__ uint8_t coarse[1024];
+    __shared__ uint8_t coarse[kCoarseTableBytes];
     __shared__ float red[kET / 64];
     const int tid = threadIdx.x;
     if (a.uses_encode) {
         for (int i = tid; i < 256; i += kET) thr[i] = a.thr[i];
-        for (int i = tid; i < 1024; i += kET) coarse[i] = a.coarse[i];
+        for (int i = tid; i < kCoarseTableBytes; i += kET) coarse[i] = a.coarse[i];
         __syncthreads();
     }
     float R0[NREG], R1[NREG], R2[NREG], R3[NREG], R4[NREG], R5[NREG], R6[NREG], R7[NREG];  // R4..R7 vanish when PX == 4
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
                         EW_FOR if (valid[k]) ((float*)p.ptr)[(size_t)ii[k] * p.stride] = xs[k];
                     } else {
 #pragma unroll
-                        EW_FOR if (valid[k]) ((uint8_t*)p.ptr)[(size_t)ii[k] * p.stride] = (uint8_t)quantize_coarse<float, 2>(xs[k], thr, coarse, a.lo_key);
+                        EW_FOR if (valid[k]) ((uint8_t*)p.ptr)[(size_t)ii[k] * p.stride] = (uint8_t)quantize_coarse<float, kCoarseNFix>(xs[k], thr, coarse, a.lo_key);
                     }
                     continue;
                 }

@@ -42,13 +42,13 @@ __device__ __forceinline__ float l2s_f(float l) {  // uv_helpers.linear_to_srgb 
 __global__ __launch_bounds__(kMT) void k_encode_hwc(const float* __restrict__ in, size_t n3, const float* __restrict__ thr_g, const uint8_t* __restrict__ coarse_g,
                                                     uint32_t lo_key, uint8_t* __restrict__ out, float* __restrict__ out_f = nullptr) {
     __shared__ float thr[256];
-    __shared__ uint8_t coarse[1024];
+    __shared__ uint8_t coarse[kCoarseTableBytes];
     for (int i = threadIdx.x; i < 256; i += kMT) thr[i] = thr_g[i];
-    for (int i = threadIdx.x; i < 1024; i += kMT) coarse[i] = coarse_g[i];
+    for (int i = threadIdx.x; i < kCoarseTableBytes; i += kMT) coarse[i] = coarse_g[i];
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n3; i += (size_t)gridDim.x * kMT) {
         if (out_f) out_f[i] = l2s_f(clip01f(in[i]));
-        else out[i] = (uint8_t)quantize_coarse<float, 2>(in[i], thr, coarse, lo_key);
+        else out[i] = (uint8_t)quantize_coarse<float, kCoarseNFix>(in[i], thr, coarse, lo_key);
     }
 }
 
@@ -203,9 +203,9 @@ struct FinishArgs { const float* P; const float* periph; int H, W; const float* 
 // :268-278: radial sigmoid blend with the blurred copy, then encode
 __global__ __launch_bounds__(kMT) void k_finish(FinishArgs a) {
     __shared__ float thr[256];
-    __shared__ uint8_t coarse[1024];
+    __shared__ uint8_t coarse[kCoarseTableBytes];
     for (int i = threadIdx.x; i < 256; i += kMT) thr[i] = a.thr[i];
-    for (int i = threadIdx.x; i < 1024; i += kMT) coarse[i] = a.coarse[i];
+    for (int i = threadIdx.x; i < kCoarseTableBytes; i += kMT) coarse[i] = a.coarse[i];
     __syncthreads();
     const size_t n = (size_t)a.H * a.W;
     for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < n; p += (size_t)gridDim.x * kMT) {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kMT) void k_finish(FinishArgs a) {
             float v = a.P[(size_t)c * n + p];
             if (a.do_periph) v = (1.0f - t) * v + t * a.periph[(size_t)c * n + p];
             if (a.out_f) a.out_f[p * 3 + c] = l2s_f(clip01f(v));
-            else a.out[p * 3 + c] = (uint8_t)quantize_coarse<float, 2>(v, thr, coarse, a.lo_key);
+            else a.out[p * 3 + c] = (uint8_t)quantize_coarse<float, kCoarseNFix>(v, thr, coarse, a.lo_key);
         }
     }
 }

@@ -521,9 +521,9 @@ __device__ __forceinline__ void purple_yellow_soft(float U, double p98, float ep
 
 __global__ __launch_bounds__(kT) void k_map_encode(MapArgs a) {
     __shared__ float thr[256];
-    __shared__ uint8_t coarse[1024];
+    __shared__ uint8_t coarse[kCoarseTableBytes];
     for (int i = threadIdx.x; i < 256; i += kT) thr[i] = a.enc_thr[i];
-    for (int i = threadIdx.x; i < 1024; i += kT) coarse[i] = a.coarse[i];
+    for (int i = threadIdx.x; i < kCoarseTableBytes; i += kT) coarse[i] = a.coarse[i];
     __syncthreads();
     const size_t n = a.n;
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kT) void k_map_encode(MapArgs a) {
                 const float l = rgb[c] < 0.f ? 0.f : (rgb[c] > 1.f ? 1.f : rgb[c]);
                 a.out_f[i * 3 + c] = l <= 0.0031308f ? l * 12.92f : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f;
             } else {
-                a.out[i * 3 + c] = (uint8_t)quantize_coarse<float, 2>(rgb[c], thr, coarse, a.lo_key);
+                a.out[i * 3 + c] = (uint8_t)quantize_coarse<float, kCoarseNFix>(rgb[c], thr, coarse, a.lo_key);
             }
         }
     }
