@@ -106,7 +106,7 @@ int avx_init(int device, avx_ctx** out_ctx) {
         for (int i = 0; i < 255; ++i) tb[i] = which == 0 ? (uint64_t)kEncThrF32Bits[i] : kEncThrF64Bits[i];
         const uint64_t one_bits = which == 0 ? 0x3f800000ull : 0x3ff0000000000000ull;
         const uint32_t lo = (uint32_t)(tb[0] >> shift), hi = (uint32_t)(one_bits >> shift);
-        const uint32_t n = hi - lo + 1;
+        const uint32_t n = hi - lo + 2;  // + the leading "below the first bucket" entry
         if (n > (uint32_t)avxk::kCoarseTableBytes) {
             avx_fail(nullptr, AVX_ERR_INVALID, "avx_init: quantiser bucket table too large (%u)", n);
             delete ctx;
@@ -114,7 +114,8 @@ int avx_init(int device, avx_ctx** out_ctx) {
         }
         uint8_t table[avxk::kCoarseTableBytes];
         int n_fix = 0;
-        for (uint32_t k = 0; k < n; ++k) {
+        table[0] = 0;
+        for (uint32_t k = 0; k + 1 < n; ++k) {
             // non-negative IEEE floats order like their bit patterns
             const uint64_t start = (uint64_t)(lo + k) << shift, next = (uint64_t)(lo + k + 1) << shift;
             int le = 0, inside = 0;
@@ -122,14 +123,14 @@ int avx_init(int device, avx_ctx** out_ctx) {
                 if (tb[i] <= start) ++le;
                 else if (tb[i] < next) ++inside;
             }
-            table[k] = (uint8_t)le;
+            table[k + 1] = (uint8_t)le;
             if (inside > n_fix) n_fix = inside;
         }
         uint8_t** dst = which == 0 ? &ctx->d_coarse_f32 : &ctx->d_coarse_f64;
         INIT_HIP(hipMalloc((void**)dst, avxk::kCoarseTableBytes));
         INIT_HIP(hipMemset(*dst, 0, avxk::kCoarseTableBytes));
         INIT_HIP(hipMemcpy(*dst, table, n, hipMemcpyHostToDevice));
-        ctx->coarse_lo_key[which] = lo;
+        ctx->coarse_lo_key[which] = lo - 1;  // index = max(key, lo - 1) - (lo - 1)
         ctx->coarse_n_keys[which] = n;
         ctx->coarse_n_fix[which] = n_fix;
     }

@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t quantize(T v, const T* __restrict__ thr) {
 
 struct QuantCoarse {
     const uint8_t* table;  // device: count of thresholds <= bucket start, per bucket
-    uint32_t lo_key;       // first bucket key (keys below it quantise to 0)
+    uint32_t lo_key;       // key just BEFORE the first bucket: table index = max(key, lo_key) - lo_key, entry 0 quantises to 0
     uint32_t n_keys;
     int n_fix;             // max thresholds strictly inside one bucket (refinement steps)
 };
@@ -74,8 +74,10 @@ __device__ __forceinline__ uint32_t key_of(double v) { return (uint32_t)(__doubl
 template <typename T, int NFIX>
 __device__ __forceinline__ uint32_t quantize_coarse(T v, const T* __restrict__ thr, const uint8_t* __restrict__ coarse, uint32_t lo_key) {
     v = v < (T)0 ? (T)0 : (v > (T)1 ? (T)1 : v);
+    // table[0] is the "below the first bucket" entry (0) and lo_key the key just before the first bucket: one max + one
+    // subtract, no branch around the lookup (a conditional load compiled to a divergent branch per sample)
     const uint32_t key = key_of(v);
-    uint32_t k = key < lo_key ? 0u : (uint32_t)coarse[key - lo_key];
+    uint32_t k = (uint32_t)coarse[(key > lo_key ? key : lo_key) - lo_key];
 #pragma unroll
     for (int i = 0; i < NFIX; ++i) k += (thr[k] <= v) ? 1u : 0u;  // thr[255] is a huge pad: never passes
     return k;
