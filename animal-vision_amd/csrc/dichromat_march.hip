@@ -103,6 +103,9 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
     auto A_of = [&](int t) { return reinterpret_cast<P*>(smem_raw + C::off_A + (size_t)(t & 1) * C::A_bytes); };
     auto RAW_of = [&](int t) { return smem_raw + C::off_raw + (size_t)(t & 1) * C::raw_bytes; };
     auto OUT_of = [&](int t) { return smem_raw + C::off_out + (size_t)(t & 1) * C::out_bytes; };
+    // AVX_ABLATE (phase skipping, tuning only) exists in the diagnostic instantiation alone: as run-time tests these uniform
+    // branches split the loop into small blocks and kept the compiler from overlapping the quantiser's LDS lookups across rows
+    const int ablate = STAMP ? a.ablate : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bookkeeping on the SALU
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
         const uint8_t* RAW = RAW_of(t);
         P* A = A_of(t);
 #pragma unroll 1
-        for (int item = (a.ablate & 1) ? (1 << 30) : tid; item < (SY / 2) * C::NG4; item += kMarchThreads) {
+        for (int item = (ablate & 1) ? (1 << 30) : tid; item < (SY / 2) * C::NG4; item += kMarchThreads) {
             const int sp = item / C::NG4, q4 = item - sp * C::NG4;
             if (q4 * 4 >= aws) continue;
             uint32_t code[2][4][3];
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
 #pragma unroll
                 for (int j = 0; j < 2 * R; ++j) cw[xp][j] = cw[xp][j + SY];
 #pragma unroll
-            for (int sp = 0; sp < ((a.ablate & 2) ? 0 : SY / 2); ++sp) {
+            for (int sp = 0; sp < ((ablate & 2) ? 0 : SY / 2); ++sp) {
                 const P* src = A + ((size_t)(sp * 3 + c)) * C::PA + xg * XPT;
                 P w[XPT + 2 * R];  // {row 2sp, row 2sp+1} at columns xg*XPT + i
 #pragma unroll
@@ -359,14 +362,14 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
                 __builtin_amdgcn_sched_barrier(0);  // one row-pair window live at a time (register budget)
             }
 #pragma unroll
-            for (int i = 0; i < ((a.ablate & 4) ? 0 : SY); ++i) {
+            for (int i = 0; i < ((ablate & 4) ? 0 : SY); ++i) {
 #pragma unroll
                 for (int xp = 0; xp < XPT / 2; ++xp) {
                     P sacc = cw[xp][R + i] * kk[0];
 #pragma unroll
                     for (int j = 1; j <= R; ++j) sacc = pfma(cw[xp][R + i + j] + cw[xp][R + i - j], kk[j], sacc);
                     uint32_t q0, q1;
-                    if (a.ablate & 8) {
+                    if (ablate & 8) {
                         q0 = (uint32_t)(sacc.x * (T)255); q1 = (uint32_t)(sacc.y * (T)255);
                     } else {
                         q0 = quantize_coarse<T, NFIX>(sacc.x, thr, coarse, qc.lo_key);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
         stamp(3);
         compute(t);
         stamp(4);
-        if (t > 0 && !(a.ablate & 32)) store_out(t - 1);
+        if (t > 0 && !(ablate & 32)) store_out(t - 1);
         stamp(0);
         __syncthreads();
         stamp(5);
