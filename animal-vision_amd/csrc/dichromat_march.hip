@@ -37,15 +37,23 @@ template <> struct VecN<float, 2> { using type = float2; };
 template <> struct VecN<double, 2> { using type = double2; };
 template <> struct VecN<double, 1> { using type = double; };
 
-template <typename T, int R, int SY, int XPT_, int NG>
+// SPEC (wave-specialised form): one extra wave per workgroup is the PRODUCER -- it alone stages the raw rows and decodes them
+// for the next iteration -- while the 3 * NG / 64 compute waves only run the row/column passes and the quantiser.  In the
+// plain form wave 0 did all of the decode on top of its share of compute and the other waves waited for it at the barrier
+// (in-kernel stamps: raw staging 26 % + decode 27 % + compute 35 % of wave 0's iteration).
+template <typename T, int R, int SY, int XPT_, int NG, bool SPEC = false>
 struct MarchCfg {
-    static constexpr int kMarchThreads = 3 * NG;
+    static constexpr int kComputeThreads = 3 * NG;
+    static constexpr int kMarchThreads = 3 * NG + (SPEC ? 64 : 0);
     static constexpr int kGroups = NG;
     static constexpr int XPT = XPT_;                          // columns per thread = one LDS vector read
     static constexpr int SW = XPT * kGroups;
     static constexpr int AWS = SW + 2 * R;
     static constexpr int NWV = 1 + (2 * R + XPT - 1) / XPT;   // vector reads per row window
     static constexpr int NG4 = (AWS + 3) / 4;                 // decode groups (4 px) per row
+    // SPEC: the producer decodes a row pair in ONE pass of its 64 lanes, so a strip (with halo) is at most 256 / SY px wide
+    static constexpr int NG4S = 64 / (SY / 2);
+    static constexpr int SW_CAP = SPEC ? (NG4S * 4 - 2 * R < SW ? NG4S * 4 - 2 * R : SW) : SW;
     static constexpr int PA0 = SW - XPT + NWV * XPT;
     static constexpr int PA = ((PA0 > NG4 * 4 ? PA0 : NG4 * 4) + 3) / 4 * 4;
     static constexpr int RAW_LEAD = 64;
@@ -85,9 +93,9 @@ template <typename P> __device__ __forceinline__ P pfma(P a, P b, P c) { return 
 
 // STAMP = true is a DIAGNOSTIC instantiation (AVX_STAMPS=1): tid 0 accumulates s_memtime deltas per section
 // into a.stamps (never into an output); its run time is not representative.
-template <typename T, int COLOR, bool DARK, int R, int SY, int XPT_, int NG, int MINW, int NFIX, bool STAMP = false>
-__global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(DichromatArgs a, Taps<T> taps, QuantCoarse qc, MarchGeom g) {
-    using C = MarchCfg<T, R, SY, XPT_, NG>;
+template <typename T, int COLOR, bool DARK, int R, int SY, int XPT_, int NG, int MINW, int NFIX, bool STAMP = false, bool SPEC = false>
+__global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_march_kernel(DichromatArgs a, Taps<T> taps, QuantCoarse qc, MarchGeom g) {
+    using C = MarchCfg<T, R, SY, XPT_, NG, SPEC>;
     constexpr int kMarchThreads = C::kMarchThreads;
     constexpr int kGroups = C::kGroups;
     using P = typename Pair<T>::type;
@@ -150,65 +158,74 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
 #pragma unroll
     for (int d = 0; d <= R; ++d) { const T k = ktab[d]; kk[d] = P{k, k}; }
 
-    const int c = tid / kGroups;        // channel of this thread (uniform per wave: 128 = 2 waves)
-    const int xg = tid - c * kGroups;   // column group: columns xg*XPT .. xg*XPT+XPT-1 of the strip
-    const bool col_active = xg * XPT < vw;
+    const bool producer = SPEC && wave >= C::kComputeThreads / 64;  // from the readfirstlane'd wave index: a SCALAR condition, so the
+                                                                    // role branches are uniform and the row bookkeeping stays on the SALU
+    const bool decoder = !SPEC || producer;                   // who decodes
+    const bool stager = !SPEC || producer;                    // who stages the raw rows
+    const int c = producer ? 0 : tid / kGroups;  // channel of this thread (uniform per wave: 128 = 2 waves)
+    const int xg = tid - c * kGroups;            // column group: columns xg*XPT .. xg*XPT+XPT-1 of the strip
+    const bool col_active = !producer && xg * XPT < vw;
 
     // ---- raw row loads: (row, 64-dword segment) units dealt to waves; row math is scalar ---------
     constexpr int NSEG = (C::DPR + 63) / 64;
-    constexpr int NLD = (SY * NSEG + NWAVES - 1) / NWAVES;
+    constexpr int NSTAGE = SPEC ? 1 : NWAVES;           // waves that share the raw-row units
+    const int swave = SPEC ? 0 : wave;
+    constexpr int NLD = (SY * NSEG + NSTAGE - 1) / NSTAGE;
     // The host only launches this kernel on batches whose byte size and base address are multiples of 4 (every standard
     // video size): aligned dwords that contain a valid byte then never cross the end of the batch, and no tail guard is
     // needed.  (The guarded path used to live here too; its scalar bookkeeping alone spilled 14 SGPRs through v_readlane.)
     uint8_t* rowshift = smem_raw + C::off_ktab + 48 * sizeof(T);  // [2][SY] raw-row misalignments, by iteration parity
-    auto row_base = [&](int t, int s, uint32_t& shift) -> const uint8_t* {
-        int y = ys - R + t * SY + s;
+    // Row addressing in 32 bits: offsets are relative to the frame base rounded DOWN to a dword (the host checks that a frame
+    // is < 4 GiB), so a row costs three scalar instructions instead of a 64-bit multiply-add chain, and a load is one vector
+    // add on top of a scalar base.  A wave issues one instruction every four cycles at best: this bookkeeping, not the
+    // 8 loads it serves, was half of the producer wave's iteration.
+    const uint32_t fin_align = (uint32_t)((uintptr_t)fin & 3u);
+    const uint8_t* const fin_base = fin - fin_align;
+    auto row_off = [&](int t, int s, uint32_t& shift) -> uint32_t {
+        const int y = ys - R + t * SY + s;
         const int gy = (unsigned)y < (unsigned)a.H ? y : reflect101(y, a.H);
-        const uint8_t* rowp = fin + ((size_t)gy * a.W + gx0) * 3;
-        shift = (uint32_t)((uintptr_t)rowp & 3u);
-        return rowp - shift;
+        const uint32_t off = fin_align + ((uint32_t)gy * (uint32_t)a.W + (uint32_t)gx0) * 3u;
+        shift = off & 3u;
+        return off - shift;
     };
-    // Straight-line issue: no branch between two loads, so all NLD loads are in flight together (a guarded
-    // bytewise path inside the loop made hipcc put s_waitcnt vmcnt(0) after every load and serialise them).
+    // Unconditional, straight-line issue: lanes past the row's last dword re-read that last dword (always a valid address:
+    // batch size and base are multiples of 4) instead of being masked off -- a guarded load is a branch, and a branch between
+    // two loads keeps them from being in flight together.  Nothing consumes those duplicates but the detector, which masks them.
     auto issue_raw_loads = [&](int t, uint32_t (&rv)[NLD]) {
-        const uint8_t* ptr[NLD];
-        bool ok[NLD];
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
-            const int u = wave + n * NWAVES;            // uniform
+            const int u = swave + n * NSTAGE;            // uniform
             const int s = u / NSEG, seg = u - s * NSEG; // uniform
             uint32_t shift;
-            const uint8_t* base = row_base(t, s < SY ? s : 0, shift);
+            const uint32_t aoff = row_off(t, s < SY ? s : 0, shift);
+            const int last = ((int)shift + row_bytes - 1) >> 2;
             const int d = seg * 64 + lane;
-            ptr[n] = base + (size_t)d * 4;
-            ok[n] = s < SY && d * 4 < (int)shift + row_bytes;
+            const int dc = d < last ? d : last;
+            rv[n] = *reinterpret_cast<const uint32_t*>(fin_base + (size_t)(aoff + (uint32_t)dc * 4u));
         }
-#pragma unroll
-        for (int n = 0; n < NLD; ++n) rv[n] = ok[n] ? *reinterpret_cast<const uint32_t*>(ptr[n]) : 0u;
     };
     auto write_raw = [&](int t, const uint32_t (&rv)[NLD]) {
         uint8_t* RAW = RAW_of(t);
         uint32_t seen = 0;
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
-            const int u = wave + n * NWAVES;
+            const int u = swave + n * NSTAGE;
             const int s = u / NSEG, seg = u - s * NSEG;
             if (s < SY) {
                 const int d = seg * 64 + lane;
                 uint32_t shift;
-                (void)row_base(t, s, shift);                      // scalar
+                (void)row_off(t, s, shift);                       // scalar
                 if (seg == 0 && lane == 0) rowshift[(t & 1) * SY + s] = (uint8_t)shift;
                 if (d < C::DPR) {
                     *reinterpret_cast<uint32_t*>(RAW + (size_t)s * C::RAWP + C::RAW_LEAD + d * 4) = rv[n];
                     if (!DARK) {
-                        // "byte > 1" detector, masked to the row's own bytes: only the first and the last dword
-                        // of a row hold foreign bytes (<= 3 before / after it)
+                        // "byte > 1" detector, masked to the row's own bytes: only the first and the last dword of a row
+                        // hold foreign bytes (<= 3 before / after it); lanes past the last dword hold copies of it
                         const int last = ((int)shift + row_bytes - 1) >> 2;                        // scalar
                         const uint32_t mlo = 0xfefefefeu << (8 * shift);                           // scalar
                         const uint32_t mhi = 0xfefefefeu >> (8 * (3 - (((int)shift + row_bytes - 1) & 3)));
-                        uint32_t m = d > last ? 0u : 0xfefefefeu;
+                        uint32_t m = d >= last ? mhi : 0xfefefefeu;
                         m = d == 0 ? (m & mlo) : m;
-                        m = d == last ? (m & mhi) : m;
                         seen |= rv[n] & m;
                     }
                 }
@@ -254,9 +271,11 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
     auto decode = [&](int t) {
         const uint8_t* RAW = RAW_of(t);
         P* A = A_of(t);
+        if (!decoder) return;  // (SPEC only: the plain form has a barrier below that every thread must reach)
+        constexpr int kNG4 = SPEC ? C::NG4S : C::NG4, kStep = SPEC ? 64 : kMarchThreads;
 #pragma unroll 1
-        for (int item = (ablate & 1) ? (1 << 30) : tid; item < (SY / 2) * C::NG4; item += kMarchThreads) {
-            const int sp = item / C::NG4, q4 = item - sp * C::NG4;
+        for (int item = (ablate & 1) ? (1 << 30) : (SPEC ? lane : tid); item < (SY / 2) * kNG4; item += kStep) {
+            const int sp = item / kNG4, q4 = item - sp * kNG4;
             if (q4 * 4 >= aws) continue;
             uint32_t code[2][4][3];
 #pragma unroll
@@ -320,9 +339,9 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
             }
         }
         if (border) {  // BORDER_REFLECT_101 in x: halo entries outside the image copy their mirror pixel
-            __syncthreads();
+            if constexpr (!SPEC) __syncthreads();  // SPEC: the same wave wrote A (LDS serves a wave's accesses in order)
             const int nl = lead, nr = (xs + vw + R) - gx1;  // halo pixels left / right of the image
-            for (int item = tid; item < (SY / 2) * 3 * (nl + nr); item += kMarchThreads) {
+            for (int item = SPEC ? lane : tid; item < (SY / 2) * 3 * (nl + nr); item += kStep) {
                 const int e = item % (nl + nr), pl = item / (nl + nr);
                 const int lx = e < nl ? e : (gx1 - (xs - R)) + (e - nl);
                 const int src = reflect101(xs - R + lx, a.W) - (xs - R);
@@ -394,12 +413,14 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
             st_t = now;
         }
     };
-    issue_raw_loads(0, rv);
-    write_raw(0, rv);
-    if (n_iter > 1) issue_raw_loads(1, rv);
+    if (stager) {
+        issue_raw_loads(0, rv);
+        write_raw(0, rv);
+        if (n_iter > 1) issue_raw_loads(1, rv);
+    }
     __syncthreads();
     decode(0);
-    if (n_iter > 1) {
+    if (stager && n_iter > 1) {
         write_raw(1, rv);
         if (n_iter > 2) issue_raw_loads(2, rv);
     }
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
         stamp(-1);
         // raw staging first: its s_waitcnt vmcnt covers only the loads issued one interval ago (vmcnt counts
         // stores too, in order: behind store_out it would also wait for those stores to retire)
-        if (t + 2 < n_iter) {
+        if (stager && t + 2 < n_iter) {
             write_raw(t + 2, rv);
             stamp(1);
             if (t + 3 < n_iter) issue_raw_loads(t + 3, rv);
@@ -426,22 +447,22 @@ __global__ __launch_bounds__(3 * NG, MINW) void dichromat_march_kernel(Dichromat
     }
     store_out(n_iter - 1);
     if constexpr (STAMP) {
-        if (tid == 0 && a.stamps) {
+        if (tid == (SPEC ? C::kComputeThreads : 0) && a.stamps) {
             for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_acc[i]);
             atomicAdd(a.stamps + 6, (unsigned long long)n_iter);
         }
     }
 }
 
-template <typename T, int COLOR, int R, int SY, int XPT, int NG, int MINW, int NFIX>
+template <typename T, int COLOR, int R, int SY, int XPT, int NG, int MINW, int NFIX, bool SPEC = false>
 int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, const QuantCoarse& qc, hipStream_t s) {
-    using C = MarchCfg<T, R, SY, XPT, NG>;
+    using C = MarchCfg<T, R, SY, XPT, NG, SPEC>;
     constexpr int kMarchThreads = C::kMarchThreads;
     Taps<T> taps;
     for (int i = 0; i < AVX_MAX_KSIZE; ++i) taps.k[i] = (T)0;
     for (int i = 0; i < d->ksize; ++i) taps.k[i] = (T)d->taps_host[i];
-    auto kmain = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, NG, MINW, NFIX>;
-    auto kdark = dichromat_march_kernel<T, COLOR, true, R, SY, XPT, NG, MINW, NFIX>;
+    auto kmain = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, NG, MINW, NFIX, false, SPEC>;
+    auto kdark = dichromat_march_kernel<T, COLOR, true, R, SY, XPT, NG, MINW, NFIX, false, SPEC>;
     const size_t lds = C::lds_bytes;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kmain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kdark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -449,7 +470,7 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
     AVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kmain, kMarchThreads, lds));
     if (per_cu < 1) per_cu = 1;
     MarchGeom g{};
-    g.nstrips = (a.W + C::SW - 1) / C::SW;
+    g.nstrips = (a.W + C::SW_CAP - 1) / C::SW_CAP;
     g.sw = ((a.W + g.nstrips - 1) / g.nstrips + C::XPT - 1) / C::XPT * C::XPT;
     // Row chunks per (frame, strip).  The best split depends on how the workgroup count tiles the resident slots, the XCD
     // round-robin and the priming cost (2R rows per chunk): measured, not modelled -- the first call for a (kernel
@@ -516,8 +537,8 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
     const long total = set_chunks(nchunks);
     AVX_REQUIRE(ctx, total < (1L << 30), "avx_dichromat_u8: too many workgroups");
     if (getenv("AVX_STAMPS")) {
-        if constexpr (R == 6 || R == 14) {
-            auto kst = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, NG, MINW, NFIX, true>;
+        if constexpr (R == 6 || R == 14 || (R == 4 && sizeof(T) == 8)) {
+            auto kst = dichromat_march_kernel<T, COLOR, false, R, SY, XPT, NG, MINW, NFIX, true, SPEC>;
             AVX_HIP(ctx, hipFuncSetAttribute((const void*)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             avx_ws* wst = avx_workspace(ctx, s);
             AVX_HIP(ctx, (wst && avx_ensure_scratch(ctx, wst, 64) == AVX_OK) ? hipSuccess : hipErrorOutOfMemory);
@@ -559,8 +580,6 @@ static uint64_t width_key(bool f64, int R, int frames, int H, int W) {
 // shapes start tuned; any other (kernel, batch, frame size) is measured on its first call.
 void avx_march_seed_tuned(avx_ctx* ctx) {
     static const struct { int f64, R, frames, H, W, NG, chunks; } kSeed[] = {
-        {1, 4, 32, 1080, 1920, 64, 12},   // cat 1080p (default bench)
-        {1, 4, 8, 2160, 3840, 64, 16},    // cat 4K
         {0, 14, 32, 1080, 1920, 128, 1},  // dog 1080p
         {0, 14, 8, 2160, 3840, 128, 8},   // dog 4K
         {0, 6, 32, 1080, 1920, 64, 8},    // wolf 1080p
@@ -580,7 +599,7 @@ static int march_dispatch(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_de
     AVX_REQUIRE(ctx, ctx->coarse_n_fix[w] <= NF, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[w], NF);
     QuantCoarse qc{f64_cat ? ctx->d_coarse_f64 : ctx->d_coarse_f32, ctx->coarse_lo_key[w], ctx->coarse_n_keys[w], ctx->coarse_n_fix[w]};
     if (f64_cat) {
-        if (a.r == 4) return ng64 ? launch_march<double, AVX_COLOR_CAT_MERGE, 4, 4, 2, 64, 3, NF>(ctx, a, d, qc, s)
+        if (a.r == 4) return ng64 ? launch_march<double, AVX_COLOR_CAT_MERGE, 4, 4, 2, 64, 3, NF, true>(ctx, a, d, qc, s)
                                   : launch_march<double, AVX_COLOR_CAT_MERGE, 4, 4, 2, 128, 3, NF>(ctx, a, d, qc, s);
         return AVX_ERR_UNSUPPORTED;
     }
@@ -602,6 +621,7 @@ int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichrom
     // The kernel reads rows as aligned dwords without a tail guard: batches whose byte size or base address is not a multiple
     // of 4 (no standard video size) take the 2-D tiled / reference kernels instead.
     if (((((size_t)a.H * a.W * 3 * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) != 0) return AVX_ERR_UNSUPPORTED;
+    if ((size_t)a.H * a.W * 3 >= ((size_t)1 << 32) - 16) return AVX_ERR_UNSUPPORTED;  // 32-bit row offsets inside a frame
     // Workgroup width: 192 threads (NG = 64) or 384 (NG = 128).  Which is faster depends on the radius, the element type
     // and the batch geometry (cat: 64; dog: 128; wolf at 1080p: 64 by 13 %), so like the row split it is measured on the
     // first call per (radius, type, batch, frame size) and remembered.  AVX_MARCH_NG=64|128 pins it.
