@@ -57,8 +57,8 @@ struct MarchCfg {
     static constexpr int PA0 = SW - XPT + NWV * XPT;
     static constexpr int PA = ((PA0 > NG4 * 4 ? PA0 : NG4 * 4) + 3) / 4 * 4;
     static constexpr int RAW_LEAD = 64;
-    static constexpr int RAWP = RAW_LEAD + ((AWS * 3 + 3 + 16 + 3) & ~3);
-    static constexpr int DPR = (RAWP - RAW_LEAD) / 4;
+    static constexpr int DPR = (((AWS * 3 + 3 + 16 + 3) & ~3) / 4 + 63) / 64 * 64;  // dwords per raw row, whole 64-lane segments
+    static constexpr int RAWP = RAW_LEAD + DPR * 4;
     static constexpr int OUTP = SW * 3;
     static constexpr int WIN = 2 * R + SY;                    // rows in a column window
     static constexpr size_t off_thr = 0;
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
                 const int d = seg * 64 + lane;
                 uint32_t shift;
                 (void)row_off(t, s, shift);                       // scalar
-                if (seg == 0 && lane == 0) rowshift[(t & 1) * SY + s] = (uint8_t)shift;
-                if (d < C::DPR) {
+                if (seg == 0) rowshift[(t & 1) * SY + s] = (uint8_t)shift;  // every lane stores the same byte: no branch
+                {
                     *reinterpret_cast<uint32_t*>(RAW + (size_t)s * C::RAWP + C::RAW_LEAD + d * 4) = rv[n];
                     if (!DARK) {
                         // "byte > 1" detector, masked to the row's own bytes: only the first and the last dword of a row
@@ -243,8 +243,9 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     auto store_out = [&](int t) {
         const uint8_t* OUT = OUT_of(t);
         const int per_row = nbytes / gran;
+        if (producer) return;  // SPEC: the compute waves store (they wait for the producer anyway)
 #pragma unroll 1
-        for (int v = tid; v < SY * per_row; v += kMarchThreads) {
+        for (int v = tid; v < SY * per_row; v += C::kComputeThreads) {
             const int i = v / per_row, e = v - i * per_row;
             const int rel = t * SY + i - 2 * R;
             if (rel < 0 || rel >= ch) continue;
