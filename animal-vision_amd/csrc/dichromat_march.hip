@@ -585,6 +585,8 @@ void avx_march_seed_tuned(avx_ctx* ctx) {
         {0, 14, 8, 2160, 3840, 128, 8},   // dog 4K
         {0, 6, 32, 1080, 1920, 64, 8},    // wolf 1080p
         {0, 5, 32, 1080, 1920, 64, 8},    // lion / tiger 1080p
+        {1, 4, 32, 1080, 1920, 64, 8},    // cat 1080p (default bench; wave-specialised form)
+        {1, 4, 8, 2160, 3840, 64, 24},    // cat 4K
         {0, 3, 32, 1080, 1920, 128, 4},   // squirrel 1080p
     };
     for (const auto& e : kSeed) {
@@ -607,12 +609,16 @@ static int march_dispatch(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_de
     switch (a.r) {
         // <R, SY, XPT, min waves/SIMD>, from A/B runs on MI355X: 2 columns per thread keeps the
         // row-window reads conflict-free (16-byte lane stride) and the register windows under 128 VGPRs.
-#define AVX_MARCH_F32(RR, XX, MW)                                                                            \
+        // SP: the 192-thread form runs wave-specialised (+ one producer wave; strips capped at 128 - 2R px so the producer
+        // decodes a row pair in one pass).  Measured for the float32 species (wolf, lion: 0.58 / 0.55 ms against 0.44 / 0.41 ms
+        // plain): their decode is too light to fill a producer wave and the narrower strips idle compute lanes -- off.
+#define AVX_MARCH_F32(RR, XX, MW, SP)                                                                        \
     case RR:                                                                                                 \
-        return ng64 ? launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, 64, MW, NF>(ctx, a, d, qc, s)          \
+        return ng64 ? launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, 64, MW, NF, SP>(ctx, a, d, qc, s)      \
                     : launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, 128, MW, NF>(ctx, a, d, qc, s);
-        AVX_MARCH_F32(1, 4, 3) AVX_MARCH_F32(3, 4, 3) AVX_MARCH_F32(4, 2, 3) AVX_MARCH_F32(5, 2, 3) AVX_MARCH_F32(6, 2, 3)
-        AVX_MARCH_F32(7, 2, 3) AVX_MARCH_F32(8, 2, 3) AVX_MARCH_F32(9, 2, 3) AVX_MARCH_F32(14, 2, 2)
+        AVX_MARCH_F32(1, 4, 3, false) AVX_MARCH_F32(3, 4, 3, false) AVX_MARCH_F32(4, 2, 3, false) AVX_MARCH_F32(5, 2, 3, false)
+        AVX_MARCH_F32(6, 2, 3, false) AVX_MARCH_F32(7, 2, 3, false) AVX_MARCH_F32(8, 2, 3, false) AVX_MARCH_F32(9, 2, 3, false)
+        AVX_MARCH_F32(14, 2, 2, false)
 #undef AVX_MARCH_F32
         default: return AVX_ERR_UNSUPPORTED;
     }

@@ -18,7 +18,7 @@ WRITE_SIZE
 GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
 GROUPS
 python - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc/p*/**/*counter_collection.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
@@ -30,7 +30,8 @@ for f in glob.glob("gpurun_out/pmc/p*/**/*counter_collection.csv", recursive=Tru
         k = r["Kernel_Name"]
         if "_kernel<" in k and int(r["Dispatch_Id"]) not in keep:
             continue
-        k = "main" if "_kernel<" in k and ", false," in k else ("dark" if "_kernel<" in k else k[:40])
+        mm = re.search(r"_kernel<\w+, \d+, (true|false),", k)  # third template argument = DARK
+        k = ("main" if mm.group(1) == "false" else "dark") if mm else k[:40]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 import json, os
 for k, d in agg.items():
