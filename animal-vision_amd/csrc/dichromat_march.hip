@@ -183,7 +183,10 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     const uint8_t* const fin_base = fin - fin_align;
     auto row_off = [&](int t, int s, uint32_t& shift) -> uint32_t {
         const int y = ys - R + t * SY + s;
-        const int gy = (unsigned)y < (unsigned)a.H ? y : reflect101(y, a.H);
+        const int ay = y < 0 ? -y : y;
+        const int my = 2 * (a.H - 1) - ay;
+        const int gy = ay < my ? ay : my;  // BORDER_REFLECT_101 in one step (the host sends frames shorter than 2 (R + SY) rows
+                                           // elsewhere): three scalar instructions, where the general loop was ~25 per row
         const uint32_t off = fin_align + ((uint32_t)gy * (uint32_t)a.W + (uint32_t)gx0) * 3u;
         shift = off & 3u;
         return off - shift;
@@ -239,7 +242,8 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     const int nbytes = vw * 3;
     const uintptr_t o0 = (uintptr_t)(fout + (size_t)xs * 3);
     const uintptr_t pitch = (uintptr_t)a.W * 3;
-    const int gran = (((o0 | pitch | (uintptr_t)nbytes) & 15u) == 0) ? 16 : ((((o0 | pitch | (uintptr_t)nbytes) & 3u) == 0) ? 4 : 1);
+    const uintptr_t oall = o0 | pitch | (uintptr_t)nbytes;
+    const int gran = ((oall & 15u) == 0) ? 16 : (((oall & 7u) == 0) ? 8 : (((oall & 3u) == 0) ? 4 : 1));
     auto store_out = [&](int t) {
         const uint8_t* OUT = OUT_of(t);
         const int per_row = nbytes / gran;
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
             uint8_t* grow = fout + ((size_t)(ys + rel) * a.W + xs) * 3;
             const uint8_t* orow = OUT + (size_t)i * C::OUTP;
             if (gran == 16) reinterpret_cast<uint4*>(grow)[e] = reinterpret_cast<const uint4*>(orow)[e];
+            else if (gran == 8) reinterpret_cast<uint2*>(grow)[e] = reinterpret_cast<const uint2*>(orow)[e];
             else if (gran == 4) reinterpret_cast<uint32_t*>(grow)[e] = reinterpret_cast<const uint32_t*>(orow)[e];
             else grow[e] = orow[e];
         }
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     }
     store_out(n_iter - 1);
     if constexpr (STAMP) {
-        if (tid == (SPEC ? C::kComputeThreads : 0) && a.stamps) {
+        if (tid == ((SPEC && !(a.ablate & 64)) ? C::kComputeThreads : 0) && a.stamps) {  // AVX_ABLATE=64: the first compute wave instead of the producer
             for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_acc[i]);
             atomicAdd(a.stamps + 6, (unsigned long long)n_iter);
         }
@@ -629,6 +634,7 @@ int avx_launch_dichromat_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichrom
     // of 4 (no standard video size) take the 2-D tiled / reference kernels instead.
     if (((((size_t)a.H * a.W * 3 * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) != 0) return AVX_ERR_UNSUPPORTED;
     if ((size_t)a.H * a.W * 3 >= ((size_t)1 << 32) - 16) return AVX_ERR_UNSUPPORTED;  // 32-bit row offsets inside a frame
+    if (a.H < 2 * (a.r + 4)) return AVX_ERR_UNSUPPORTED;                              // single-step row reflection (SY = 4)
     // Workgroup width: 192 threads (NG = 64) or 384 (NG = 128).  Which is faster depends on the radius, the element type
     // and the batch geometry (cat: 64; dog: 128; wolf at 1080p: 64 by 13 %), so like the row split it is measured on the
     // first call per (radius, type, batch, frame size) and remembered.  AVX_MARCH_NG=64|128 pins it.
