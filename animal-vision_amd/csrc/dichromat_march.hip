@@ -154,9 +154,13 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     if (tid == 10) cmf[10] = a.one_minus_alpha;
     if constexpr (COLOR != AVX_COLOR_MATRIX) { if (tid < 9) cbk[tid] = a.Bk[tid]; }
     __syncthreads();
-    P kk[R + 1];  // taps, splat into both halves, in VGPRs (via LDS: as SGPRs they spill through v_readlane)
+    // Taps, splat into both halves, straight from the kernel arguments: uniform values, so they live in SGPRs and enter each
+    // packed FMA as its one scalar operand -- 2 (R + 1) VGPRs fewer than the vector copies (read back from LDS) this kernel used
+    // while its scalar file was overcommitted (dog, 29 taps: 189 -> 165 VGPRs = three waves per SIMD instead of two, 79 -> 98 GP/s).
+    P kk[R + 1];
 #pragma unroll
-    for (int d = 0; d <= R; ++d) { const T k = ktab[d]; kk[d] = P{k, k}; }
+    for (int d = 0; d <= R; ++d) { const T k = sizeof(T) == 8 ? ktab[d] : taps.k[R + d]; kk[d] = P{k, k}; }  // (cat's float64 taps: 4 SGPRs
+                                                                                          // each, the scalar file spills again: VGPR copies)
 
     const bool producer = SPEC && wave >= C::kComputeThreads / 64;  // from the readfirstlane'd wave index: a SCALAR condition, so the
                                                                     // role branches are uniform and the row bookkeeping stays on the SALU
@@ -586,13 +590,13 @@ static uint64_t width_key(bool f64, int R, int frames, int H, int W) {
 // shapes start tuned; any other (kernel, batch, frame size) is measured on its first call.
 void avx_march_seed_tuned(avx_ctx* ctx) {
     static const struct { int f64, R, frames, H, W, NG, chunks; } kSeed[] = {
-        {0, 14, 32, 1080, 1920, 128, 1},  // dog 1080p
-        {0, 14, 8, 2160, 3840, 128, 8},   // dog 4K
+        {0, 14, 32, 1080, 1920, 64, 2},   // dog 1080p
+        {0, 14, 8, 2160, 3840, 64, 8},    // dog 4K
         {0, 6, 32, 1080, 1920, 64, 8},    // wolf 1080p
         {0, 5, 32, 1080, 1920, 64, 8},    // lion / tiger 1080p
+        {0, 3, 32, 1080, 1920, 128, 4},   // squirrel 1080p
         {1, 4, 32, 1080, 1920, 64, 8},    // cat 1080p (default bench; wave-specialised form)
         {1, 4, 8, 2160, 3840, 64, 24},    // cat 4K
-        {0, 3, 32, 1080, 1920, 128, 4},   // squirrel 1080p
     };
     for (const auto& e : kSeed) {
         if (ctx->n_march_tuned + 2 > 64) break;
