@@ -248,16 +248,21 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     const uintptr_t pitch = (uintptr_t)a.W * 3;
     const uintptr_t oall = o0 | pitch | (uintptr_t)nbytes;
     const int gran = ((oall & 15u) == 0) ? 16 : (((oall & 7u) == 0) ? 8 : (((oall & 3u) == 0) ? 4 : 1));
+    // Each thread's first (row, vector) item is fixed for the whole strip: the division by the run-time row length is done once,
+    // not every iteration (one pass covers the tile whenever SY * per_row <= threads, which holds at 8- and 16-byte granularity).
+    const int per_row = nbytes / gran;
+    const int st_i0 = tid / per_row, st_e0 = tid - st_i0 * per_row;
+    const uint32_t row_pitch = (uint32_t)a.W * 3u, strip_off = (uint32_t)xs * 3u;
     auto store_out = [&](int t) {
         const uint8_t* OUT = OUT_of(t);
-        const int per_row = nbytes / gran;
         if (producer) return;  // SPEC: the compute waves store (they wait for the producer anyway)
+        int i = st_i0, e = st_e0;
 #pragma unroll 1
         for (int v = tid; v < SY * per_row; v += C::kComputeThreads) {
-            const int i = v / per_row, e = v - i * per_row;
+            if (v != tid) { i = v / per_row; e = v - i * per_row; }
             const int rel = t * SY + i - 2 * R;
             if (rel < 0 || rel >= ch) continue;
-            uint8_t* grow = fout + ((size_t)(ys + rel) * a.W + xs) * 3;
+            uint8_t* grow = fout + (size_t)((uint32_t)(ys + rel) * row_pitch + strip_off);  // 32-bit offset inside the frame (< 4 GiB, host-checked)
             const uint8_t* orow = OUT + (size_t)i * C::OUTP;
             if (gran == 16) reinterpret_cast<uint4*>(grow)[e] = reinterpret_cast<const uint4*>(orow)[e];
             else if (gran == 8) reinterpret_cast<uint2*>(grow)[e] = reinterpret_cast<const uint2*>(orow)[e];
