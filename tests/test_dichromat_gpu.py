@@ -153,3 +153,23 @@ def test_float_frames_collapse_matrix_species(av, oracle, name):
         _, want = oracle.dichromat_visualize(oracle.DICHROMATS[name], frame)
         assert base is frame and out.dtype == frame.dtype == want.dtype and out.shape == frame.shape
         np.testing.assert_allclose(out, want, rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["cat", "dog", "wolf", "squirrel"])
+def test_marching_kernel_ragged_strips_and_misaligned_frames(av, oracle, name):
+    """Shapes that stay on the marching-strip kernel (batch bytes a multiple of 4, frames taller than 2 (R + 4) rows) but stress
+    its addressing: row lengths that are not multiples of 4 bytes (per-row dword misalignment), several ragged strips, and a
+    batch whose individual frames have an odd byte size (every second frame base is misaligned)."""
+    from animal_vision_amd import animals
+    from animal_vision_amd.dichromat import DichromatOp
+
+    spec = getattr(animals, name.capitalize()).SPEC
+    for (n, H, W) in [(1, 96, 250), (1, 52, 121 * 4), (4, 45, 33), (2, 40, 1001 * 2), (1, 1080 // 4, 1922)]:
+        assert (n * H * W * 3) % 4 == 0
+        batch = np.random.default_rng(n * H + W).integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+        op = DichromatOp(spec)
+        op.desc.variant = 3
+        got = op(batch)
+        for i in range(n):
+            _, want = oracle.dichromat_visualize(oracle.DICHROMATS[name], batch[i])
+            assert np.array_equal(got[i], want), f"{name} frame {i} of {(n, H, W)}: {int((got[i] != want).sum())} bytes differ"
