@@ -64,6 +64,32 @@ __device__ __forceinline__ void streak_along_row(const float* __restrict__ src, 
     }
 }
 
+// pass 1, "row" direction of the reference's W x 3 image = ACROSS the three channels (reflect-101 on a width of 3).  The radius
+// is uniform per image row, so it is a template argument: every source-channel index is then a compile-time constant and the
+// K1 taps sit in registers -- 3 * K1 FMAs per pixel, where the run-time form spent two LDS reads, a dynamic select and loop
+// control on every tap (ablation: a third of the kernel's time).  Same sequential FMA chain, tap by tap.
+__host__ __device__ constexpr int refl3(int p) {
+    while (p < 0 || p >= 3) p = p < 0 ? -p : 4 - p;
+    return p;
+}
+template <int R1>
+__device__ __forceinline__ void streak_across(const float* __restrict__ src, float* __restrict__ dst, int W, int PW, const float* __restrict__ t1, int tid) {
+    constexpr int K1 = 2 * R1 + 1;
+    float t[K1];
+#pragma unroll
+    for (int j = 0; j < K1; ++j) t[j] = t1[j];
+    for (int x = tid; x < W; x += kST) {
+        const float px[3] = {src[kPad + x], src[PW + kPad + x], src[2 * PW + kPad + x]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sacc = px[refl3(c - R1)] * t[0];
+#pragma unroll
+            for (int j = 1; j < K1; ++j) sacc = fma_t(px[refl3(c - R1 + j)], t[j], sacc);
+            dst[(size_t)c * PW + kPad + x] = sacc;
+        }
+    }
+}
+
 // mirror the interior of each plane into its halo (BORDER_REFLECT_101 on W)
 __device__ __forceinline__ void streak_fill_halo(float* buf, int W, int PW, int r, int tid) {
     for (int item = tid; item < 3 * 2 * r; item += kST) {
@@ -92,7 +118,6 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
     __shared__ float thr[256];
     __shared__ uint8_t coarse[kCoarseTableBytes];
     __shared__ float t1[16], td1[20], td2[20];
-    __shared__ int idx1[3][16];
     const int tid = threadIdx.x;
     if constexpr (!PLANES) {
         for (int i = tid; i < 256; i += kST) { lut[i] = a.decode_lut[i]; thr[i] = reinterpret_cast<const float*>(a.enc_thr)[i]; }
@@ -132,7 +157,6 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
         const int r1 = k1 / 2, r2 = k2 / 2;
         if (tid < 16) t1[tid] = tid < k1 ? rt[2 + tid] : 0.f;
         if (tid < 20) { td1[tid] = tid <= r1 ? rt[2 + r1 + tid] : 0.f; td2[tid] = tid <= r2 ? rt[15 + r2 + tid] : 0.f; }
-        if (tid < 48) { const int c = tid / 16, j = tid - 16 * c; idx1[c][j] = j < k1 ? reflect101(c - r1 + j, 3) : 0; }
         const uint8_t* src = a.in + frame_bytes * f + (size_t)y * n3;
         uint8_t* dst = a.out + frame_bytes * f + (size_t)y * n3;
         // ---- decode + colour stage -> buf0 planes -----------------------------------------------------
@@ -162,14 +186,14 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
         }
         __syncthreads();
         // ---- pass 1, "row" direction = across the 3 channels (width 3, reflect-101) -> buf1 planes --------
-        for (int x = tid; x < W; x += kST) {
-            const float px[3] = {buf0[kPad + x], buf0[PW + kPad + x], buf0[2 * PW + kPad + x]};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sacc = px[idx1[c][0]] * t1[0];
-                for (int j = 1; j < k1; ++j) sacc = fma_t(px[idx1[c][j]], t1[j], sacc);
-                buf1[(size_t)c * PW + kPad + x] = sacc;
-            }
+        switch (r1) {  // uniform per row
+            case 0: streak_across<0>(buf0, buf1, W, PW, t1, tid); break;
+            case 1: streak_across<1>(buf0, buf1, W, PW, t1, tid); break;
+            case 2: streak_across<2>(buf0, buf1, W, PW, t1, tid); break;
+            case 3: streak_across<3>(buf0, buf1, W, PW, t1, tid); break;
+            case 4: streak_across<4>(buf0, buf1, W, PW, t1, tid); break;
+            case 5: streak_across<5>(buf0, buf1, W, PW, t1, tid); break;
+            default: streak_across<6>(buf0, buf1, W, PW, t1, tid); break;  // 13 taps: the table's maximum
         }
         __syncthreads();
         // the halo is filled out to the window radius RB (>= r): the zero taps beyond r must meet finite values
