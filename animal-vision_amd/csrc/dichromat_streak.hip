@@ -72,14 +72,17 @@ __host__ __device__ constexpr int refl3(int p) {
     while (p < 0 || p >= 3) p = p < 0 ? -p : 4 - p;
     return p;
 }
-template <int R1>
-__device__ __forceinline__ void streak_across(const float* __restrict__ src, float* __restrict__ dst, int W, int PW, const float* __restrict__ t1, int tid) {
+// `load(x, px)` produces the pixel's three linear-light channels (decode + colour stage, or a read of the float planes): the
+// pass is pointwise in x, so it consumes them from registers -- no intermediate plane, no barrier in between.
+template <int R1, typename Load>
+__device__ __forceinline__ void streak_across(Load load, float* __restrict__ dst, int W, int PW, const float* __restrict__ t1, int tid) {
     constexpr int K1 = 2 * R1 + 1;
     float t[K1];
 #pragma unroll
     for (int j = 0; j < K1; ++j) t[j] = t1[j];
     for (int x = tid; x < W; x += kST) {
-        const float px[3] = {src[kPad + x], src[PW + kPad + x], src[2 * PW + kPad + x]};
+        float px[3];
+        load(x, px);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float sacc = px[refl3(c - R1)] * t[0];
@@ -159,41 +162,37 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
         if (tid < 20) { td1[tid] = tid <= r1 ? rt[2 + r1 + tid] : 0.f; td2[tid] = tid <= r2 ? rt[15 + r2 + tid] : 0.f; }
         const uint8_t* src = a.in + frame_bytes * f + (size_t)y * n3;
         uint8_t* dst = a.out + frame_bytes * f + (size_t)y * n3;
-        // ---- decode + colour stage -> buf0 planes -----------------------------------------------------
+        // ---- decode + colour stage, then pass 1 "row" direction = across the 3 channels (width 3, reflect-101) -> buf1 planes ----
         uint32_t seen = 0;
-        if constexpr (PLANES) {
-            const size_t plane = (size_t)a.H * W;
-            for (int x = tid; x < W; x += kST) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) buf0[(size_t)c * PW + kPad + x] = st.pin[c * plane + (size_t)y * W + x];
-            }
-        } else {
-        if constexpr (PREF) __syncthreads();  // the staged row is complete
         const uint8_t* rowb = PREF ? outb + ((uintptr_t)src & 3u) : src;
-        for (int x = tid; x < W; x += kST) {
-            const uint32_t b0 = rowb[3 * x], b1 = rowb[3 * x + 1], b2 = rowb[3 * x + 2];
-            seen |= (b0 | b1 | b2) >> 1;
-            float c0, c1, c2;
-            if (DARK) { c0 = b0 ? 1.0f : 0.0f; c1 = b1 ? 1.0f : 0.0f; c2 = b2 ? 1.0f : 0.0f; }
-            else { c0 = lut[b0]; c1 = lut[b1]; c2 = lut[b2]; }
-            buf0[kPad + x] = fma_t(c2, a.M[2], fma_t(c1, a.M[1], c0 * a.M[0]));
-            buf0[PW + kPad + x] = fma_t(c2, a.M[5], fma_t(c1, a.M[4], c0 * a.M[3]));
-            buf0[2 * PW + kPad + x] = fma_t(c2, a.M[8], fma_t(c1, a.M[7], c0 * a.M[6]));
-        }
+        auto load_px = [&](int x, float (&px)[3]) {
+            if constexpr (PLANES) {
+                const size_t plane = (size_t)a.H * W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[c] = st.pin[c * plane + (size_t)y * W + x];
+            } else {
+                const uint32_t b0 = rowb[3 * x], b1 = rowb[3 * x + 1], b2 = rowb[3 * x + 2];
+                seen |= (b0 | b1 | b2) >> 1;
+                float c0, c1, c2;
+                if (DARK) { c0 = b0 ? 1.0f : 0.0f; c1 = b1 ? 1.0f : 0.0f; c2 = b2 ? 1.0f : 0.0f; }
+                else { c0 = lut[b0]; c1 = lut[b1]; c2 = lut[b2]; }
+                px[0] = fma_t(c2, a.M[2], fma_t(c1, a.M[1], c0 * a.M[0]));
+                px[1] = fma_t(c2, a.M[5], fma_t(c1, a.M[4], c0 * a.M[3]));
+                px[2] = fma_t(c2, a.M[8], fma_t(c1, a.M[7], c0 * a.M[6]));
+            }
+        };
+        __syncthreads();  // this row's taps (t1 / td1 / td2) and, with PREF, its staged bytes are in place
+        switch (r1) {  // uniform per row
+            case 0: streak_across<0>(load_px, buf1, W, PW, t1, tid); break;
+            case 1: streak_across<1>(load_px, buf1, W, PW, t1, tid); break;
+            case 2: streak_across<2>(load_px, buf1, W, PW, t1, tid); break;
+            case 3: streak_across<3>(load_px, buf1, W, PW, t1, tid); break;
+            case 4: streak_across<4>(load_px, buf1, W, PW, t1, tid); break;
+            case 5: streak_across<5>(load_px, buf1, W, PW, t1, tid); break;
+            default: streak_across<6>(load_px, buf1, W, PW, t1, tid); break;  // 13 taps: the table's maximum
         }
         if constexpr (!PLANES) {
             if (!DARK && seen) a.flags[f] = 1u;
-        }
-        __syncthreads();
-        // ---- pass 1, "row" direction = across the 3 channels (width 3, reflect-101) -> buf1 planes --------
-        switch (r1) {  // uniform per row
-            case 0: streak_across<0>(buf0, buf1, W, PW, t1, tid); break;
-            case 1: streak_across<1>(buf0, buf1, W, PW, t1, tid); break;
-            case 2: streak_across<2>(buf0, buf1, W, PW, t1, tid); break;
-            case 3: streak_across<3>(buf0, buf1, W, PW, t1, tid); break;
-            case 4: streak_across<4>(buf0, buf1, W, PW, t1, tid); break;
-            case 5: streak_across<5>(buf0, buf1, W, PW, t1, tid); break;
-            default: streak_across<6>(buf0, buf1, W, PW, t1, tid); break;  // 13 taps: the table's maximum
         }
         __syncthreads();
         // the halo is filled out to the window radius RB (>= r): the zero taps beyond r must meet finite values
