@@ -387,7 +387,7 @@ static int launch_plane_blur(avx_ctx* ctx, const BlurArgs& a, hipStream_t s) {
         break;                                                                                                               \
     }
     switch (a.r) {
-        AVX_BLUR_T(1) AVX_BLUR_T(2) AVX_BLUR_T(3) AVX_BLUR_T(4) AVX_BLUR_T(5) AVX_BLUR_T(6) AVX_BLUR_T(9)
+        AVX_BLUR_T(1) AVX_BLUR_T(2) AVX_BLUR_T(3) AVX_BLUR_T(4) AVX_BLUR_T(5) AVX_BLUR_T(6) AVX_BLUR_T(7) AVX_BLUR_T(8) AVX_BLUR_T(9) AVX_BLUR_T(12)
         default: {
             const int AW = 64 + 2 * a.r, AH = 32 + 2 * a.r;
             const size_t lds = sizeof(float) * ((size_t)AH * AW + (size_t)AH * 64);
