@@ -108,15 +108,21 @@ __device__ __forceinline__ void streak_fill_halo(float* buf, int W, int PW, int 
 // all of a thread's loads in flight together and ONE ROW AHEAD (they travel while the previous row is being filtered), staged
 // in the LDS bytes that hold the output at the end of the row.  The plain form reads three bytes per pixel straight from
 // global memory inside the decode loop: 8 dependent trips of ~1.5 us per row, a third of the row's time.
-constexpr int kRawRegs = 12;  // dwords per thread and row: rows up to 12 * 256 * 4 - 8 bytes (W <= 4093)
-template <bool DARK, bool PLANES = false, bool PREF = false>
-__global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, StreakArgs st, QuantCoarse qc) {
+// NRAW = dwords per thread and row for that prefetch: 6 covers rows up to 6 * 256 * 4 - 8 bytes (W <= 2045), 12 up to W <= 4093.
+// Three waves per SIMD (<= 168 VGPRs) so that three 51 KB workgroups really are resident per CU.
+template <bool DARK, bool PLANES = false, bool PREF = false, int NRAW = 12>
+__global__ __launch_bounds__(kST, 3) void dichromat_streak_kernel(DichromatArgs a, StreakArgs st, QuantCoarse qc) {
+    constexpr int kRawRegs = NRAW;
     extern __shared__ __align__(16) float smem_f[];
     const int W = a.W, n3 = a.W * 3;
     const int PW = ((W + 3) / 4 * 4) + 2 * kPad;     // plane pitch (multiple of 4)
     float* buf0 = smem_f;                            // 3 planes
     float* buf1 = smem_f + (size_t)3 * PW;           // 3 planes
-    uint8_t* outb = reinterpret_cast<uint8_t*>(smem_f + (size_t)6 * PW);  // W*3 bytes (+ pad)
+    // The row's bytes (staged input at the top of a row, quantised output at its end) live in buf0's storage: buf0 is written by
+    // the first along-row pass only after the staged input has been decoded, and is dead again once the second pass has read
+    // it.  Without a byte buffer of its own a workgroup needs 51 KB instead of 57 KB of LDS: three fit a CU instead of two,
+    // and the kernel is bound by how many latency-limited rows are in flight.
+    uint8_t* outb = reinterpret_cast<uint8_t*>(buf0);  // W*3 bytes (+ <= 8 of misalignment) <= 3 planes of floats
     __shared__ float lut[256];
     __shared__ float thr[256];
     __shared__ uint8_t coarse[kCoarseTableBytes];
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(kST) void dichromat_streak_kernel(DichromatArgs a, 
 int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, const avx_dichromat_desc* d, hipStream_t s) {
     AVX_REQUIRE(ctx, d->streak_rows_host != nullptr && d->streak_stride >= 48, "avx_dichromat_u8: streak tables missing (stride >= 48)");
     const int PW = ((a.W + 3) / 4 * 4) + 2 * 16;
-    const size_t lds = sizeof(float) * (size_t)PW * 6 + (((size_t)a.W * 3 + 8 + 15) & ~(size_t)15);
+    const size_t lds = sizeof(float) * (size_t)PW * 6;  // (the byte staging shares buf0's storage)
     AVX_REQUIRE(ctx, ctx->coarse_n_fix[0] <= kCoarseNFix, "quantiser needs %d refinements, kernel built for %d", ctx->coarse_n_fix[0], kCoarseNFix);
     QuantCoarse qc{ctx->d_coarse_f32, ctx->coarse_lo_key[0], ctx->coarse_n_keys[0], ctx->coarse_n_fix[0]};
     AVX_REQUIRE(ctx, lds <= 150 * 1024, "avx_dichromat_u8: frame width %d too large for the streak kernel (row must fit LDS)", a.W);
@@ -259,14 +265,16 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
     }
     AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, d->streak_rows_host, tbytes, hipMemcpyHostToDevice, s));
     StreakArgs st{ws->d_row_gain, d->streak_stride, nullptr, nullptr};
-    const bool pref = ((((size_t)a.H * a.W * 3 * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) == 0 && a.W * 3 + 8 <= kRawRegs * kST * 4;
-    auto kmain = pref ? dichromat_streak_kernel<false, false, true> : dichromat_streak_kernel<false>;
-    auto kdark = pref ? dichromat_streak_kernel<true, false, true> : dichromat_streak_kernel<true>;
+    const bool aligned = ((((size_t)a.H * a.W * 3 * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) == 0;
+    const bool pref6 = aligned && a.W * 3 + 8 <= 6 * kST * 4, pref12 = aligned && a.W * 3 + 8 <= 12 * kST * 4;
+    auto kmain = pref6 ? dichromat_streak_kernel<false, false, true, 6> : (pref12 ? dichromat_streak_kernel<false, false, true, 12> : dichromat_streak_kernel<false>);
+    auto kdark = pref6 ? dichromat_streak_kernel<true, false, true, 6> : (pref12 ? dichromat_streak_kernel<true, false, true, 12> : dichromat_streak_kernel<true>);
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kmain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kdark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long rows = (long)a.n_frames * a.H;
     const long cap = (long)ctx->num_cus * 4;
     const int grid = (int)(rows < cap ? rows : cap);
+    if (getenv("AVX_TUNE_LOG")) { int pc = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, (const void*)kmain, kST, lds); fprintf(stderr, "[avx streak] lds=%zu occupancy=%d workgroups/CU grid=%d\n", lds, pc, grid); }
     AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
     hipLaunchKernelGGL(kmain, dim3(grid), dim3(kST), lds, s, a, st, qc);
     AVX_HIP(ctx, hipGetLastError());
@@ -284,7 +292,7 @@ extern "C" int avx_streak_planes_f32(avx_ctx* ctx, const float* src_planes, floa
     avx_ws* ws = avx_workspace(ctx, s);
     AVX_REQUIRE(ctx, ws != nullptr, "avx_streak_planes_f32: no workspace for this stream");
     const int PW = ((W + 3) / 4 * 4) + 2 * 16;
-    const size_t lds = sizeof(float) * (size_t)PW * 6 + (((size_t)W * 3 + 15) & ~(size_t)15);
+    const size_t lds = sizeof(float) * (size_t)PW * 6;
     AVX_REQUIRE(ctx, lds <= 150 * 1024, "avx_streak_planes_f32: frame width %d too large (a row must fit LDS)", W);
     const size_t tbytes = sizeof(float) * (size_t)H * stride;
     if (tbytes > ws->row_gain_cap * sizeof(float)) {
