@@ -713,6 +713,59 @@ int launch_posemb(avx_ctx* ctx, const void* v, const float* w1, const float* w2,
     return AVX_OK;
 }
 
+// ---- ConvTranspose2d(C -> C/2, kernel 2, stride 2) + bias: MST decoder upsampling (:214, :256) -------------------------
+// Kernel size == stride: output pixel (2y + dy, 2x + dx) depends on input pixel (y, x) alone, through tap (dy, dx) -- four
+// independent C x C/2 GEMMs whose results interleave in the output.  A wave takes 32 consecutive input pixels of a row and
+// writes, per tap and output-channel tile, 32 contiguous bytes per lane at the scattered output pixel.
+template <int C>
+__global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ x /*[B][H][W][C]*/, const uint2* __restrict__ wpack /*[4][C/64][C/8][64]*/,
+                                                     const float* __restrict__ bias /*[C/2]*/, __half* __restrict__ out /*[B][2H][2W][C/2]*/, int B, int H, int W) {
+    constexpr int KS = C / 8, CO = C / 2, NT = CO / 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2* wl = reinterpret_cast<uint2*>(smem);
+    float* bl = reinterpret_cast<float*>(smem + (size_t)4 * NT * KS * 64 * sizeof(uint2));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * NT * KS * 64; i += kT) wl[i] = wpack[i];
+    for (int i = tid; i < CO; i += kT) bl[i] = bias[i];
+    __syncthreads();
+    const int xt = (W + 31) / 32;
+    const long total = (long)B * H * xt;
+    const int p = lane & 31, h = lane >> 5;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < total; tile += (long)gridDim.x * 4) {
+        const int x0 = (int)(tile % xt) * 32, y = (int)((tile / xt) % H);
+        const long b = tile / ((long)xt * H);
+        const int xw = x0 + p;
+        half4_t xf[KS];
+        {
+            const size_t row = (size_t)((b * H + y) * (long)W + (xw < W ? xw : W - 1));
+            const uint4* src = reinterpret_cast<const uint4*>(x + row * C + h * (C / 2));
+#pragma unroll
+            for (int q = 0; q < C / 16; ++q) {
+                const half8_t h8 = __builtin_bit_cast(half8_t, src[q]);
+                xf[2 * q] = half4_t{h8[0], h8[1], h8[2], h8[3]};
+                xf[2 * q + 1] = half4_t{h8[4], h8[5], h8[6], h8[7]};
+            }
+        }
+        if constexpr (C > 64) asm volatile("" ::: "memory");  // weight fragments stay in LDS
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            const size_t opix = ((size_t)(b * 2 * H + 2 * y + (tap >> 1)) * (size_t)(2 * W) + (size_t)(2 * xw + (tap & 1)));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float16_t d;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) d[v] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d = mfma(__builtin_bit_cast(half4_t, wl[((tap * NT + t) * KS + s) * 64 + lane]), xf[s], d);
+                _Float16 o[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) o[v] = (_Float16)(d[v] + bl[32 * t + 16 * h + v]);
+                if (xw < W) store_tile16(out + opix * CO + 32 * t + 16 * h, o);
+            }
+        }
+    }
+}
+
 template <int C>
 int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
     constexpr int KS = C / 8, HD = C / 32;
@@ -869,6 +922,30 @@ int avx_mst_posemb(avx_ctx* ctx, const void* v, const float* w1_c9, const float*
     if (C == 32) return launch_posemb<32, 8, 32>(ctx, v, w1_c9, w2_c9, residual, bias, out, B, H, W, s);
     if (C == 64) return launch_posemb<64, 8, 16>(ctx, v, w1_c9, w2_c9, residual, bias, out, B, H, W, s);
     return launch_posemb<128, 4, 16>(ctx, v, w1_c9, w2_c9, residual, bias, out, B, H, W, s);
+}
+
+int avx_mst_convt2x2(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack && bias && out && B > 0 && H > 0 && W > 0, "avx_mst_convt2x2: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 64 || C == 128, "avx_mst_convt2x2: C=%d (64 or 128 input channels)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)out)) & 15u) == 0, "avx_mst_convt2x2: pointers must be 16-byte aligned");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    const long total = (long)B * H * ((W + 31) / 32);
+    long blocks = (total + 3) / 4;
+    const long cap = (long)ctx->num_cus * (C == 128 ? 2 : 8);
+    if (blocks > cap) blocks = cap;
+    if (C == 64) {
+        const size_t lds = (size_t)4 * 1 * 8 * 64 * sizeof(uint2) + sizeof(float) * 32;
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mst_convt2x2<64>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (__half*)out, B, H, W);
+    } else {
+        const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(uint2) + sizeof(float) * 64;
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mst_convt2x2<128>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (__half*)out, B, H, W);
+    }
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
 }
 
 }  // extern "C"

@@ -164,6 +164,18 @@ class _AvxOps:
                                             torch.cuda.current_stream(x2.device).cuda_stream))
         return out
 
+    def convt2x2(self, x: torch.Tensor, wpack: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+        """ConvTranspose2d(c -> c/2, 2, stride 2) + bias on (b, h, w, c) float16 -> (b, 2h, 2w, c/2) (csrc/mst_mfma.hip)."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        x = x.contiguous()
+        out = torch.empty((b, 2 * h, 2 * w, c // 2), dtype=torch.float16, device=x.device)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_convt2x2(ctx._h, x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), out.data_ptr(), b, h, w, c,
+                                        torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
     def posemb(self, v: torch.Tensor, w1_c9: torch.Tensor, w2_c9: torch.Tensor, residual: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
         """dw3x3(gelu(dw3x3(v))) + residual + bias on (b, h, w, c) float16 in one pass (csrc/mst_mfma.hip::k_mst_posemb)."""
         from .._lib import lib
@@ -486,8 +498,13 @@ class MSTPlusPlus(torch.nn.Module):
             heads *= 2
         fea = self._msab(fea, p + ".bottleneck", heads)
         for i in range(2):
-            up = F.conv_transpose2d(fea.permute(0, 3, 1, 2), self._w(f"{p}.decoder_layers.{i}.0.weight", (0, 1)),
-                                    self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)), stride=2).permute(0, 2, 3, 1)
+            kw = f"{p}.decoder_layers.{i}.0.weight"
+            if _AVX.fused_ok(fea) and fea.shape[-1] in (64, 128):  # four 1x1 products on the matrix cores (kernel size == stride)
+                wt = self._prep(kw + ".frag4", lambda: torch.stack([pack_fragments(self._w(kw, (0, 1))[:, :, t // 2, t % 2].contiguous(), True) for t in range(4)]).contiguous())
+                bt = self._prep(kw + ".bias32", lambda: self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)).float().contiguous())
+                up = _AVX.convt2x2(fea, wt, bt)
+            else:
+                up = F.conv_transpose2d(fea.permute(0, 3, 1, 2), self._w(kw, (0, 1)), self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)), stride=2).permute(0, 2, 3, 1)
             heads //= 2
             skip = skips[1 - i]
             b, h, w, ch = up.shape

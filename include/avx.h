@@ -355,6 +355,10 @@ int avx_mst_conv3x3_add(avx_ctx* ctx, const void* x, const void* wpack, const vo
 int avx_mst_posemb(avx_ctx* ctx, const void* v, const float* w1_c9, const float* w2_c9, const void* residual, const float* bias, void* out, int B,
                    int H, int W, int C, void* stream);
 
+/* ConvTranspose2d(C -> C/2, kernel 2, stride 2) + bias on B x H x W x C float16 -> B x 2H x 2W x C/2 (MST decoder, :214,
+ * :256): four independent C x C/2 products, one per output-pixel parity.  wpack: 4 taps (dy*2 + dx) in fragment order. */
+int avx_mst_convt2x2(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, void* out, int B, int H, int W, int C, void* stream);
+
 /* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
  * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
 int avx_dwconv3x3_nhwc(avx_ctx* ctx, const void* x, const float* w_c9, void* y, int dtype, int B, int H, int W, int C, int gelu_out, void* stream);
