@@ -129,7 +129,9 @@ class Cat(_Dichromat):
     def visualize(self, image: np.ndarray):
         assert isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] == 3, "HxWx3 RGB"
         if image.dtype != np.uint8:
-            raise NotImplementedError(f"Cat: device path implemented for uint8 frames, got {image.dtype}")
+            if np.issubdtype(image.dtype, np.floating):
+                return self._visualize_float(image)
+            raise NotImplementedError(f"Cat: device path implemented for uint8 and float frames, got {image.dtype}")
         from .. import geometry as G
 
         H, W = image.shape[:2]
@@ -155,3 +157,55 @@ class Cat(_Dichromat):
         finally:
             d_in.free(); d_warp.free(); d_out.free()
         return human_zoomed, cat_out
+
+    def _visualize_float(self, image: np.ndarray):
+        """cat.py:73-112 for a float frame, as a plane program in float32 (the reference's float64 tail is held to the float
+        pipeline's 1e-4, like every float frame): get_normalized_image's `max > 1` rule, the binocular warp as two
+        cv2.remap's with per-column / per-row maps + the cos^2 blend, srgb_to_linear, RGB->LMS, L/M merge, LMS->RGB, sigma 1.0
+        blur, OETF; returns (centre-zoomed input, cat view), both in the input's dtype."""
+        from .. import geometry as G
+        from ..dichromat import cv_auto_ksize, gaussian_taps
+        from ..planevm import DeviceBackend, PlaneRef
+
+        H, W = image.shape[:2]
+        scale = G.zoom_scale_from_cat_ratio(camera_hfov_deg=self.CAMERA_HFOV_DEG, cat_per_eye_half_fov_deg=self.CAT_PER_EYE_HALF_FOV_DEG,
+                                            cat_to_human_ratio=self.CAT_TO_HUMAN_RATIO)
+        human_zoomed = G.center_zoom(image, scale=scale)
+        plans = self.__dict__.setdefault("_float_plans", {})
+        key = (H, W, bool(self.ENABLE_FOV_WARP))
+        be = plans.get(key)
+        if be is None:
+            if len(plans) >= 4:
+                plans.pop(next(iter(plans))).close()
+            be = DeviceBackend(H, W, float_frames=True)
+            y = [be.load(PlaneRef(be.d_in, 4 * c, 3)) for c in range(3)]
+            mx = be.max(be.maximum(be.maximum(y[0], y[1]), y[2]))
+            x = [be.clip01(be.where(mx > 1.0, v / 255.0, v)) for v in y]  # get_normalized_image (animal_utils.py:41-50)
+            if self.ENABLE_FOV_WARP:  # cat_widevision_utils.py:46-99
+                xL, xR, ymap, wL, wR = G.binocular_warp_tables(H, W, W, H, self.CAMERA_HFOV_DEG, self.CAT_PER_EYE_HALF_FOV_DEG, self.CAT_OVERLAP_DEG)
+                my = be.row(ymap)
+                left = be.remap(x, be.col(xL), my, 0.0)
+                right = be.remap(x, be.col(xR), my, 0.0)
+                cwl, cwr = be.col(wL), be.col(wR)
+                wsum = cwl + cwr + 1e-8
+                x = [be.clip01((left[c] * cwl + right[c] * cwr) / wsum) for c in range(3)]
+            a = 0.055
+            lin = [be.where(v <= 0.04045, v / 12.92, ((v + a) / (1 + a)) ** 2.4) for v in x]
+            M = [[0.31399022, 0.63951294, 0.04649755], [0.15537241, 0.75789446, 0.08670142], [0.01775239, 0.10944209, 0.87256922]]
+            Bk = [[5.472213, -4.6419606, 0.16963711], [-1.125242, 2.2931712, -0.16789523], [0.02980164, -0.19318072, 1.1636479]]
+            lms = [lin[0] * M[i][0] + lin[1] * M[i][1] + lin[2] * M[i][2] for i in range(3)]       # animal_utils.py:52-63
+            al = float(np.float32(self.SPEC.alpha))
+            lm = lms[0] * al + lms[1] * float(np.float32(1.0 - self.SPEC.alpha))                    # cat.py:99
+            rgb = [lm * Bk[i][0] + lm * Bk[i][1] + lms[2] * Bk[i][2] for i in range(3)]            # LMS_to_RGB (:65-77)
+            k = cv_auto_ksize(self.SPEC.sigma)
+            rgb = be.blur_taps(rgb, k, gaussian_taps(k, self.SPEC.sigma))
+            for c in range(3):
+                v = be.clip01(rgb[c])
+                be.store(be.clip01(be.where(v <= 0.0031308, 12.92 * v, (1 + a) * be.power(v, 1 / 2.4) - a)), PlaneRef(be.d_out, 4 * c, 3))
+            be.flush()
+            plans[key] = be
+        ctx = be.ctx
+        ctx.upload(np.ascontiguousarray(image, dtype=np.float32), be.d_in)
+        be.run_device()
+        out = ctx.download(be.d_out, image.shape, np.float32)
+        return human_zoomed.astype(image.dtype, copy=False), out.astype(image.dtype, copy=False)

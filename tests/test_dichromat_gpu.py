@@ -135,8 +135,8 @@ def test_bad_arguments_raise(av):
         Dog().visualize(np.zeros((4, 4, 3), np.int32))
     from animal_vision_amd.animals import Cat
 
-    with pytest.raises(NotImplementedError):  # float frames: the collapse-matrix species only (Cat's tail is float64)
-        Cat().visualize(np.zeros((4, 4, 3), np.float32))
+    with pytest.raises(NotImplementedError):
+        Cat().visualize(np.zeros((4, 4, 3), np.int32))
 
 
 @pytest.mark.parametrize("name", ["dog", "wolf", "rat", "squirrel", "sheep", "pig", "rabbit", "panda", "kangaroo"])
@@ -173,3 +173,21 @@ def test_marching_kernel_ragged_strips_and_misaligned_frames(av, oracle, name):
         for i in range(n):
             _, want = oracle.dichromat_visualize(oracle.DICHROMATS[name], batch[i])
             assert np.array_equal(got[i], want), f"{name} frame {i} of {(n, H, W)}: {int((got[i] != want).sum())} bytes differ"
+
+
+@pytest.mark.parametrize("warp", [False, True])
+def test_cat_float_frames(av, oracle, warp):
+    """Same-dtype contract for Cat on float frames: float32 in [0,1] and [0,255], float64; zoomed baseline + cat
+    view (with and without the binocular FOV warp) against the oracle's cat_visualize, 1e-4 (float pipeline)."""
+    from animal_vision_amd.animals import Cat
+    from animal_vision_amd.synthetic import structured_frame
+
+    u8 = structured_frame(5, 72, 100)
+    cat = Cat()
+    cat.ENABLE_FOV_WARP = warp
+    for frame in ((u8 / 255.0).astype(np.float32), u8.astype(np.float32), u8 / 255.0):
+        base, out = cat.visualize(frame)
+        want_base, want = oracle.cat_visualize(frame, enable_fov_warp=warp)
+        assert out.dtype == frame.dtype == want.dtype and out.shape == frame.shape and base.dtype == frame.dtype
+        np.testing.assert_allclose(out, want, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(base, want_base, rtol=0, atol=1e-4 * max(1.0, float(frame.max())))
