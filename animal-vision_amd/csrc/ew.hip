@@ -90,8 +90,12 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
 #pragma unroll
             EW_FOR { py[k] = ii[k] / W; px[k] = ii[k] - py[k] * W; }
         }
+        // The instruction word of pc + 1 is fetched (scalar load from the kernel-argument segment) while pc executes: fetched at
+        // the top of its own iteration, every instruction began with an exposed scalar-cache round trip.
+        avx_ew_insn in_next = a.insn[0];
         for (int pc = 0; pc < a.n_insn; ++pc) {
-            const avx_ew_insn in = a.insn[pc];
+            const avx_ew_insn in = in_next;
+            in_next = a.insn[pc + 1 < a.n_insn ? pc + 1 : pc];
             const int ra = in.a & (NREG - 1), rb = in.b & (NREG - 1), rd = in.dst & (NREG - 1);
             const float imm = __uint_as_float(in.imm);
             const bool ia = in.op & AVX_EW_IMM_A, ib = in.op & AVX_EW_IMM_B;  // an operand is the immediate constant
