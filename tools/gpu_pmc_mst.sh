@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the MST++ route (separate runs per counter group; --pmc only, no trace domains): per-kernel means.
+# PMC passes over the MST++ route (WL=...: any workload; kernels of the library are reported by name) (separate runs per counter group; --pmc only, no trace domains): per-kernel means.
 set -o pipefail
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_mst
@@ -16,7 +16,7 @@ GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LD
 TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TA_BUSY TA_FLAT_READ_WAVEFRONTS TA_FLAT_WRITE_WAVEFRONTS
 GROUPS
 python - <<'PY' | tee gpurun_out/pmc_mst/summary.txt
-import csv, glob, collections
+import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
@@ -25,11 +25,12 @@ for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive
     for r in rows:
         byk[r["Kernel_Name"]].append(r)
     for k, rs in byk.items():
-        if "k_mst_" not in k and "k_dwconv" not in k:
+        if not any(t in k for t in ("k_mst_", "k_dwconv", "k_ew", "k_sel_pass", "k_plane_blur", "streak")):
             continue
         ids = sorted({int(r["Dispatch_Id"]) for r in rs})
         keep = set(ids[len(ids) * 2 // 3:])
-        name = k.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        mm = re.search(r"(k_\w+(<[^>]*>)?|dichromat_\w+)", k)
+        name = mm.group(1) if mm else k[:40]
         for r in rs:
             if int(r["Dispatch_Id"]) in keep:
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
