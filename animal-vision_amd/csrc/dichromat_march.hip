@@ -211,6 +211,7 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
             rv[n] = *reinterpret_cast<const uint32_t*>(fin_base + (size_t)(aoff + (uint32_t)dc * 4u));
         }
     };
+    bool flag_done = false;  // wave-uniform: this wave has already reported a byte > 1 for the frame -- nothing left to detect
     auto write_raw = [&](int t, const uint32_t (&rv)[NLD]) {
         uint8_t* RAW = RAW_of(t);
         uint32_t seen = 0;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
                 if (seg == 0) rowshift[(t & 1) * SY + s] = (uint8_t)shift;  // every lane stores the same byte: no branch
                 {
                     *reinterpret_cast<uint32_t*>(RAW + (size_t)s * C::RAWP + C::RAW_LEAD + d * 4) = rv[n];
-                    if (!DARK) {
+                    if (!DARK && !flag_done) {
                         // "byte > 1" detector, masked to the row's own bytes: only the first and the last dword of a row
                         // hold foreign bytes (<= 3 before / after it); lanes past the last dword hold copies of it
                         const int last = ((int)shift + row_bytes - 1) >> 2;                        // scalar
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
                 }
             }
         }
-        if (!DARK && seen) a.flags[f] = 1u;  // benign race: every writer stores the same value
+        if (!DARK && !flag_done) {
+            if (seen) a.flags[f] = 1u;  // benign race: every writer stores the same value
+            flag_done = __builtin_amdgcn_readfirstlane((uint32_t)(__ballot(seen != 0u) != 0ull)) != 0u;
+        }
     };
     // ---- output rows of iteration t: OUT (LDS) -> HBM -------------------------------------------
     // Store granularity is the same for every row of the strip: 16 bytes when row pitch, strip origin
