@@ -399,24 +399,53 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one row-pair window live at a time (register budget)
             }
+            // Column pass for all SY rows first, then the quantiser in BATCHES: every bucket lookup of the iteration is issued
+            // before the first refinement read, and every byte is written at the end.  Written row by row, each row's two
+            // dependent LDS lookups (bucket table, then threshold) completed before the next row started -- the OUT byte
+            // stores in between keep the compiler from hoisting the next row's reads -- and the quantiser was 47 % of the compute
+            // waves' iteration (in-kernel stamps with the lookups ablated).
+            constexpr int NS = SY * XPT;  // samples of this thread in the iteration
+            T sv[NS];
 #pragma unroll
-            for (int i = 0; i < ((ablate & 4) ? 0 : SY); ++i) {
+            for (int i = 0; i < SY; ++i) {
 #pragma unroll
                 for (int xp = 0; xp < XPT / 2; ++xp) {
                     P sacc = cw[xp][R + i] * kk[0];
 #pragma unroll
                     for (int j = 1; j <= R; ++j) sacc = pfma(cw[xp][R + i + j] + cw[xp][R + i - j], kk[j], sacc);
-                    uint32_t q0, q1;
-                    if (ablate & 8) {
-                        q0 = (uint32_t)(sacc.x * (T)255); q1 = (uint32_t)(sacc.y * (T)255);
-                    } else {
-                        q0 = quantize_coarse<T, NFIX>(sacc.x, thr, coarse, qc.lo_key);
-                        q1 = quantize_coarse<T, NFIX>(sacc.y, thr, coarse, qc.lo_key);
-                    }
-                    uint8_t* dst = OUT + (size_t)i * C::OUTP + (xg * XPT + 2 * xp) * 3 + c;
-                    dst[0] = (uint8_t)q0;
-                    dst[3] = (uint8_t)q1;
+                    sv[i * XPT + 2 * xp] = sacc.x;
+                    sv[i * XPT + 2 * xp + 1] = sacc.y;
                 }
+            }
+            if (!(ablate & 4)) {
+                uint32_t q[NS];
+                if (ablate & 8) {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) q[n] = (uint32_t)(sv[n] * (T)255);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) {  // clip + bucket lookups, all in flight together
+                        sv[n] = sv[n] < (T)0 ? (T)0 : (sv[n] > (T)1 ? (T)1 : sv[n]);
+                        const uint32_t key = key_of(sv[n]);
+                        q[n] = (uint32_t)coarse[(key > qc.lo_key ? key : qc.lo_key) - qc.lo_key];
+                    }
+#pragma unroll
+                    for (int f2 = 0; f2 < NFIX; ++f2) {  // refinement: thr[255] is a huge pad, never passes
+                        T tv[NS];
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) tv[n] = thr[q[n]];
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) q[n] += (tv[n] <= sv[n]) ? 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < SY; ++i)
+#pragma unroll
+                    for (int xp = 0; xp < XPT / 2; ++xp) {
+                        uint8_t* dst = OUT + (size_t)i * C::OUTP + (xg * XPT + 2 * xp) * 3 + c;
+                        dst[0] = (uint8_t)q[i * XPT + 2 * xp];
+                        dst[3] = (uint8_t)q[i * XPT + 2 * xp + 1];
+                    }
             }
         }
     };
