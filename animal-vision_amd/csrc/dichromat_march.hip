@@ -178,7 +178,6 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     // The host only launches this kernel on batches whose byte size and base address are multiples of 4 (every standard
     // video size): aligned dwords that contain a valid byte then never cross the end of the batch, and no tail guard is
     // needed.  (The guarded path used to live here too; its scalar bookkeeping alone spilled 14 SGPRs through v_readlane.)
-    uint8_t* rowshift = smem_raw + C::off_ktab + 48 * sizeof(T);  // [2][SY] raw-row misalignments, by iteration parity
     // Row addressing in 32 bits: offsets are relative to the frame base rounded DOWN to a dword (the host checks that a frame
     // is < 4 GiB), so a row costs three scalar instructions instead of a 64-bit multiply-add chain, and a load is one vector
     // add on top of a scalar base.  A wave issues one instruction every four cycles at best: this bookkeeping, not the
@@ -223,7 +222,6 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
                 const int d = seg * 64 + lane;
                 uint32_t shift;
                 (void)row_off(t, s, shift);                       // scalar
-                if (seg == 0) rowshift[(t & 1) * SY + s] = (uint8_t)shift;  // every lane stores the same byte: no branch
                 {
                     *reinterpret_cast<uint32_t*>(RAW + (size_t)s * C::RAWP + C::RAW_LEAD + d * 4) = rv[n];
                     if (!DARK && !flag_done) {
@@ -300,7 +298,8 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int s = 2 * sp + h;
-                const uint32_t shift = rowshift[(t & 1) * SY + s];
+                uint32_t shift;  // the row's dword misalignment: three scalar instructions to recompute -- as a byte parked in LDS by the
+                (void)row_off(t, s, shift);  // staging step it was one more dependent LDS round trip at the head of the decode chain
                 const int boff = C::RAW_LEAD + (int)shift - 3 * lead + 12 * q4;  // LDS byte offset of pixel lx = 4*q4
                 const uint32_t* dw = reinterpret_cast<const uint32_t*>(RAW + (size_t)s * C::RAWP + (boff & ~3));
                 const uint32_t sh = (uint32_t)boff & 3u;
