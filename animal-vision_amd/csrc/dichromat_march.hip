@@ -52,8 +52,10 @@ struct MarchCfg {
     static constexpr int NWV = 1 + (2 * R + XPT - 1) / XPT;   // vector reads per row window
     static constexpr int NG4 = (AWS + 3) / 4;                 // decode groups (4 px) per row
     // SPEC: the producer decodes a row pair in ONE pass of its 64 lanes, so a strip (with halo) is at most 256 / SY px wide
-    static constexpr int NG4S = 64 / (SY / 2);
-    static constexpr int SW_CAP = SPEC ? (NG4S * 4 - 2 * R < SW ? NG4S * 4 - 2 * R : SW) : SW;
+    // (float64 only: its decode is heavy enough that a second, nearly empty pass would cost more than the narrower strips)
+    static constexpr bool kCapStrips = SPEC && sizeof(T) == 8;
+    static constexpr int NG4S = kCapStrips ? 64 / (SY / 2) : NG4;
+    static constexpr int SW_CAP = kCapStrips ? (NG4S * 4 - 2 * R < SW ? NG4S * 4 - 2 * R : SW) : SW;
     static constexpr int PA0 = SW - XPT + NWV * XPT;
     static constexpr int PA = ((PA0 > NG4 * 4 ? PA0 : NG4 * 4) + 3) / 4 * 4;
     static constexpr int RAW_LEAD = 64;
@@ -627,14 +629,15 @@ static uint64_t width_key(bool f64, int R, int frames, int H, int W) {
 // shapes start tuned; any other (kernel, batch, frame size) is measured on its first call.
 void avx_march_seed_tuned(avx_ctx* ctx) {
     static const struct { int f64, R, frames, H, W, NG, chunks; } kSeed[] = {
-        {0, 14, 32, 1080, 1920, 64, 2},   // dog 1080p
-        {0, 14, 8, 2160, 3840, 64, 8},    // dog 4K
+        {0, 14, 32, 1080, 1920, 64, 3},   // dog 1080p
+        {0, 14, 8, 2160, 3840, 64, 16},   // dog 4K
         {0, 6, 32, 1080, 1920, 64, 8},    // wolf 1080p
         {0, 5, 32, 1080, 1920, 64, 8},    // lion / tiger 1080p
-        {0, 3, 32, 1080, 1920, 128, 4},   // squirrel 1080p
+        {0, 3, 32, 1080, 1920, 64, 6},    // squirrel 1080p
         {1, 4, 32, 1080, 1920, 64, 8},    // cat 1080p (default bench; wave-specialised form)
         {1, 4, 8, 2160, 3840, 64, 24},    // cat 4K
     };
+    if (getenv("AVX_MARCH_NOSEED")) return;  // measure everything on first use (re-deriving the table below)
     for (const auto& e : kSeed) {
         if (ctx->n_march_tuned + 2 > 64) break;
         ctx->march_tuned[ctx->n_march_tuned++] = {width_key(e.f64, e.R, e.frames, e.H, e.W), e.NG};
@@ -655,16 +658,17 @@ static int march_dispatch(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_de
     switch (a.r) {
         // <R, SY, XPT, min waves/SIMD>, from A/B runs on MI355X: 2 columns per thread keeps the
         // row-window reads conflict-free (16-byte lane stride) and the register windows under 128 VGPRs.
-        // SP: the 192-thread form runs wave-specialised (+ one producer wave; strips capped at 128 - 2R px so the producer
-        // decodes a row pair in one pass).  Measured for the float32 species (wolf, lion: 0.58 / 0.55 ms against 0.44 / 0.41 ms
-        // plain): their decode is too light to fill a producer wave and the narrower strips idle compute lanes -- off.
+        // SP: the 192-thread form runs wave-specialised (+ one producer wave that stages and decodes; full-width strips, the
+        // producer takes two or three passes over a row pair).  Measured on for every float32 radius: wolf 165 -> 175, lion
+        // 176 -> 203, squirrel 202 -> 236, dog 110 -> 120 GP/s.  The 384-thread form stays plain (one producer cannot feed
+        // six compute waves: 0.56 vs 0.33 ms for squirrel) and remains the tuner's alternative.
 #define AVX_MARCH_F32(RR, XX, MW, SP)                                                                        \
     case RR:                                                                                                 \
         return ng64 ? launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, 64, MW, NF, SP>(ctx, a, d, qc, s)      \
                     : launch_march<float, AVX_COLOR_MATRIX, RR, 4, XX, 128, MW, NF>(ctx, a, d, qc, s);
-        AVX_MARCH_F32(1, 4, 3, false) AVX_MARCH_F32(3, 4, 3, false) AVX_MARCH_F32(4, 2, 3, false) AVX_MARCH_F32(5, 2, 3, false)
-        AVX_MARCH_F32(6, 2, 3, false) AVX_MARCH_F32(7, 2, 3, false) AVX_MARCH_F32(8, 2, 3, false) AVX_MARCH_F32(9, 2, 3, false)
-        AVX_MARCH_F32(14, 2, 2, false)
+        AVX_MARCH_F32(1, 4, 3, true) AVX_MARCH_F32(3, 4, 3, true) AVX_MARCH_F32(4, 2, 3, true) AVX_MARCH_F32(5, 2, 3, true)
+        AVX_MARCH_F32(6, 2, 3, true) AVX_MARCH_F32(7, 2, 3, true) AVX_MARCH_F32(8, 2, 3, true) AVX_MARCH_F32(9, 2, 3, true)
+        AVX_MARCH_F32(14, 2, 2, true)
 #undef AVX_MARCH_F32
         default: return AVX_ERR_UNSUPPORTED;
     }

@@ -9,7 +9,7 @@ while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
   rm -rf gpurun_out/pmc/p$i
-  timeout -k 10 300 rocprofv3 --pmc $group --output-format csv -d gpurun_out/pmc/p$i -- python bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc/p$i.out 2> gpurun_out/pmc/p$i.err || { tail -5 gpurun_out/pmc/p$i.err; }
+  timeout -k 10 300 rocprofv3 --pmc $group --output-format csv -d gpurun_out/pmc/p$i -- python bench.py --workload $WL --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-e2e > gpurun_out/pmc/p$i.out 2> gpurun_out/pmc/p$i.err || { tail -5 gpurun_out/pmc/p$i.err; }
 done <<GROUPS
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA

@@ -8,7 +8,7 @@ while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
   rm -rf gpurun_out/pmc_mst/p$i
-  timeout -k 10 300 rocprofv3 --pmc $group --output-format csv -d gpurun_out/pmc_mst/p$i -- python bench.py --workload ${WL:-honeybee_mst_1080p} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc_mst/p$i.out 2> gpurun_out/pmc_mst/p$i.err || { tail -3 gpurun_out/pmc_mst/p$i.err; }
+  timeout -k 10 300 rocprofv3 --pmc $group --output-format csv -d gpurun_out/pmc_mst/p$i -- python bench.py --workload ${WL:-honeybee_mst_1080p} --steps 2 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-e2e > gpurun_out/pmc_mst/p$i.out 2> gpurun_out/pmc_mst/p$i.err || { tail -3 gpurun_out/pmc_mst/p$i.err; }
 done <<GROUPS
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_INST_ANY
 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
