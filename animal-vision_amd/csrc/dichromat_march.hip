@@ -291,11 +291,17 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
         const uint8_t* RAW = RAW_of(t);
         P* A = A_of(t);
         if (!decoder) return;  // (SPEC only: the plain form has a barrier below that every thread must reach)
-        constexpr int kNG4 = SPEC ? C::NG4S : C::NG4, kStep = SPEC ? 64 : kMarchThreads;
+        constexpr int kStep = SPEC ? 64 : kMarchThreads;
+        // SPEC: items run over the strip's ACTUAL haloed width, row pairs interleaved (item = q4 * SY/2 + sp) -- how many 64-lane
+        // passes the producer needs is then the host's choice of strip width alone (launch_march), not a compile-time constant
+        constexpr bool kMix = SPEC && sizeof(T) == 4;  // (the float64 cat keeps row-pair-major items over its fixed 120-px strips:
+                                                       //  interleaved, its 16-byte plane writes conflict -- 143 -> 114 GP/s)
+        constexpr int kNG4 = kMix ? 1 : (SPEC ? C::NG4S : C::NG4);
+        const int item_end = kMix ? (SY / 2) * ((aws + 3) >> 2) : (SY / 2) * kNG4;
 #pragma unroll 1
-        for (int item = (ablate & 1) ? (1 << 30) : (SPEC ? lane : tid); item < (SY / 2) * kNG4; item += kStep) {
-            const int sp = item / kNG4, q4 = item - sp * kNG4;
-            if (q4 * 4 >= aws) continue;
+        for (int item = (ablate & 1) ? (1 << 30) : (SPEC ? lane : tid); item < item_end; item += kStep) {
+            const int sp = kMix ? item % (SY / 2) : item / kNG4, q4 = kMix ? item / (SY / 2) : item - sp * kNG4;
+            if (!kMix && q4 * 4 >= aws) continue;
             uint32_t code[2][4][3];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -503,6 +509,8 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     }
 }
 
+constexpr int kNarrowStrips = 1 << 16;  // flag bit in a remembered launch geometry: use the narrowed strips
+
 template <typename T, int COLOR, int R, int SY, int XPT, int NG, int MINW, int NFIX, bool SPEC = false>
 int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, const QuantCoarse& qc, hipStream_t s) {
     using C = MarchCfg<T, R, SY, XPT, NG, SPEC>;
@@ -519,14 +527,38 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
     AVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kmain, kMarchThreads, lds));
     if (per_cu < 1) per_cu = 1;
     MarchGeom g{};
-    g.nstrips = (a.W + C::SW_CAP - 1) / C::SW_CAP;
-    g.sw = ((a.W + g.nstrips - 1) / g.nstrips + C::XPT - 1) / C::XPT * C::XPT;
+    // Strip width.  The producer wave (SPEC) decodes a strip's row pairs in passes of 64 items (4 px x 2 rows each); a pass
+    // costs the same whether 64 lanes or 6 are active, so a strip whose last pass would be nearly empty MAY be better narrowed
+    // to fit one pass less (cat: 120 px, fixed in MarchCfg; float32: a multiple of 16 px so rows still store as 16-byte
+    // vectors -- wolf 1080p: 112-px strips, +4 %; lion, squirrel: no difference; dog: 96-px strips leave a quarter of the
+    // compute lanes idle, -17 %).  Like the row split below it is measured on first use.  AVX_MARCH_SWCAP pins it (0 = full).
+    int sw_narrow = 0;  // the narrowed alternative, 0 = none
+    if constexpr (SPEC && sizeof(T) == 4) {
+        constexpr int items = (SY / 2) * C::NG4, passes = (items + 63) / 64;
+        if (passes > 1) sw_narrow = (((passes - 1) * 64 / (SY / 2)) * 4 - 2 * R) / 16 * 16;
+        if (sw_narrow < 32 || sw_narrow >= C::SW) sw_narrow = 0;
+    }
+    long cols = 0;
+    auto set_strips = [&](int sw_cap) {
+        g.nstrips = (a.W + sw_cap - 1) / sw_cap;
+        g.sw = ((a.W + g.nstrips - 1) / g.nstrips + C::XPT - 1) / C::XPT * C::XPT;
+        // prefer 16-px multiples (16-byte output vectors) when they fit under the cap, even if the last strip comes out narrower
+        const int sw16 = (g.sw + 15) / 16 * 16;
+        if (sw16 <= sw_cap) { g.sw = sw16; g.nstrips = (a.W + g.sw - 1) / g.sw; }
+        cols = (long)a.n_frames * g.nstrips;
+    };
+    int sw_base = C::SW_CAP;
+    if constexpr (SPEC && sizeof(T) == 4) {
+        const char* ce = getenv("AVX_MARCH_SWCAP");
+        if (ce && *ce) { const int v = atoi(ce); sw_base = v >= 32 && v < C::SW ? v / C::XPT * C::XPT : C::SW; sw_narrow = 0; }
+    }
+    if (a.W <= sw_narrow) sw_narrow = 0;
+    set_strips(sw_base);
     // Row chunks per (frame, strip).  The best split depends on how the workgroup count tiles the resident slots, the XCD
     // round-robin and the priming cost (2R rows per chunk): measured, not modelled -- the first call for a (kernel
     // configuration, batch, frame size) times a handful of candidates on the caller's own frames (the output does not
     // depend on the split) and the winner is remembered in the context.  AVX_MARCH_CHUNKS pins it.
     const long resident = (long)ctx->num_cus * per_cu;
-    const long cols = (long)a.n_frames * g.nstrips;
     const long max_chunks = a.H / (8 * SY) > 0 ? a.H / (8 * SY) : 1;  // never shorter than 8*SY rows
     auto set_chunks = [&](long nc) {
         if (nc > max_chunks) nc = max_chunks;
@@ -553,6 +585,22 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
             hipEvent_t e0, e1;
             AVX_HIP(ctx, hipEventCreate(&e0));
             AVX_HIP(ctx, hipEventCreate(&e1));
+            {   // An idle GPU runs its first tens of milliseconds at lower clocks: the candidates timed first would lose to the
+                // ones timed last.  Run the fallback geometry until ~40 ms have passed before timing anything.
+                const long tot = set_chunks(nchunks);
+                float warm_ms = 0.f;
+                for (int i = 0; i < 200 && warm_ms < 40.f && tot < (1L << 30); ++i) {
+                    AVX_HIP(ctx, hipEventRecord(e0, s));
+                    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(kmain, dim3((unsigned)tot), dim3(kMarchThreads), lds, s, a, taps, qc, g);
+                    AVX_HIP(ctx, hipEventRecord(e1, s));
+                    AVX_HIP(ctx, hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    AVX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+                    warm_ms += ms;
+                }
+            }
+            for (int narrow = 0; narrow <= (sw_narrow ? 1 : 0); ++narrow) {
+            if (narrow) set_strips(sw_narrow);
             long tried[10];
             int ntried = 0;
             for (long nc : cand) {
@@ -574,14 +622,16 @@ int launch_march(avx_ctx* ctx, DichromatArgs& a, const avx_dichromat_desc* d, co
                     AVX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
                     ms_min = ms < ms_min ? ms : ms_min;
                 }
-                if (ms_min < best_ms) { best_ms = ms_min; found = (int)nc; }
+                if (ms_min < best_ms) { best_ms = ms_min; found = (int)nc | (narrow ? kNarrowStrips : 0); }
+            }
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (found && ctx->n_march_tuned < 64) ctx->march_tuned[ctx->n_march_tuned++] = {tkey, found};
-            if (getenv("AVX_TUNE_LOG")) fprintf(stderr, "[avx tune] chunks: f64=%d R=%d NG=%d frames=%d H=%d W=%d -> %d (%.3f ms)\n", (int)(sizeof(T) == 8), R, NG, a.n_frames, a.H, a.W, found, best_ms);
+            if (getenv("AVX_TUNE_LOG")) fprintf(stderr, "[avx tune] chunks: f64=%d R=%d NG=%d frames=%d H=%d W=%d -> %d%s (%.3f ms)\n", (int)(sizeof(T) == 8), R, NG, a.n_frames, a.H, a.W, found & (kNarrowStrips - 1), (found & kNarrowStrips) ? " narrow strips" : "", best_ms);
         }
-        if (found) nchunks = found;
+        if (found) nchunks = found & (kNarrowStrips - 1);
+        set_strips((found & kNarrowStrips) && sw_narrow ? sw_narrow : sw_base);
     }
     const long total = set_chunks(nchunks);
     AVX_REQUIRE(ctx, total < (1L << 30), "avx_dichromat_u8: too many workgroups");
@@ -629,13 +679,13 @@ static uint64_t width_key(bool f64, int R, int frames, int H, int W) {
 // shapes start tuned; any other (kernel, batch, frame size) is measured on its first call.
 void avx_march_seed_tuned(avx_ctx* ctx) {
     static const struct { int f64, R, frames, H, W, NG, chunks; } kSeed[] = {
-        {0, 14, 32, 1080, 1920, 64, 3},   // dog 1080p
-        {0, 14, 8, 2160, 3840, 64, 16},   // dog 4K
-        {0, 6, 32, 1080, 1920, 64, 8},    // wolf 1080p
+        {0, 14, 32, 1080, 1920, 64, 4},   // dog 1080p
+        {0, 14, 8, 2160, 3840, 64, 6},    // dog 4K
+        {0, 6, 32, 1080, 1920, 64, 8 | kNarrowStrips},  // wolf 1080p (112-px strips: 191 -> 199 GP/s)
         {0, 5, 32, 1080, 1920, 64, 8},    // lion / tiger 1080p
         {0, 3, 32, 1080, 1920, 64, 6},    // squirrel 1080p
         {1, 4, 32, 1080, 1920, 64, 8},    // cat 1080p (default bench; wave-specialised form)
-        {1, 4, 8, 2160, 3840, 64, 24},    // cat 4K
+        {1, 4, 8, 2160, 3840, 64, 16},    // cat 4K
     };
     if (getenv("AVX_MARCH_NOSEED")) return;  // measure everything on first use (re-deriving the table below)
     for (const auto& e : kSeed) {
