@@ -41,6 +41,21 @@ static void avx_ws_release(avx_ws* w) {
     *w = avx_ws();
 }
 
+int avx_lanes(avx_ctx* ctx, int want) {
+    if (want > avx_ctx::kMaxLanes) want = avx_ctx::kMaxLanes;
+    if (!ctx->lane_fork && hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming) != hipSuccess) return 0;
+    while (ctx->n_lanes < want) {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(st); break; }
+        ctx->lanes[ctx->n_lanes] = st;
+        ctx->lane_done[ctx->n_lanes] = ev;
+        ++ctx->n_lanes;
+    }
+    return ctx->n_lanes < want ? ctx->n_lanes : want;
+}
+
 int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes) {
     if (bytes <= ws->scratch_cap) return AVX_OK;
     if (ws->d_scratch) {
@@ -152,6 +167,11 @@ void avx_destroy(avx_ctx* ctx) {
     for (int i = 0; i < ctx->n_ws; ++i) avx_ws_release(&ctx->ws[i]);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    for (int i = 0; i < ctx->n_lanes; ++i) {
+        (void)hipStreamDestroy(ctx->lanes[i]);
+        (void)hipEventDestroy(ctx->lane_done[i]);
+    }
+    if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
     delete ctx;
 }
 

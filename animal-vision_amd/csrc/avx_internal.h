@@ -54,12 +54,21 @@ struct avx_ctx {
     struct tuned { uint64_t key; int nchunks; };
     tuned march_tuned[64] = {};
     int n_march_tuned = 0;
+    // Frame lanes (uv.hip): the UV tail of a frame is ~10 dependent launches of 7-25 us each, none of which fills the GPU at
+    // 1080p; independent frames of a batch are therefore enqueued round-robin on these internal streams (forked from and
+    // joined back into the caller's stream with events), each with its own workspace, so their kernels overlap.
+    static constexpr int kMaxLanes = 8;
+    hipStream_t lanes[kMaxLanes] = {};
+    hipEvent_t lane_done[kMaxLanes] = {};
+    hipEvent_t lane_fork = nullptr;
+    int n_lanes = 0;
 };
 
 int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...);
 void avx_march_seed_tuned(avx_ctx* ctx);  // dichromat_march.hip: measured launch geometries of the standard workloads
 avx_ws* avx_workspace(avx_ctx* ctx, hipStream_t stream);  // find or create; NULL when all slots are taken
 int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes);
+int avx_lanes(avx_ctx* ctx, int want);  // creates the frame-lane streams on first use; returns how many exist (<= want), 0 on failure
 
 #define AVX_HIP(ctx, call)                                                                          \
     do {                                                                                            \

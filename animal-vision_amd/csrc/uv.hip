@@ -972,21 +972,40 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
     AVX_REQUIRE(ctx, d->blur_ksize == 0 || ((d->blur_ksize & 1) && d->blur_ksize <= AVX_MAX_KSIZE && d->blur_taps_host), "avx_honeybee_u8: bad blur");
     if (n_frames == 0) return AVX_OK;
     AVX_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = avx_pick_stream(ctx, stream);
-    UvScratch u;
-    avx_ws* ws = nullptr;
-    int rc = uv_small_scratch(ctx, s, &u, &ws);
-    if (rc) return rc;
+    hipStream_t s0 = avx_pick_stream(ctx, stream);
     const size_t n = (size_t)H * W;
-    rc = avx_ensure_scratch(ctx, ws, sizeof(float) * n * 9 + 256);
-    if (rc) return rc;
-    float* raw = (float*)ws->d_scratch;       // 3 planes: catches
-    float* ubg = raw + 3 * n;                 // 3 planes: adapted + blurred
-    float* aux = ubg + 3 * n;                 // 3 planes: radius/L, or mixed
     const int g = grid_for(ctx, n);
-    if (d->source == 0) AVX_HIP(ctx, hipMemcpyAsync(u.mat, d->rgb_matrix, sizeof(float) * 9, hipMemcpyHostToDevice, s));
-    else AVX_HIP(ctx, hipMemcpyAsync(u.mat, d->weights_host, sizeof(float) * 3 * d->bands, hipMemcpyHostToDevice, s));
+    // Frame lanes: the frames of a batch are independent and no kernel of this tail fills the GPU at video sizes, so frame f
+    // runs on internal stream f % lanes with that stream's own workspace (AVX_UV_LANES pins the count; 1 = the caller's
+    // stream only, which is also what a single frame uses).
+    int want_lanes = n_frames < 4 ? n_frames : 4;
+    { const char* e = getenv("AVX_UV_LANES"); if (e && *e) want_lanes = atoi(e) < n_frames ? atoi(e) : n_frames; }
+    const int n_lanes = want_lanes > 1 ? avx_lanes(ctx, want_lanes) : 0;
+    hipStream_t lane_s[avx_ctx::kMaxLanes];
+    UvScratch lane_u[avx_ctx::kMaxLanes];
+    float* lane_raw[avx_ctx::kMaxLanes];
+    const int n_run = n_lanes > 1 ? n_lanes : 1;
+    if (n_lanes > 1) AVX_HIP(ctx, hipEventRecord(ctx->lane_fork, s0));
+    for (int l = 0; l < n_run; ++l) {
+        lane_s[l] = n_lanes > 1 ? ctx->lanes[l] : s0;
+        if (n_lanes > 1) AVX_HIP(ctx, hipStreamWaitEvent(lane_s[l], ctx->lane_fork, 0));
+        avx_ws* ws = nullptr;
+        int rc = uv_small_scratch(ctx, lane_s[l], &lane_u[l], &ws);
+        if (rc) return rc;
+        rc = avx_ensure_scratch(ctx, ws, sizeof(float) * n * 9 + 256);
+        if (rc) return rc;
+        lane_raw[l] = (float*)ws->d_scratch;
+        if (d->source == 0) AVX_HIP(ctx, hipMemcpyAsync(lane_u[l].mat, d->rgb_matrix, sizeof(float) * 9, hipMemcpyHostToDevice, lane_s[l]));
+        else AVX_HIP(ctx, hipMemcpyAsync(lane_u[l].mat, d->weights_host, sizeof(float) * 3 * d->bands, hipMemcpyHostToDevice, lane_s[l]));
+    }
+    int rc = AVX_OK;
     for (int f = 0; f < n_frames; ++f) {
+        const int l = f % n_run;
+        hipStream_t s = lane_s[l];
+        const UvScratch& u = lane_u[l];
+        float* raw = lane_raw[l];                 // 3 planes: catches
+        float* ubg = raw + 3 * n;                 // 3 planes: adapted + blurred
+        float* aux = ubg + 3 * n;                 // 3 planes: radius/L, or mixed
         uint8_t* out = out_hwc + (size_t)f * n * 3;
         // 1-3) catches U, B, G (+ per-plane statistics)
         if (d->source == 0) {
@@ -1034,6 +1053,11 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
         hipLaunchKernelGGL(k_map_encode, dim3(g), dim3(kT), 0, s, m);
         AVX_HIP(ctx, hipGetLastError());
     }
+    if (n_lanes > 1)
+        for (int l = 0; l < n_run; ++l) {  // join: the caller's stream continues when every lane has drained
+            AVX_HIP(ctx, hipEventRecord(ctx->lane_done[l], lane_s[l]));
+            AVX_HIP(ctx, hipStreamWaitEvent(s0, ctx->lane_done[l], 0));
+        }
     return AVX_OK;
 }
 
