@@ -58,6 +58,16 @@ struct MarchCfg {
     static constexpr int SW_CAP = kCapStrips ? (NG4S * 4 - 2 * R < SW ? NG4S * 4 - 2 * R : SW) : SW;
     static constexpr int PA0 = SW - XPT + NWV * XPT;
     static constexpr int PA = ((PA0 > NG4 * 4 ? PA0 : NG4 * 4) + 3) / 4 * 4;
+    // kSplit (the float64 cat): a decoded plane row is stored as its even pixels followed by its odd pixels (PAH entries each).
+    // A thread of the row pass reads pixels 2 xg + i: with 16-byte entries in pixel order the lane stride is 32 bytes and every
+    // ds_read_b128 group hits each 16-byte slot twice; split by parity the stride is 16 bytes and the reads are conflict-free.
+    // The decode writes one pixel per lane per store (pixel = lane + 64 j), so the 8 lanes of a ds_write_b128 group put 4
+    // entries in each half: conflict-free as well when the halves are 64 bytes apart modulo the 128-byte write row
+    // (PAH = 4 mod 8).  Before: 56 % of the kernel's LDS cycles were bank conflicts (PMC), half from these stores (4-way:
+    // 64-byte lane stride), most of the rest from the row-pass reads.
+    static constexpr bool kSplit = SPEC && sizeof(T) == 8;
+    static constexpr int PAH = PA / 2;
+    static_assert(!kSplit || (PA % 2 == 0 && PAH % 8 == 4 && 2 * PAH >= SW + 2 * R && XPT_ % 2 == 0), "parity-split plane layout");
     static constexpr int RAW_LEAD = 64;
     static constexpr int DPR = (((AWS * 3 + 3 + 16 + 3) & ~3) / 4 + 63) / 64 * 64;  // dwords per raw row, whole 64-lane segments
     static constexpr int RAWP = RAW_LEAD + DPR * 4;
@@ -167,6 +177,11 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     const bool producer = SPEC && wave >= C::kComputeThreads / 64;  // from the readfirstlane'd wave index: a SCALAR condition, so the
                                                                     // role branches are uniform and the row bookkeeping stays on the SALU
     const bool decoder = !SPEC || producer;                   // who decodes
+    // The producer is one wave feeding three; it shares its SIMD with compute waves of this and other workgroups, and when it
+    // falls behind everyone waits at the barrier: it gets the higher issue priority (AVX_ABLATE bit 128 in the diagnostic
+    // build leaves it at the default).  Measured per configuration: cat 142 -> 149 GP/s, squirrel 244 -> 251; but dog 129 ->
+    // 121, wolf 198 -> 161, lion 205 -> 197 (their compute waves are the critical path), so only where it paid.
+    if (SPEC && (sizeof(T) == 8 || XPT_ == 4) && producer && !(ablate & 128)) __builtin_amdgcn_s_setprio(3);
     const bool stager = !SPEC || producer;                    // who stages the raw rows
     const int c = producer ? 0 : tid / kGroups;  // channel of this thread (uniform per wave: 128 = 2 waves)
     const int xg = tid - c * kGroups;            // column group: columns xg*XPT .. xg*XPT+XPT-1 of the strip
@@ -292,6 +307,71 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
         P* A = A_of(t);
         if (!decoder) return;  // (SPEC only: the plain form has a barrier below that every thread must reach)
         constexpr int kStep = SPEC ? 64 : kMarchThreads;
+        if constexpr (C::kSplit) {
+            // One pixel x two rows per lane and step (pixel = lane + 64 j): every plane store of the wave is lane-contiguous.
+            using F2 = typename Pair<float>::type;
+            using D2 = typename Pair<double>::type;
+            float M[12];
+            {
+                const float4 m0 = reinterpret_cast<const float4*>(cmf)[0], m1 = reinterpret_cast<const float4*>(cmf)[1], m2 = reinterpret_cast<const float4*>(cmf)[2];
+                M[0] = m0.x; M[1] = m0.y; M[2] = m0.z; M[3] = m0.w; M[4] = m1.x; M[5] = m1.y; M[6] = m1.z; M[7] = m1.w; M[8] = m2.x; M[9] = m2.y; M[10] = m2.z; M[11] = m2.w;
+            }
+#pragma unroll 1
+            for (int sp = (ablate & 1) ? SY : 0; sp < SY / 2; ++sp) {
+                uint32_t shift0, shift1;
+                (void)row_off(t, 2 * sp, shift0);
+                (void)row_off(t, 2 * sp + 1, shift1);
+                const int o0 = C::RAW_LEAD + (int)shift0 - 3 * lead, o1 = C::RAW_LEAD + (int)shift1 - 3 * lead;  // byte offset of pixel 0
+                const uint8_t* r0 = RAW + (size_t)(2 * sp) * C::RAWP;
+                const uint8_t* r1 = r0 + C::RAWP;
+#pragma unroll 2
+                for (int px = lane; px < aws; px += 64) {
+                    // the three codes of a pixel as byte reads (ds_read_u8 with immediate offsets 0/1/2 on one address): no
+                    // dword alignment, funnel shift or field extraction -- this wave is issue-bound, LDS instructions are cheap
+                    const uint8_t* b0 = r0 + o0 + 3 * px;
+                    const uint8_t* b1 = r1 + o1 + 3 * px;
+                    const uint32_t a0 = b0[0], a1 = b0[1], a2 = b0[2], e0 = b1[0], e1 = b1[1], e2 = b1[2];
+                    F2 c0, c1, c2;
+                    if (DARK) {
+                        c0 = F2{a0 ? 1.0f : 0.0f, e0 ? 1.0f : 0.0f};
+                        c1 = F2{a1 ? 1.0f : 0.0f, e1 ? 1.0f : 0.0f};
+                        c2 = F2{a2 ? 1.0f : 0.0f, e2 ? 1.0f : 0.0f};
+                    } else {
+                        c0 = F2{lut[a0], lut[e0]};
+                        c1 = F2{lut[a1], lut[e1]};
+                        c2 = F2{lut[a2], lut[e2]};
+                    }
+                    const F2 l = pfma(c2, F2{M[2], M[2]}, pfma(c1, F2{M[1], M[1]}, c0 * F2{M[0], M[0]}));
+                    const F2 m = pfma(c2, F2{M[5], M[5]}, pfma(c1, F2{M[4], M[4]}, c0 * F2{M[3], M[3]}));
+                    const F2 sv = pfma(c2, F2{M[8], M[8]}, pfma(c1, F2{M[7], M[7]}, c0 * F2{M[6], M[6]}));
+                    P* dst = A + (size_t)(sp * 3) * C::PA + (px & 1) * C::PAH + (px >> 1);
+                    if constexpr (COLOR == AVX_COLOR_MATRIX) {
+                        dst[0] = P{(T)l.x, (T)l.y};
+                        dst[C::PA] = P{(T)m.x, (T)m.y};
+                        dst[2 * C::PA] = P{(T)sv.x, (T)sv.y};
+                    } else {
+                        const F2 lm = F2{M[9], M[9]} * l + F2{M[10], M[10]} * m;  // mul, mul, add (cat.py:99)
+                        const D2 dlm = D2{(double)lm.x, (double)lm.y}, ds = D2{(double)sv.x, (double)sv.y};
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            const double k0 = cbk[3 * cc], k1 = cbk[3 * cc + 1], k2 = cbk[3 * cc + 2];
+                            const D2 r = pfma(ds, D2{k2, k2}, pfma(dlm, D2{k1, k1}, dlm * D2{k0, k0}));
+                            dst[cc * C::PA] = P{(T)r.x, (T)r.y};
+                        }
+                    }
+                }
+            }
+            if (border) {  // halo mirrors: the same wave wrote the sources (LDS serves a wave's accesses in order)
+                const int nl = lead, nr = (xs + vw + R) - gx1;
+                for (int item = lane; item < (SY / 2) * 3 * (nl + nr); item += 64) {
+                    const int e = item % (nl + nr), pl = item / (nl + nr);
+                    const int lx = e < nl ? e : (gx1 - (xs - R)) + (e - nl);
+                    const int src = reflect101(xs - R + lx, a.W) - (xs - R);
+                    A[(size_t)pl * C::PA + (lx & 1) * C::PAH + (lx >> 1)] = A[(size_t)pl * C::PA + (src & 1) * C::PAH + (src >> 1)];
+                }
+            }
+            return;
+        }
         // SPEC: items run over the strip's ACTUAL haloed width, row pairs interleaved (item = q4 * SY/2 + sp) -- how many 64-lane
         // passes the producer needs is then the host's choice of strip width alone (launch_march), not a compile-time constant
         constexpr bool kMix = SPEC && sizeof(T) == 4;  // (the float64 cat keeps row-pair-major items over its fixed 120-px strips:
@@ -390,7 +470,10 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
                 const P* src = A + ((size_t)(sp * 3 + c)) * C::PA + xg * XPT;
                 P w[XPT + 2 * R];  // {row 2sp, row 2sp+1} at columns xg*XPT + i
 #pragma unroll
-                for (int i = 0; i < XPT + 2 * R; ++i) w[i] = src[i];
+                for (int i = 0; i < XPT + 2 * R; ++i) {
+                    if constexpr (C::kSplit) w[i] = (A + ((size_t)(sp * 3 + c)) * C::PA + xg * (XPT / 2))[(i & 1) * C::PAH + (i >> 1)];
+                    else w[i] = src[i];
+                }
                 P acc[XPT];
 #pragma unroll
                 for (int x = 0; x < XPT; ++x) {
