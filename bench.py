@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive pipeline leg (profiling runs)")
+    ap.add_argument("--frames", choices=["auto", "noise", "structured"], default="auto",
+                    help="synthetic content: uniform noise (dichromat default: worst case for the decode-table lookups) or gradients + bars + noise")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
 
@@ -101,6 +103,8 @@ def main():
 
     # This rank's shard of the synthetic stream: global frame index i = rank + j*world (round-robin).
     gen = structured_frame if (bee or uvsp) else noise_frame  # percentile-driven stages need non-degenerate statistics
+    if args.frames != "auto":
+        gen = structured_frame if args.frames == "structured" else noise_frame
     pool = [gen(rank + j * world, H, W) for j in range(min(B, 4))]
     batch = np.stack([pool[j % len(pool)] for j in range(B)])
     d_in = ctx.upload(batch)
