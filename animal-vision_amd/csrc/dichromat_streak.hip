@@ -39,17 +39,28 @@ struct StreakArgs {
 //   * bucketed quantiser; bytes are staged in LDS and leave with 4-byte stores.
 constexpr int kPad = 16;  // halo samples per side (>= the largest radius, multiple of 4)
 
+// The planes are addressed in float4 units from the (16-byte aligned) start of the dynamic LDS block: with float pointers and
+// a run-time pitch the compiler could not prove the 16-byte alignment of a window and split every float4 load into
+// ds_read2_b32 / ds_read2_b64 -- at this 16-byte lane stride those are 4-way / 2-way bank conflicts (PMC: 85 % of the
+// kernel's conflict cycles, which were 54 % of its LDS cycles); ds_read_b128 at that stride is conflict-free.
 template <int RB>
-__device__ __forceinline__ void streak_along_row(const float* __restrict__ src, float* __restrict__ dst, int W, int PW, const float* __restrict__ td /*taps by distance, zero beyond r*/,
+__device__ __forceinline__ void streak_along_row(const float4* __restrict__ src4, float4* __restrict__ dst4, int W, int PW4, const float* __restrict__ td /*taps by distance, zero beyond r*/,
                                                 int tid) {
+    static_assert(RB % 4 == 0 && kPad % 4 == 0, "windows start on float4 boundaries");
     const int ngroups = (W + 3) / 4;
     for (int item = tid; item < 3 * ngroups; item += kST) {
         const int c = item / ngroups, xg = item - c * ngroups;
-        const float* base = src + (size_t)c * PW + kPad + 4 * xg - RB;  // 16-byte aligned: PW, kPad, RB multiples of 4
+        const float4* base = src4 + (c * PW4 + (kPad - RB) / 4 + xg);
         float w[4 + 2 * RB];
 #pragma unroll
         for (int q = 0; q < (4 + 2 * RB) / 4; ++q) {
-            const float4 v = reinterpret_cast<const float4*>(base)[q];
+            float4 v = base[q];
+            // The packed FMAs below pair neighbouring samples, and every other pairing starts on an odd register: left to itself
+            // the compiler fetches a second, one-sample-shifted copy of the window from LDS with ds_read2_b32 / ds_read2_b64,
+            // which at this 16-byte lane stride are 4-way / 2-way bank conflicts (PMC with phases ablated: the two along-row
+            // passes held 85 % of the kernel's conflict cycles, themselves 54 % of its LDS cycles).  Passing the loaded values
+            // through an empty asm makes them opaque: one conflict-free ds_read_b128 per float4, pairs formed in registers.
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
         float o[4];
@@ -60,7 +71,7 @@ __device__ __forceinline__ void streak_along_row(const float* __restrict__ src, 
             for (int j = 1; j <= RB; ++j) sacc = fma_t(w[RB + x + j] + w[RB + x - j], td[j], sacc);
             o[x] = sacc;
         }
-        *reinterpret_cast<float4*>(dst + (size_t)c * PW + kPad + 4 * xg) = make_float4(o[0], o[1], o[2], o[3]);
+        dst4[c * PW4 + kPad / 4 + xg] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -118,6 +129,9 @@ __global__ __launch_bounds__(kST, 3) void dichromat_streak_kernel(DichromatArgs 
     const int PW = ((W + 3) / 4 * 4) + 2 * kPad;     // plane pitch (multiple of 4)
     float* buf0 = smem_f;                            // 3 planes
     float* buf1 = smem_f + (size_t)3 * PW;           // 3 planes
+    const int PW4 = PW / 4;
+    float4* const buf0_4 = reinterpret_cast<float4*>(smem_f);  // the same planes in float4 units (alignment visible to the compiler)
+    float4* const buf1_4 = buf0_4 + 3 * PW4;
     // The row's bytes (staged input at the top of a row, quantised output at its end) live in buf0's storage: buf0 is written by
     // the first along-row pass only after the staged input has been decoded, and is dead again once the second pass has read
     // it.  Without a byte buffer of its own a workgroup needs 51 KB instead of 57 KB of LDS: three fit a CU instead of two,
@@ -188,6 +202,7 @@ __global__ __launch_bounds__(kST, 3) void dichromat_streak_kernel(DichromatArgs 
             }
         };
         __syncthreads();  // this row's taps (t1 / td1 / td2) and, with PREF, its staged bytes are in place
+        if (!(a.ablate & 1))
         switch (r1) {  // uniform per row
             case 0: streak_across<0>(load_px, buf1, W, PW, t1, tid); break;
             case 1: streak_across<1>(load_px, buf1, W, PW, t1, tid); break;
@@ -206,16 +221,18 @@ __global__ __launch_bounds__(kST, 3) void dichromat_streak_kernel(DichromatArgs 
         streak_fill_halo(buf1, W, PW, rb1, tid);
         __syncthreads();
         // ---- pass 1, "column" direction = along the image row (sigma_x) -> buf0 ----------------------------
-        if (r1 <= 4) streak_along_row<4>(buf1, buf0, W, PW, td1, tid);
-        else streak_along_row<8>(buf1, buf0, W, PW, td1, tid);
+        if (a.ablate & 2) {}
+        else if (r1 <= 4) streak_along_row<4>(buf1_4, buf0_4, W, PW4, td1, tid);
+        else streak_along_row<8>(buf1_4, buf0_4, W, PW4, td1, tid);
         __syncthreads();
         streak_fill_halo(buf0, W, PW, rb2, tid);
         __syncthreads();
         // ---- pass 2: 1-tap row direction is x*1.0 (exact); along the image row again (sigma_y) -> buf1 ----
-        if (r2 <= 4) streak_along_row<4>(buf0, buf1, W, PW, td2, tid);
-        else if (r2 <= 8) streak_along_row<8>(buf0, buf1, W, PW, td2, tid);
-        else if (r2 <= 12) streak_along_row<12>(buf0, buf1, W, PW, td2, tid);
-        else streak_along_row<16>(buf0, buf1, W, PW, td2, tid);
+        if (a.ablate & 4) {}
+        else if (r2 <= 4) streak_along_row<4>(buf0_4, buf1_4, W, PW4, td2, tid);
+        else if (r2 <= 8) streak_along_row<8>(buf0_4, buf1_4, W, PW4, td2, tid);
+        else if (r2 <= 12) streak_along_row<12>(buf0_4, buf1_4, W, PW4, td2, tid);
+        else streak_along_row<16>(buf0_4, buf1_4, W, PW4, td2, tid);
         __syncthreads();
         if constexpr (PLANES) {
             const size_t plane = (size_t)a.H * W;
@@ -226,7 +243,7 @@ __global__ __launch_bounds__(kST, 3) void dichromat_streak_kernel(DichromatArgs 
             continue;
         }
         // ---- chroma compression (rabbit, panda), quantise -> staged bytes -----------------------------------
-        for (int x = tid; x < W; x += kST) {
+        for (int x = (a.ablate & 8) ? W : tid; x < W; x += kST) {
             float v[3] = {buf1[kPad + x], buf1[PW + kPad + x], buf1[2 * PW + kPad + x]};
             if (a.chroma_enable) {  // apply_chroma_compression, animal_utils.py:180-181
                 const float gray = ((v[0] + v[1]) + v[2]) / 3.0f;
