@@ -344,7 +344,13 @@ __global__ __launch_bounds__(kT) void k_plane_blur_t(BlurArgs a) {
             const float4* wp = reinterpret_cast<const float4*>(A + ly * AWP + 4 * g);
             float w[(4 + 2 * R + 3) & ~3];
 #pragma unroll
-            for (int q = 0; q < (4 + 2 * R + 3) / 4; ++q) { const float4 v = wp[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+            for (int q = 0; q < (4 + 2 * R + 3) / 4; ++q) {
+                float4 v = wp[q];
+                // opaque to the compiler: otherwise it re-reads one-sample-shifted copies of the window with ds_read2_b32 / _b64 to
+                // feed odd-aligned packed FMAs -- 4-way / 2-way bank conflicts at this 16-byte lane stride (see dichromat_streak.hip)
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
             float o[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
