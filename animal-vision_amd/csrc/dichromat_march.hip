@@ -57,7 +57,10 @@ struct MarchCfg {
     static constexpr int NG4S = kCapStrips ? 64 / (SY / 2) : NG4;
     static constexpr int SW_CAP = kCapStrips ? (NG4S * 4 - 2 * R < SW ? NG4S * 4 - 2 * R : SW) : SW;
     static constexpr int PA0 = SW - XPT + NWV * XPT;
-    static constexpr int PA = ((PA0 > NG4 * 4 ? PA0 : NG4 * 4) + 3) / 4 * 4;
+    // float32 SPEC: the decode's lanes alternate between the two row pairs (planes 3 PA entries apart) and each writes 32
+    // bytes; with PA = 2 mod 4 the four lanes of one row pair and the four of the other in a ds_write_b128 group land on
+    // interleaved 16-byte slots of the 128-byte write row instead of the same ones (2-way conflict otherwise).
+    static constexpr int PA = ((PA0 > NG4 * 4 ? PA0 : NG4 * 4) + 3) / 4 * 4 + ((SPEC && sizeof(T) == 4) ? 2 : 0);
     // kSplit (the float64 cat): a decoded plane row is stored as its even pixels followed by its odd pixels (PAH entries each).
     // A thread of the row pass reads pixels 2 xg + i: with 16-byte entries in pixel order the lane stride is 32 bytes and every
     // ds_read_b128 group hits each 16-byte slot twice; split by parity the stride is 16 bytes and the reads are conflict-free.
