@@ -289,9 +289,16 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kmain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)kdark, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long rows = (long)a.n_frames * a.H;
-    const long cap = (long)ctx->num_cus * 4;
+    // Persistent workgroups, exactly one resident set: the grid is CUs x (workgroups that fit a CU).  With a fixed 4 per CU and
+    // only 3 fitting (LDS), a quarter of the workgroups started when the first ones had finished -- their 34 rows each ran as a
+    // second round at a third of the machine's width (sheep 1080p: 83 or 102 GP/s from one run to the next, depending on how
+    // the dispatcher interleaved them; 45 rows each in one round is the same work without the tail).
+    int per_cu = 0;
+    AVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kmain, kST, lds));
+    if (per_cu < 1) per_cu = 1;
+    const long cap = (long)ctx->num_cus * per_cu;
     const int grid = (int)(rows < cap ? rows : cap);
-    if (getenv("AVX_TUNE_LOG")) { int pc = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, (const void*)kmain, kST, lds); fprintf(stderr, "[avx streak] lds=%zu occupancy=%d workgroups/CU grid=%d\n", lds, pc, grid); }
+    if (getenv("AVX_TUNE_LOG")) fprintf(stderr, "[avx streak] lds=%zu occupancy=%d workgroups/CU grid=%d\n", lds, per_cu, grid);
     AVX_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * a.n_frames, s));
     hipLaunchKernelGGL(kmain, dim3(grid), dim3(kST), lds, s, a, st, qc);
     AVX_HIP(ctx, hipGetLastError());
@@ -326,7 +333,9 @@ extern "C" int avx_streak_planes_f32(avx_ctx* ctx, const float* src_planes, floa
     QuantCoarse qc{};
     auto k = dichromat_streak_kernel<false, true>;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long cap = (long)ctx->num_cus * 4;
+    int per_cu = 0;  // one resident set of persistent workgroups (see avx_launch_dichromat_streak)
+    AVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, kST, lds));
+    const long cap = (long)ctx->num_cus * (per_cu < 1 ? 1 : per_cu);
     hipLaunchKernelGGL(k, dim3((unsigned)(H < cap ? H : cap)), dim3(kST), lds, s, a, st, qc);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
