@@ -1,6 +1,7 @@
 // csrc/avx_core.hip -- context, device memory, streams, HIP-event stopwatch of libavx.so.
 // Nothing here exists in the reference (pure Python, no device runtime: SURVEY.md 2.1); it is the
 // plumbing under the C ABI of include/avx.h.
+#include <cstdlib>
 #include "avx_internal.h"
 #include "dichromat_common.h"
 #include "srgb_tables.h"
@@ -32,6 +33,7 @@ avx_ws* avx_workspace(avx_ctx* ctx, hipStream_t stream) {
 static void avx_ws_release(avx_ws* w) {
     if (w->d_flags) (void)hipFree(w->d_flags);
     if (w->d_row_gain) (void)hipFree(w->d_row_gain);
+    if (w->h_row_tab) free(w->h_row_tab);
     if (w->uv_small) (void)hipFree(w->uv_small);
     if (w->d_scratch) (void)hipFree(w->d_scratch);
     if (w->d_geom) (void)hipFree(w->d_geom);
@@ -39,6 +41,31 @@ static void avx_ws_release(avx_ws* w) {
     for (int i = 0; i < w->n_geom_tabs; ++i)
         if (((w->geom_tabs[i].key >> 54) & 0xf) < 8) (void)hipFree(w->geom_tabs[i].dev);  // component >= 8: a scalar, not a pointer
     *w = avx_ws();
+}
+
+// A species' per-row table is the same for every batch of a video, and a pageable host-to-device copy in front of every launch
+// is a staging copy plus a DMA the kernel has to wait for (streak species, 207 KB per launch at 1080p): the workspace remembers
+// the bytes it uploaded last and skips the copy when they have not changed.
+int avx_upload_row_table(avx_ctx* ctx, avx_ws* ws, const void* host, size_t bytes, hipStream_t s) {
+    if (bytes > ws->row_gain_cap * sizeof(float)) {
+        if (ws->d_row_gain) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_row_gain)); }
+        ws->d_row_gain = nullptr;
+        ws->row_gain_cap = 0;
+        ws->h_row_tab_bytes = 0;
+        AVX_HIP(ctx, hipMalloc((void**)&ws->d_row_gain, bytes));
+        ws->row_gain_cap = bytes / sizeof(float);
+    }
+    if (ws->h_row_tab && ws->h_row_tab_bytes == bytes && memcmp(ws->h_row_tab, host, bytes) == 0) return AVX_OK;
+    if (bytes > ws->h_row_tab_cap) {
+        void* p = realloc(ws->h_row_tab, bytes);
+        if (!p) return avx_fail(ctx, AVX_ERR_NOMEM, "row table mirror: out of host memory");
+        ws->h_row_tab = p;
+        ws->h_row_tab_cap = bytes;
+    }
+    memcpy(ws->h_row_tab, host, bytes);
+    ws->h_row_tab_bytes = bytes;
+    AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, ws->h_row_tab, bytes, hipMemcpyHostToDevice, s));
+    return AVX_OK;
 }
 
 int avx_lanes(avx_ctx* ctx, int want) {

@@ -16,6 +16,8 @@ struct avx_ws {
     size_t flags_cap = 0;
     float* d_row_gain = nullptr;     // per-row gains (AVX_POST_ROWGAIN)
     size_t row_gain_cap = 0;
+    void* h_row_tab = nullptr;       // host mirror of what d_row_gain holds: an unchanged table is not uploaded again
+    size_t h_row_tab_bytes = 0, h_row_tab_cap = 0;
     void* uv_small = nullptr;        // UV path: partial statistics, histogram, select state, percentiles
     void* d_scratch = nullptr;       // scratch arena (UV path planes)
     size_t scratch_cap = 0;
@@ -68,6 +70,8 @@ int avx_fail(avx_ctx* ctx, int code, const char* fmt, ...);
 void avx_march_seed_tuned(avx_ctx* ctx);  // dichromat_march.hip: measured launch geometries of the standard workloads
 avx_ws* avx_workspace(avx_ctx* ctx, hipStream_t stream);  // find or create; NULL when all slots are taken
 int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes);
+// Per-row table (row gains / streak taps) -> ws->d_row_gain: grows the buffer, uploads only when the bytes differ from the last upload.
+int avx_upload_row_table(avx_ctx* ctx, avx_ws* ws, const void* host, size_t bytes, hipStream_t s);
 int avx_lanes(avx_ctx* ctx, int want);  // creates the frame-lane streams on first use; returns how many exist (<= want), 0 on failure
 
 #define AVX_HIP(ctx, call)                                                                          \

@@ -608,14 +608,7 @@ extern "C" int avx_dichromat_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* ou
     }
     if (d->post_mode == AVX_POST_ROWGAIN) {
         AVX_REQUIRE(ctx, d->row_gain_host != nullptr, "avx_dichromat_u8: row_gain_host is NULL");
-        if ((size_t)H > ws->row_gain_cap) {
-            if (ws->d_row_gain) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_row_gain)); }
-            ws->d_row_gain = nullptr;
-            ws->row_gain_cap = 0;
-            AVX_HIP(ctx, hipMalloc((void**)&ws->d_row_gain, sizeof(float) * H));
-            ws->row_gain_cap = H;
-        }
-        AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, d->row_gain_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
+        { const int rcu = avx_upload_row_table(ctx, ws, d->row_gain_host, sizeof(float) * (size_t)H, s); if (rcu) return rcu; }
         a.row_gain = ws->d_row_gain;
         a.row_gain_clamp = d->row_gain_clamp;
     }

@@ -273,14 +273,7 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
     QuantCoarse qc{ctx->d_coarse_f32, ctx->coarse_lo_key[0], ctx->coarse_n_keys[0], ctx->coarse_n_fix[0]};
     AVX_REQUIRE(ctx, lds <= 150 * 1024, "avx_dichromat_u8: frame width %d too large for the streak kernel (row must fit LDS)", a.W);
     const size_t tbytes = sizeof(float) * (size_t)a.H * d->streak_stride;
-    if (tbytes > ws->row_gain_cap * sizeof(float)) {  // the per-row table shares the row-gain buffer
-        if (ws->d_row_gain) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_row_gain)); }
-        ws->d_row_gain = nullptr;
-        ws->row_gain_cap = 0;
-        AVX_HIP(ctx, hipMalloc((void**)&ws->d_row_gain, tbytes));
-        ws->row_gain_cap = tbytes / sizeof(float);
-    }
-    AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, d->streak_rows_host, tbytes, hipMemcpyHostToDevice, s));
+    { const int rcu = avx_upload_row_table(ctx, ws, d->streak_rows_host, tbytes, s); if (rcu) return rcu; }
     StreakArgs st{ws->d_row_gain, d->streak_stride, nullptr, nullptr};
     const bool aligned = ((((size_t)a.H * a.W * 3 * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) == 0;
     const bool pref6 = aligned && a.W * 3 + 8 <= 6 * kST * 4, pref12 = aligned && a.W * 3 + 8 <= 12 * kST * 4;
@@ -319,14 +312,7 @@ extern "C" int avx_streak_planes_f32(avx_ctx* ctx, const float* src_planes, floa
     const size_t lds = sizeof(float) * (size_t)PW * 6;
     AVX_REQUIRE(ctx, lds <= 150 * 1024, "avx_streak_planes_f32: frame width %d too large (a row must fit LDS)", W);
     const size_t tbytes = sizeof(float) * (size_t)H * stride;
-    if (tbytes > ws->row_gain_cap * sizeof(float)) {
-        if (ws->d_row_gain) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_row_gain)); }
-        ws->d_row_gain = nullptr;
-        ws->row_gain_cap = 0;
-        AVX_HIP(ctx, hipMalloc((void**)&ws->d_row_gain, tbytes));
-        ws->row_gain_cap = tbytes / sizeof(float);
-    }
-    AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, rows_host, tbytes, hipMemcpyHostToDevice, s));
+    { const int rcu = avx_upload_row_table(ctx, ws, rows_host, tbytes, s); if (rcu) return rcu; }
     DichromatArgs a{};
     a.H = H; a.W = W; a.n_frames = 1;
     StreakArgs st{ws->d_row_gain, stride, src_planes, dst_planes};
