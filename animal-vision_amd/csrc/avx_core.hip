@@ -34,6 +34,7 @@ static void avx_ws_release(avx_ws* w) {
     if (w->d_flags) (void)hipFree(w->d_flags);
     if (w->d_row_gain) (void)hipFree(w->d_row_gain);
     if (w->h_row_tab) free(w->h_row_tab);
+    for (auto& c : w->consts) { if (c.dev) (void)hipFree(c.dev); if (c.host) free(c.host); }
     if (w->uv_small) (void)hipFree(w->uv_small);
     if (w->d_scratch) (void)hipFree(w->d_scratch);
     if (w->d_geom) (void)hipFree(w->d_geom);
@@ -65,6 +66,32 @@ int avx_upload_row_table(avx_ctx* ctx, avx_ws* ws, const void* host, size_t byte
     memcpy(ws->h_row_tab, host, bytes);
     ws->h_row_tab_bytes = bytes;
     AVX_HIP(ctx, hipMemcpyAsync(ws->d_row_gain, ws->h_row_tab, bytes, hipMemcpyHostToDevice, s));
+    return AVX_OK;
+}
+
+// Same idea for the small constant tables that used to be copied from pageable host memory in front of every frame (six per
+// mantis frame): each slot owns its device buffer, so nothing else can overwrite what the mirror says is there.
+int avx_const_upload(avx_ctx* ctx, avx_ws* ws, int slot, const void* host, size_t bytes, hipStream_t s, void** dev_out) {
+    AVX_REQUIRE(ctx, slot >= 0 && slot < 8 && host && bytes > 0, "avx_const_upload: bad arguments");
+    avx_ws::const_slot& c = ws->consts[slot];
+    if (bytes > c.cap) {
+        if (c.dev) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(c.dev)); }
+        c.dev = nullptr;
+        c.cap = 0;
+        c.bytes = 0;
+        const size_t cap = (bytes + 255) & ~(size_t)255;
+        void* h = realloc(c.host, cap);
+        if (!h) return avx_fail(ctx, AVX_ERR_NOMEM, "constant table mirror: out of host memory");
+        c.host = h;
+        AVX_HIP(ctx, hipMalloc(&c.dev, cap));
+        c.cap = cap;
+    }
+    if (c.bytes != bytes || memcmp(c.host, host, bytes) != 0) {
+        memcpy(c.host, host, bytes);
+        c.bytes = bytes;
+        AVX_HIP(ctx, hipMemcpyAsync(c.dev, c.host, bytes, hipMemcpyHostToDevice, s));
+    }
+    *dev_out = c.dev;
     return AVX_OK;
 }
 

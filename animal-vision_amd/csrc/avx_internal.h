@@ -18,6 +18,10 @@ struct avx_ws {
     size_t row_gain_cap = 0;
     void* h_row_tab = nullptr;       // host mirror of what d_row_gain holds: an unchanged table is not uploaded again
     size_t h_row_tab_bytes = 0, h_row_tab_cap = 0;
+    // Small constant tables of a caller's pipeline (matrices, weights, coordinate rows): device copy + host mirror per slot,
+    // uploaded only when the bytes change (avx_const_upload).  Slots: 0 UV matrix / weights, 2-7 mantis tables.
+    struct const_slot { void* dev = nullptr; void* host = nullptr; size_t bytes = 0, cap = 0; };
+    const_slot consts[8];
     void* uv_small = nullptr;        // UV path: partial statistics, histogram, select state, percentiles
     void* d_scratch = nullptr;       // scratch arena (UV path planes)
     size_t scratch_cap = 0;
@@ -72,6 +76,7 @@ avx_ws* avx_workspace(avx_ctx* ctx, hipStream_t stream);  // find or create; NUL
 int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes);
 // Per-row table (row gains / streak taps) -> ws->d_row_gain: grows the buffer, uploads only when the bytes differ from the last upload.
 int avx_upload_row_table(avx_ctx* ctx, avx_ws* ws, const void* host, size_t bytes, hipStream_t s);
+int avx_const_upload(avx_ctx* ctx, avx_ws* ws, int slot, const void* host, size_t bytes, hipStream_t s, void** dev_out);
 int avx_lanes(avx_ctx* ctx, int want);  // creates the frame-lane streams on first use; returns how many exist (<= want), 0 on failure
 
 #define AVX_HIP(ctx, call)                                                                          \

@@ -388,13 +388,16 @@ extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_b
     float2* mm = (float2*)(base + o_mm);
     double* pct = (double*)(base + o_pct);
     const int B = d->n_wavelengths;
-    float* dM = tab; float* drows = tab + K * 3; float* dxx = drows + H; float* dyy = dxx + W; float* dgains = dyy + H; float* dwts = dgains + 3 * B;
-    AVX_HIP(ctx, hipMemcpyAsync(dgains, d->lobe_gains_host, sizeof(float) * B * 3, hipMemcpyHostToDevice, s));
-    AVX_HIP(ctx, hipMemcpyAsync(dwts, d->band_weights_host, sizeof(float) * B * K, hipMemcpyHostToDevice, s));
-    AVX_HIP(ctx, hipMemcpyAsync(dM, d->band_matrix_host, sizeof(float) * K * 3, hipMemcpyHostToDevice, s));
-    AVX_HIP(ctx, hipMemcpyAsync(drows, d->rows_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
-    AVX_HIP(ctx, hipMemcpyAsync(dxx, d->xx_host, sizeof(float) * W, hipMemcpyHostToDevice, s));
-    AVX_HIP(ctx, hipMemcpyAsync(dyy, d->yy_host, sizeof(float) * H, hipMemcpyHostToDevice, s));
+    // constant tables of the species: cached per workspace, uploaded only when their bytes change (was six pageable copies in
+    // front of every frame)
+    float *dM, *drows, *dxx, *dyy, *dgains, *dwts;
+    (void)tab;
+    if ((rc = avx_const_upload(ctx, ws, 2, d->lobe_gains_host, sizeof(float) * B * 3, s, (void**)&dgains))) return rc;
+    if ((rc = avx_const_upload(ctx, ws, 3, d->band_weights_host, sizeof(float) * B * K, s, (void**)&dwts))) return rc;
+    if ((rc = avx_const_upload(ctx, ws, 4, d->band_matrix_host, sizeof(float) * K * 3, s, (void**)&dM))) return rc;
+    if ((rc = avx_const_upload(ctx, ws, 5, d->rows_host, sizeof(float) * H, s, (void**)&drows))) return rc;
+    if ((rc = avx_const_upload(ctx, ws, 6, d->xx_host, sizeof(float) * W, s, (void**)&dxx))) return rc;
+    if ((rc = avx_const_upload(ctx, ws, 7, d->yy_host, sizeof(float) * H, s, (void**)&dyy))) return rc;
     const int g = grid_for(ctx, n);
     // 1) to_float01 + srgb_to_linear (:148-149); float frames arrive already linearised (lin_hwc_in, built by the caller's
     //    plane program: to_float01's max rule needs a frame-wide reduction)

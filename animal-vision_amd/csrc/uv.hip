@@ -899,8 +899,9 @@ int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype,
         if (KP == 4) AVX_SPEC(4) else if (KP == 8) AVX_SPEC(8) else if (KP == 12) AVX_SPEC(12) else AVX_SPEC(16)
 #undef AVX_SPEC
     } else {
-        AVX_HIP(ctx, hipMemcpyAsync(u.mat, weights_host, sizeof(float) * K * B, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_spectral_integrate<16>, dim3(g), dim3(kT), sizeof(float) * K * B, s, hsi, layout, dtype, n, B, u.mat, K, out_planes, u.partials);
+        float* dmat = nullptr;  // cached: uploaded only when the weights change
+        { avx_ws* wsc = avx_workspace(ctx, s); if (!wsc) return AVX_ERR_NOMEM; const int rcu = avx_const_upload(ctx, wsc, 0, weights_host, sizeof(float) * K * B, s, (void**)&dmat); if (rcu) return rcu; }
+        hipLaunchKernelGGL(k_spectral_integrate<16>, dim3(g), dim3(kT), sizeof(float) * K * B, s, hsi, layout, dtype, n, B, dmat, K, out_planes, u.partials);
     }
     hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(1024), 0, s, u.partials, g, K, n, 0, 0.0f, u.stats);
     AVX_HIP(ctx, hipGetLastError());
@@ -958,10 +959,11 @@ int avx_rgb_to_hsi_lobes(avx_ctx* ctx, const void* in_hwc, int in_is_u8, int H, 
     UvScratch u;
     int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
-    AVX_HIP(ctx, hipMemcpyAsync(u.mat, gains_host, sizeof(float) * 3 * B, hipMemcpyHostToDevice, s));
+    float* dmat = nullptr;  // cached: uploaded only when the gains change
+    { avx_ws* wsc = avx_workspace(ctx, s); if (!wsc) return AVX_ERR_NOMEM; const int rcu = avx_const_upload(ctx, wsc, 0, gains_host, sizeof(float) * 3 * B, s, (void**)&dmat); if (rcu) return rcu; }
     const size_t n = (size_t)H * W;
     hipLaunchKernelGGL(k_lobes_cube, dim3(grid_for(ctx, n)), dim3(kT), sizeof(float) * 3 * B, s, in_hwc, in_is_u8, ctx->d_decode_lut, n, B,
-                       u.mat, denom, out_hwb);
+                       dmat, denom, out_hwb);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
@@ -1001,8 +1003,10 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
         rc = avx_ensure_scratch(ctx, ws, sizeof(float) * n * 9 + 256);
         if (rc) return rc;
         lane_raw[l] = (float*)ws->d_scratch;
-        if (d->source == 0) AVX_HIP(ctx, hipMemcpyAsync(lane_u[l].mat, d->rgb_matrix, sizeof(float) * 9, hipMemcpyHostToDevice, lane_s[l]));
-        else AVX_HIP(ctx, hipMemcpyAsync(lane_u[l].mat, d->weights_host, sizeof(float) * 3 * d->bands, hipMemcpyHostToDevice, lane_s[l]));
+        // the colour matrix / band weights: cached per lane workspace, uploaded only when they change
+        rc = d->source == 0 ? avx_const_upload(ctx, ws, 0, d->rgb_matrix, sizeof(float) * 9, lane_s[l], (void**)&lane_u[l].mat)
+                            : avx_const_upload(ctx, ws, 0, d->weights_host, sizeof(float) * 3 * d->bands, lane_s[l], (void**)&lane_u[l].mat);
+        if (rc) return rc;
     }
     int rc = AVX_OK;
     for (int f = 0; f < n_frames; ++f) {
