@@ -769,9 +769,9 @@ void avx_march_seed_tuned(avx_ctx* ctx) {
         {0, 14, 8, 2160, 3840, 64, 6},    // dog 4K
         {0, 6, 32, 1080, 1920, 64, 8 | kNarrowStrips},  // wolf 1080p (112-px strips: 191 -> 199 GP/s)
         {0, 5, 32, 1080, 1920, 64, 8},    // lion / tiger 1080p
-        {0, 3, 32, 1080, 1920, 64, 6},    // squirrel 1080p
-        {1, 4, 32, 1080, 1920, 64, 8},    // cat 1080p (default bench; wave-specialised form)
-        {1, 4, 8, 2160, 3840, 64, 16},    // cat 4K
+        {0, 3, 32, 1080, 1920, 64, 3},    // squirrel 1080p (3: 264.6 GP/s, 6: 254.1)
+        {1, 4, 32, 1080, 1920, 64, 3},    // cat 1080p (default bench): sweep 3 / 4 / 6 / 8 / 12 / 16 -> 161.6 / 153.7 / 156.2 / 152.2 / 148.8 / 142.2 GP/s
+        {1, 4, 8, 2160, 3840, 64, 3},     // cat 4K: 163.4 / 131.9 / 161.1 / 154.3 / 155.8 / 151.7
     };
     if (getenv("AVX_MARCH_NOSEED")) return;  // measure everything on first use (re-deriving the table below)
     for (const auto& e : kSeed) {
