@@ -275,6 +275,7 @@ int avx_launch_dichromat_streak(avx_ctx* ctx, avx_ws* ws, DichromatArgs& a, cons
     const size_t tbytes = sizeof(float) * (size_t)a.H * d->streak_stride;
     { const int rcu = avx_upload_row_table(ctx, ws, d->streak_rows_host, tbytes, s); if (rcu) return rcu; }
     StreakArgs st{ws->d_row_gain, d->streak_stride, nullptr, nullptr};
+    if (!getenv("AVX_DIAG")) a.ablate = 0;  // phase ablation (wrong outputs, counters only) needs AVX_DIAG=1 next to AVX_ABLATE
     const bool aligned = ((((size_t)a.H * a.W * 3 * (size_t)a.n_frames) | (size_t)(uintptr_t)a.in) & 3u) == 0;
     const bool pref6 = aligned && a.W * 3 + 8 <= 6 * kST * 4, pref12 = aligned && a.W * 3 + 8 <= 12 * kST * 4;
     auto kmain = pref6 ? dichromat_streak_kernel<false, false, true, 6> : (pref12 ? dichromat_streak_kernel<false, false, true, 12> : dichromat_streak_kernel<false>);
