@@ -241,6 +241,7 @@ _SIGS = {
     "avx_resize_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "avx_binocular_warp_u8": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "avx_split_compose_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "avx_draw_label_u8": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _fp, _i, ctypes.c_float, ctypes.c_float, _i, _vp]),
     "avx_remap_linear_planes": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, ctypes.c_float, _vp]),
     "avx_sobel3_plane": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "avx_mst_gram": (_i, [_vp, _vp, _i, _sz, _i, _i, _vp, _vp, _vp, _vp]),

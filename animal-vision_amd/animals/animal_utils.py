@@ -1,12 +1,23 @@
-"""Host-side mirror of the reference's animals/animal_utils.py for the names species modules use.
+"""The reference's animals/animal_utils.py by name, NumPy in / NumPy out, with everything O(pixels) on the device.
 
-Per-pixel work lives in the fused device kernel (dichromat.DichromatOp); what remains here is the
-O(1) host logic with the reference's names and argument meaning."""
+The fused path (dichromat.DichromatOp: one launch per batch, uint8 in -> uint8 out) is what `Animal.visualize` runs; this
+module is the STEP-WISE surface of the reference -- the functions a species module written against the reference imports
+(`from animals.animal_utils import ...`, dog.py:3-12) -- so such a module runs unchanged on top of libavx: each call
+uploads its operands, runs the matching device kernels (csrc/ew.hip plane programs, the Gaussian / streak stage kernels)
+and downloads the result.  Same names, argument meaning, dtypes, error behaviour and in-place side effects as the reference
+(quirk Q4: the streak blur and the S-cone gain mutate a float32 argument).  Arithmetic: float32 on the device with the
+shared Gaussian contract, so the blurs are bit-identical to the oracle and the transfer functions differ from NumPy's by
+the device's powf (<= 2 ulp); float64 inputs are computed in float32 and cast back (documented deviation, <= 1e-6).
+There is no CPU path: without a GPU these raise (AvxError)."""
 from __future__ import annotations
 
 import numpy as np
 
-from ..dichromat import collapse_LMS_matrix, cv_auto_ksize, gaussian_taps, s_cone_row_gain  # noqa: F401
+from ..dichromat import M_LMS_TO_RGB as _M_LMS_TO_RGB  # animal_utils.py:70-76 (no dtype: float64)
+from ..dichromat import M_RGB_TO_LMS as _M_RGB_TO_LMS  # animal_utils.py:56-63 (float32)
+from ..dichromat import collapse_LMS_matrix, cv_auto_ksize, gaussian_taps, s_cone_row_gain  # noqa: F401  (host, O(1))
+
+_A = 0.055
 
 
 def check_input_image(image: np.ndarray) -> bool:
@@ -18,12 +29,155 @@ def check_input_image(image: np.ndarray) -> bool:
     return bool(np.issubdtype(image.dtype, np.number))
 
 
-def apply_acuity_blur(image: np.ndarray, sigma: float = 1.5) -> np.ndarray:
-    """animals/animal_utils.py:121-145 on the device: OpenCV GaussianBlur(img,(0,0),sigma) semantics
-    for a float32 HxWx3 image (csrc/blur.hip)."""
-    from ..ops import gaussian_blur_f32
+def _as_rows(x: np.ndarray):
+    """Any array -> (2-D float32 view for the device, restore(result) -> array of x's shape)."""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    shape = a.shape
+    flat = a.reshape(1, -1) if a.ndim < 2 else a.reshape(shape[0], -1)
+    return flat, lambda r: r.reshape(shape)
 
+
+def _elementwise(x: np.ndarray, fn) -> np.ndarray:
+    from ..planevm import run_planes
+
+    x = np.asarray(x)
+    if x.size == 0:
+        return x.astype(np.result_type(x.dtype, np.float32), copy=True)
+    flat, restore = _as_rows(x)
+    out = restore(run_planes([flat], lambda be, v: [fn(be, v[0])])[0])
+    return out.astype(x.dtype, copy=False) if np.issubdtype(x.dtype, np.floating) else out.astype(np.float64)
+
+
+def srgb_to_linear(x: np.ndarray) -> np.ndarray:
+    """animals/animal_utils.py:5-11."""
+    return _elementwise(x, lambda be, v: be.where(v <= 0.04045, v / 12.92, ((v + _A) / (1 + _A)) ** 2.4))
+
+
+def linear_to_srgb(x: np.ndarray) -> np.ndarray:
+    """animals/animal_utils.py:13-19."""
+    return _elementwise(x, lambda be, v: be.where(v <= 0.0031308, 12.92 * v, (1 + _A) * be.power(v, 1 / 2.4) - _A))
+
+
+def get_normalized_image(image: np.ndarray) -> np.ndarray:
+    """animals/animal_utils.py:41-50: astype(float32); `/ 255` only if the frame's maximum exceeds 1 (a frame-wide
+    reduction, on the device); clip to [0, 1].  Always float32."""
+    from ..planevm import run_planes
+
+    flat, restore = _as_rows(image)
+
+    def build(be, v):
+        mx = be.max(v[0])
+        return [be.clip01(be.where(mx > 1.0, v[0] / 255.0, v[0]))]
+
+    return restore(run_planes([flat], build)[0])
+
+
+def _matmul3(vec: np.ndarray, M: np.ndarray, out_dtype) -> np.ndarray:
+    """vec (..., 3) @ M.T as the FMA chain of the reference's BLAS call: out_i = fma(c2, M[i][2], fma(c1, M[i][1], c0 * M[i][0]))."""
+    from ..planevm import run_planes
+
+    v = np.ascontiguousarray(vec, dtype=np.float32)
+    if v.shape[-1] != 3:
+        raise ValueError("expected (..., 3) vectors")
+    planes = [np.ascontiguousarray(v[..., c].reshape(1, -1)) for c in range(3)]
+    Mf = np.asarray(M, np.float32)
+
+    def build(be, ch):
+        return [ch[0] * float(Mf[i, 0]) + ch[1] * float(Mf[i, 1]) + ch[2] * float(Mf[i, 2]) for i in range(3)]
+
+    out = np.stack([p.reshape(v.shape[:-1]) for p in run_planes(planes, build)], axis=-1)
+    return out.astype(out_dtype, copy=False)
+
+
+def sRGB_to_LMS(image_in_sRGB: np.ndarray) -> np.ndarray:
+    """animals/animal_utils.py:52-64: `x @ M.T` with the float32 RGB->LMS matrix."""
+    return _matmul3(image_in_sRGB, _M_RGB_TO_LMS, np.result_type(np.asarray(image_in_sRGB).dtype, np.float32))
+
+
+def LMS_to_RGB(image_in_LMS: np.ndarray) -> np.ndarray:
+    """animals/animal_utils.py:66-77: `x @ M.T` with the dtype-less (float64) LMS->RGB literal: float64 out, like the
+    reference; the products are formed in float32 on the device (<= 1e-6 relative to the reference's float64)."""
+    return _matmul3(image_in_LMS, _M_LMS_TO_RGB, np.float64)
+
+
+def merge_L_M(image_in_LMS: np.ndarray, alpha: float) -> np.ndarray:
+    """animals/animal_utils.py:79-86: (N, 3) LMS rows -> [LM, LM, S] with LM = alpha * L + (1 - alpha) * M."""
+    from ..planevm import run_planes
+
+    v = np.asarray(image_in_LMS)
+    if v.ndim != 2 or v.shape[1] != 3:
+        raise ValueError("expected (N, 3) LMS rows")
+    a = float(alpha)
+    lm = run_planes([v[:, 0].reshape(1, -1), v[:, 1].reshape(1, -1)], lambda be, c: [a * c[0] + (1.0 - a) * c[1]])[0].reshape(-1)
+    dt = np.result_type(v.dtype, np.float32) if not np.issubdtype(v.dtype, np.floating) else v.dtype
+    lm = lm.astype(dt, copy=False)
+    return np.stack([lm, lm, v[:, 2].astype(dt, copy=False)], axis=1)
+
+
+def _planes_of(image: np.ndarray):
     if image.ndim != 3 or image.shape[2] != 3:
         raise ValueError("Expected HxWx3 image")
-    k = cv_auto_ksize(sigma)
-    return gaussian_blur_f32(image, k, sigma).astype(image.dtype, copy=False)
+    f = np.ascontiguousarray(image, dtype=np.float32)
+    return [np.ascontiguousarray(f[..., c]) for c in range(3)]
+
+
+def apply_acuity_blur(image: np.ndarray, sigma: float = 1.5) -> np.ndarray:
+    """animals/animal_utils.py:121-145: cv2.GaussianBlur(float32 image, (0, 0), sigma, sigma) -- ksize = cvRound(8 sigma + 1) | 1,
+    BORDER_REFLECT_101, the shared Gaussian contract (bit-identical to oracle/avxref.cpp; OpenCV itself unpinned) -- on
+    the device; integer frames are converted to float32 first and the result cast back (truncation), like the reference."""
+    from ..planevm import run_planes
+
+    planes = _planes_of(image)
+    k = cv_auto_ksize(float(sigma))
+    taps = gaussian_taps(k, float(sigma))
+    out = np.stack(run_planes(planes, lambda be, v: be.blur_taps(v, k, taps)), axis=-1)
+    return out.astype(image.dtype, copy=False)
+
+
+def apply_anisotropic_acuity_blur_with_streak(image, y_center: float = 0.5, sigma_streak: float = 0.8, sigma_far: float = 2.2, falloff: float = 6.0):
+    """animals/animal_utils.py:147-172 AS CODED (quirk Q3: both passes run along the row, the first also across R,G,B; there
+    is no vertical blur).  Quirk Q4: a float32 argument is blurred IN PLACE and returned (pig.py:35 relies on it)."""
+    from ..planevm import run_planes
+
+    planes = _planes_of(image)
+    params = (float(y_center), float(sigma_streak), float(sigma_far), float(falloff))
+    out = np.stack(run_planes(planes, lambda be, v: be.streak(v, params)), axis=-1)
+    if image.dtype == np.float32:
+        image[...] = out
+        return image
+    return out.astype(image.dtype, copy=False)
+
+
+def apply_chroma_compression(image: np.ndarray, strength: float = 0.4):
+    """animals/animal_utils.py:174-181: gray + (image - gray) * (1 - strength), gray = mean over the channels."""
+    from ..planevm import run_planes
+
+    planes = _planes_of(image)
+    keep = float(np.float32(1.0 - strength)) if image.dtype == np.float32 else float(1.0 - strength)
+
+    def build(be, v):
+        gray = ((v[0] + v[1]) + v[2]) / 3.0
+        return [gray + (c - gray) * keep for c in v]
+
+    out = np.stack(run_planes(planes, build), axis=-1)
+    return out.astype(np.result_type(image.dtype, np.float32) if not np.issubdtype(image.dtype, np.floating) else image.dtype, copy=False)
+
+
+def apply_s_cone_vertical_gain(image_lin, s_top=1.0, s_bottom=0.6, *, power: float = 1.0, extra_boost: float = 0.0, band=None, clamp: bool = True):
+    """animals/animal_utils.py:206-259: per-row gain on the blue channel (ramp, power shaping, boost, optional Gaussian
+    bump), clipped to [0, 1] when `clamp`.  Like the reference it works on `image_lin.astype(float32, copy=False)`: a
+    float32 argument is modified in place and returned."""
+    from ..planevm import run_planes
+
+    if image_lin.ndim != 3 or image_lin.shape[2] != 3:
+        raise ValueError("Expected HxWx3 image")
+    out = image_lin.astype(np.float32, copy=False)
+    H = out.shape[0]
+    gain = s_cone_row_gain(H, s_top, s_bottom, power=power, extra_boost=extra_boost, band=band)
+
+    def build(be, v):
+        b = v[0] * be.row(gain)
+        return [be.clip01(b) if clamp else b]
+
+    out[..., 2] = run_planes([np.ascontiguousarray(out[..., 2])], build)[0]
+    return out

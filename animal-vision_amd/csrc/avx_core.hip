@@ -72,7 +72,7 @@ int avx_upload_row_table(avx_ctx* ctx, avx_ws* ws, const void* host, size_t byte
 // Same idea for the small constant tables that used to be copied from pageable host memory in front of every frame (six per
 // mantis frame): each slot owns its device buffer, so nothing else can overwrite what the mirror says is there.
 int avx_const_upload(avx_ctx* ctx, avx_ws* ws, int slot, const void* host, size_t bytes, hipStream_t s, void** dev_out) {
-    AVX_REQUIRE(ctx, slot >= 0 && slot < 8 && host && bytes > 0, "avx_const_upload: bad arguments");
+    AVX_REQUIRE(ctx, slot >= 0 && slot < 10 && host && bytes > 0, "avx_const_upload: bad arguments");
     avx_ws::const_slot& c = ws->consts[slot];
     if (bytes > c.cap) {
         if (c.dev) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(c.dev)); }

@@ -19,9 +19,10 @@ struct avx_ws {
     void* h_row_tab = nullptr;       // host mirror of what d_row_gain holds: an unchanged table is not uploaded again
     size_t h_row_tab_bytes = 0, h_row_tab_cap = 0;
     // Small constant tables of a caller's pipeline (matrices, weights, coordinate rows): device copy + host mirror per slot,
-    // uploaded only when the bytes change (avx_const_upload).  Slots: 0 UV matrix / weights, 2-7 mantis tables.
+    // uploaded only when the bytes change (avx_const_upload).  Slots: 0 UV matrix / weights, 1 band-major spectral weights (k_spectral_nhwc_h), 2-7 mantis tables,
+    // 8-9 label stroke segments (labels.hip).
     struct const_slot { void* dev = nullptr; void* host = nullptr; size_t bytes = 0, cap = 0; };
-    const_slot consts[8];
+    const_slot consts[10];
     void* uv_small = nullptr;        // UV path: partial statistics, histogram, select state, percentiles
     void* d_scratch = nullptr;       // scratch arena (UV path planes)
     size_t scratch_cap = 0;

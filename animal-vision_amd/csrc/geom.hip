@@ -79,7 +79,14 @@ __global__ __launch_bounds__(kGT) void k_resize_cubic_f32(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(kGT) void k_resize_area_fast_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd,
+// cv::saturate_cast<uchar>(float): cvRound (round half to even), clamped
+__device__ __forceinline__ void put_area(float* d, float v) { *d = v; }
+__device__ __forceinline__ void put_area(uint8_t* d, float v) { const float r = rintf(v); *d = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r)); }
+
+// T = float or uint8_t (cv::resize INTER_AREA of a uint8 image: resizeAreaFast_<uchar, int> sums integers -- exact in float32
+// below 2^24 -- and stores saturate_cast<uchar>(sum * scale); its 2x2 special case rounds (sum + 2) >> 2 instead)
+template <typename T>
+__global__ __launch_bounds__(kGT) void k_resize_area_fast_f32(const T* __restrict__ src, int H, int W, int C, T* __restrict__ dst, int Hd, int Wd,
                                                               int isx, int isy) {
     const size_t total = (size_t)Hd * Wd * C;
     const int area = isx * isy;
@@ -87,17 +94,19 @@ __global__ __launch_bounds__(kGT) void k_resize_area_fast_f32(const float* __res
     for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
         const int c = (int)(i % C);
         const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
-        const float* S = src + ((size_t)(y * isy) * W + (size_t)x * isx) * C + c;
-        auto at = [&](int k) { const int sy = k / isx, sx = k - sy * isx; return S[((size_t)sy * W + sx) * C]; };
+        const T* S = src + ((size_t)(y * isy) * W + (size_t)x * isx) * C + c;
+        auto at = [&](int k) { const int sy = k / isx, sx = k - sy * isx; return (float)S[((size_t)sy * W + sx) * C]; };
         float sum = 0;
         int k = 0;
         for (; k <= area - 4; k += 4) sum += at(k) + at(k + 1) + at(k + 2) + at(k + 3);  // resizeAreaFast_: groups of four
         for (; k < area; ++k) sum += at(k);
-        dst[i] = sum * scale;
+        if (sizeof(T) == 1 && isx == 2 && isy == 2) put_area(dst + i, (float)(((int)sum + 2) >> 2));  // ResizeAreaFastVec, 8-bit 2x2
+        else put_area(dst + i, sum * scale);
     }
 }
 
-__global__ __launch_bounds__(kGT) void k_resize_area_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd,
+template <typename T>
+__global__ __launch_bounds__(kGT) void k_resize_area_f32(const T* __restrict__ src, int H, int W, int C, T* __restrict__ dst, int Hd, int Wd,
                                                          AxisArea ax, AxisArea ay) {
     const size_t total = (size_t)Hd * Wd * C;
     for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
@@ -108,12 +117,12 @@ __global__ __launch_bounds__(kGT) void k_resize_area_f32(const float* __restrict
         const float* be = ay.alpha + (size_t)y * ay.maxcnt;
         float sum = 0.f;
         for (int j = 0; j < ny; ++j) {
-            const float* S = src + ((size_t)(y0 + j) * W + x0) * C + c;
+            const T* S = src + ((size_t)(y0 + j) * W + x0) * C + c;
             float buf = 0.f;
-            for (int k = 0; k < nx; ++k) buf += S[(size_t)k * C] * al[k];  // ResizeArea_Invoker: buf[dx] += S*alpha
+            for (int k = 0; k < nx; ++k) buf += (float)S[(size_t)k * C] * al[k];  // ResizeArea_Invoker: buf[dx] += S*alpha
             sum = j == 0 ? be[j] * buf : sum + be[j] * buf;               // first row of a dy starts the sum
         }
-        dst[i] = sum;
+        put_area(dst + i, sum);
     }
 }
 
@@ -404,7 +413,7 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
     AVX_REQUIRE(ctx, src && dst && src != dst && H > 0 && W > 0 && C > 0 && Hd > 0 && Wd > 0, "avx_resize_hwc: bad arguments");
     AVX_REQUIRE(ctx, dtype == 0 || dtype == 2, "avx_resize_hwc: dtype must be 0 (float32) or 2 (uint8)");
     AVX_REQUIRE(ctx, interp >= 0 && interp <= 3, "avx_resize_hwc: interpolation must be 0 NEAREST, 1 LINEAR, 2 CUBIC or 3 AREA");
-    AVX_REQUIRE(ctx, dtype == 0 || interp == 1, "avx_resize_hwc: uint8 supports INTER_LINEAR only");
+    AVX_REQUIRE(ctx, dtype == 0 || interp == 1 || interp == 3, "avx_resize_hwc: uint8 supports INTER_LINEAR and INTER_AREA only");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     if (interp == 0) {  // no tables
@@ -434,11 +443,13 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
         const double sx = (double)W / Wd, sy = (double)H / Hd;
         const int isx = (int)std::lrint(sx), isy = (int)std::lrint(sy);
         if (std::fabs(sx - isx) < DBL_EPSILON && std::fabs(sy - isy) < DBL_EPSILON) {
-            hipLaunchKernelGGL(k_resize_area_fast_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, isx, isy);
+            if (dtype == 0) hipLaunchKernelGGL(k_resize_area_fast_f32<float>, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, isx, isy);
+            else hipLaunchKernelGGL(k_resize_area_fast_f32<uint8_t>, dim3(g), dim3(kGT), 0, s, (const uint8_t*)src, H, W, C, (uint8_t*)dst, Hd, Wd, isx, isy);
         } else {
             AxisArea ax{}, ay{};
             if ((rc = tc.area(W, Wd, &ax)) || (rc = tc.area(H, Hd, &ay))) return rc;
-            hipLaunchKernelGGL(k_resize_area_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
+            if (dtype == 0) hipLaunchKernelGGL(k_resize_area_f32<float>, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
+            else hipLaunchKernelGGL(k_resize_area_f32<uint8_t>, dim3(g), dim3(kGT), 0, s, (const uint8_t*)src, H, W, C, (uint8_t*)dst, Hd, Wd, ax, ay);
         }
     }
     AVX_HIP(ctx, hipGetLastError());

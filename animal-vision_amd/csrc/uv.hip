@@ -865,27 +865,14 @@ int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype,
         float wT[129 * 16];
         for (int b = 0; b < B; ++b)
             for (int k = 0; k < KP; ++k) wT[b * KP + k] = k < K ? weights_host[(size_t)k * B + b] : 0.0f;
-        // weights are constants of the caller's pipeline: cached on the device under a hash of their contents (one blocking
-        // upload the first time; no copy, no synchronisation afterwards)
+        // weights are constants of the caller's pipeline: device copy + host mirror in constant slot 1 of the stream's workspace,
+        // compared byte for byte and re-uploaded (stream-ordered) only when they change (avx_const_upload)
         avx_ws* wsp = avx_workspace(ctx, s);
         if (!wsp) return AVX_ERR_NOMEM;
-        uint64_t hk = 1469598103934665603ull;
-        for (int i = 0; i < B * KP; ++i) { uint32_t bits; memcpy(&bits, &wT[i], 4); hk ^= bits; hk *= 1099511628211ull; }
-        hk ^= (uint64_t)B * 131u + (uint64_t)KP;
-        hk = (hk & 0x003fffffffffffffull) | (6ull << 58);  // kind 6, component 0 (a real device pointer)
         float* dwT = nullptr;
-        for (int i = 0; i < wsp->n_geom_tabs; ++i)
-            if (wsp->geom_tabs[i].key == hk) dwT = (float*)wsp->geom_tabs[i].dev;
-        if (!dwT) {
-            if (wsp->n_geom_tabs >= 60) {  // full: drop everything (launches may still be reading the tables)
-                AVX_HIP(ctx, hipStreamSynchronize(s));
-                for (int i = 0; i < wsp->n_geom_tabs; ++i)
-                    if (((wsp->geom_tabs[i].key >> 54) & 0xf) < 8) (void)hipFree(wsp->geom_tabs[i].dev);
-                wsp->n_geom_tabs = 0;
-            }
-            AVX_HIP(ctx, hipMalloc((void**)&dwT, sizeof(float) * B * KP + 256));
-            AVX_HIP(ctx, hipMemcpy(dwT, wT, sizeof(float) * B * KP, hipMemcpyHostToDevice));
-            wsp->geom_tabs[wsp->n_geom_tabs++] = {hk, dwT};
+        {
+            const int rcu = avx_const_upload(ctx, wsp, 1, wT, sizeof(float) * B * KP, s, (void**)&dwT);
+            if (rcu) return rcu;
         }
         const size_t lds = (size_t)kT * B * 2 + 16;
         const size_t tiles = (n + kT - 1) / kT, cap = (size_t)ctx->num_cus * 8;

@@ -313,6 +313,16 @@ class MSTPlusPlus(torch.nn.Module):
         self._shapes = reference_key_names(stage)
         self.w = torch.nn.ParameterDict({self._pk(k): torch.nn.Parameter(torch.zeros(s), requires_grad=False) for k, s in self._shapes.items()})
         self._prepared: Dict[str, torch.Tensor] = {}
+        # Diagnostics (tests/test_mstpp.py): when a list, every MS_MSA appends its (heads, 31, 31) attention matrix -- the
+        # softmax output of MST_Plus_Plus.py:131 -- recomputed from the block's Gram matrix and norms.
+        self.capture_attn = None
+
+    def _capture(self, gram: torch.Tensor, nq: torch.Tensor, nk: torch.Tensor, p: str, heads: int):
+        """gram (b, heads, >=31, >=31), nq / nk (b, heads * 32): the attention matrix the fused kernels never materialise."""
+        b = gram.shape[0]
+        a = gram[:, :, :DIM, :DIM].float() / (nk.reshape(b, heads, PAD, 1)[:, :, :DIM].clamp_min(1e-12) * nq.reshape(b, heads, 1, PAD)[..., :DIM].clamp_min(1e-12))
+        a = a * self._p(p + ".rescale").float().reshape(1, heads, 1, 1)
+        self.capture_attn.append(a.softmax(dim=-1).cpu())
 
     @staticmethod
     def _pk(k: str) -> str:
@@ -401,6 +411,8 @@ class MSTPlusPlus(torch.nn.Module):
         if _AVX.fused_ok(x):  # one pass over x: q, k live only in MFMA accumulators, v is the only tensor written
             wpk = self._prep(p + ".qkv.frag", lambda: torch.cat([pack_fragments(wqkv[:, : 2 * c], False), pack_fragments(wqkv[:, 2 * c :], True)], 0).contiguous())
             v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads)
+            if self.capture_attn is not None:
+                self._capture(gram, nq, nk, p, heads)
             # softmax(gram / (nk nq^T) * rescale) and M = blockdiag(attn_h^T) @ W_proj^T in one small launch, M already in fragment order
             resc = self._prep(p + ".rescale32", lambda: self._p(p + ".rescale").float().reshape(heads).contiguous())
             wpt = self._prep(p + ".proj.t32", lambda: self._w(p + ".proj.weight", (0, 1)).t().float().contiguous())
@@ -434,6 +446,8 @@ class MSTPlusPlus(torch.nn.Module):
         attn = attn * self._p(p + ".rescale").float().reshape(1, heads, 1, 1)
         attn[..., DIM:] = float("-inf")  # the padding column takes no part in the softmax over j
         attn = attn.softmax(dim=-1)
+        if self.capture_attn is not None:
+            self.capture_attn.append(attn[:, :, :DIM, :DIM].float().cpu())
         # out_c = proj(concat_h(attn_h @ v_h)) == v @ M + bias,  M = blockdiag(attn_h^T) @ W_proj^T
         wp = self._w(p + ".proj.weight", (0, 1))  # (c_out, c_in)
         wp_h = wp.t().reshape(heads, d, c).float()  # rows of W_proj^T grouped by head (padding rows are zero)

@@ -81,13 +81,15 @@ class FramePipeline:
     """Runs `op.run_device(d_in, d_out, 1, H, W, stream=...)` (DichromatOp / HoneybeeOp) over a stream of
     uint8 frames with `depth` frames in flight."""
 
-    def __init__(self, op, H: int, W: int, *, ctx=None, depth: int = 3, split_compare: bool = False, draw_seam: bool = True):
-        """split_compare: emit make_split_frame(original, transformed) composed on the device (renderers/video.py:198-245,
-        labels excepted) instead of the transformed frame."""
+    def __init__(self, op, H: int, W: int, *, ctx=None, depth: int = 3, split_compare: bool = False, draw_seam: bool = True,
+                 labels: Optional[Tuple[Optional[str], Optional[str]]] = ("Original", "Transformed")):
+        """split_compare: emit make_split_frame(original, transformed) composed on the device (renderers/video.py:198-245:
+        halves, seam, and the two corner labels -- `labels` = (left, right), None = none) instead of the transformed frame."""
         from .runtime import get_context
 
         self.op, self.H, self.W, self.depth = op, H, W, depth
         self.split_compare, self.draw_seam = bool(split_compare), bool(draw_seam)
+        self.labels = tuple(labels) if labels else (None, None)
         self.ctx = ctx or getattr(op, "ctx", None) or get_context()
         if getattr(op, "ctx", None) is None:
             op.ctx = self.ctx
@@ -131,6 +133,10 @@ class FramePipeline:
             self.op.run_device(s.d_in, s.d_out, 1, self.H, self.W, stream=s.stream)
             if self.split_compare:
                 ctx._check(lib.avx_split_compose_u8(ctx._h, s.d_in.ptr, s.d_out.ptr, s.d_out.ptr, self.H, self.W, int(self.draw_seam), s.stream))
+                if self.labels[0] is not None or self.labels[1] is not None:
+                    from .renderers.labels import draw_split_labels_device
+
+                    draw_split_labels_device(ctx, s.d_out, self.H, self.W, self.labels[0], self.labels[1], s.stream)
             ctx._check(lib.avx_memcpy_d2h(ctx._h, s.h_out.ptr, s.d_out.ptr, nbytes, s.stream))
             s.index, s.busy = index, True
             n += 1
@@ -139,27 +145,49 @@ class FramePipeline:
         return StreamStats(n, n * self.H * self.W, time.perf_counter() - t0)
 
 
-def run_video(animal_op, renderer, *, rank: int = 0, world: int = 1, depth: int = 3, split_compare: bool = False, dist=None) -> StreamStats:
-    """main.py:53-72 on the device: read -> visualize -> (split-compose) -> render, this rank's shard only."""
+def run_video(animal_op, renderer, *, rank: int = 0, world: int = 1, depth: int = 3, split_compare: bool = False, dist=None,
+              labels: Optional[Tuple[Optional[str], Optional[str]]] = ("Original", "Transformed")) -> StreamStats:
+    """main.py:53-72 on the device: read -> visualize -> (split-compose + labels) -> render, this rank's shard only.
+
+    A renderer that shards itself (renderers.VideoRenderer(rank=, world=): strided source, index-addressed sink) hands over
+    only this rank's frames and its `last_index` names each one's place in the stream; any other get_image()/render() pair
+    is read in full and filtered here (frame i belongs to rank i mod world).  Outputs go to the sink under their GLOBAL frame
+    index; after the ranks' closing collective (the statistics reduction) rank 0 reassembles a sharded .npy sink into the one
+    ordered stream ("host re-orders outputs by frame index before render()")."""
+    self_sharding = getattr(renderer, "world", 1) == world and getattr(renderer, "rank", 0) == rank and hasattr(renderer, "last_index") and world > 1
     first = renderer.get_image()
     if first is None:
-        return reduce_stats(StreamStats(), dist)
-    H, W, _ = first.shape
-    pipe = FramePipeline(animal_op, H, W, depth=depth, split_compare=split_compare)
+        stats = StreamStats()
+        pipe = None
+    else:
+        H, W, _ = first.shape
+        pipe = FramePipeline(animal_op, H, W, depth=depth, split_compare=split_compare, labels=labels)
 
     def frames():
         i, f = 0, first
         while f is not None:
-            if owner_of(i, world) == rank:
+            if self_sharding:
+                yield renderer.last_index, f
+            elif owner_of(i, world) == rank:
                 yield i, f
             i += 1
             f = renderer.get_image()
 
     def emit(i, out):
-        renderer.render(out)  # already split-composed on the device when split_compare
+        if self_sharding:
+            renderer.render(out, index=i)  # already split-composed on the device when split_compare
+        else:
+            renderer.render(out)
 
-    try:
-        stats = pipe.run(frames(), emit)
-    finally:
-        pipe.close()
-    return reduce_stats(stats, dist)
+    if pipe is not None:
+        try:
+            stats = pipe.run(frames(), emit)
+        finally:
+            pipe.close()
+    if hasattr(renderer, "flush"):
+        renderer.flush()
+    total = reduce_stats(stats, dist)  # a collective: every rank's shard is flushed once it returns anywhere
+    if world > 1 and rank == 0 and dist is not None and hasattr(renderer, "merge_shards"):
+        renderer.close()
+        renderer.merge_shards()
+    return total

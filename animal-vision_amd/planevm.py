@@ -681,3 +681,38 @@ class DeviceProbes:
         ctx.upload(np.ascontiguousarray(image, dtype=np.float32 if floats else np.uint8), be.d_in)
         be.run_device()
         return float(ctx.download(be.scalars.view(8 * slot, 8), (1,), np.float64)[0])
+
+
+def run_planes(inputs: Sequence[np.ndarray], build, *, scalars: bool = False, ctx: Optional[Context] = None):
+    """NumPy in / NumPy out around one recorded plan (the step-wise helper surface: animals/animal_utils.py, uv_mappers.py).
+
+    inputs: HxW float arrays (converted to float32, the reference helpers' working precision); build(be, vals) -> a list
+    of Vals, each returned as an HxW float32 array -- or, with scalars=True, a list whose Vals are frame-wide scalars
+    (reductions / percentiles), returned as Python floats.  Everything O(pixels) runs on the device (csrc/ew.hip and the
+    stage kernels); the plan is recorded per call (milliseconds: these are drop-in helpers, not the fused hot path)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in inputs]
+    H, W = arrs[0].shape
+    assert all(a.shape == (H, W) for a in arrs), "planes must share one HxW shape"
+    be = DeviceBackend(H, W, ctx=ctx, float_frames=True)
+    try:
+        refs = be.new_planes(len(arrs))
+        for a, r in zip(arrs, refs):
+            be.ctx.upload(a, r.buf.view(r.offset, a.nbytes))
+        outs = build(be, [be.load(r) for r in refs])
+        if scalars:
+            slots = []
+            for v in outs:
+                v = be._v(v)
+                if v.op != "scalar":
+                    raise TypeError("scalars=True: build() must return reductions / percentiles")
+                slots.append(v.imm)
+            be.flush()
+        else:
+            mats = [be.mat(v + 0.0 if be._v(v).op in ("load", "scalar", "const") else v) for v in outs]
+            be.flush()
+        be.run_device()
+        if scalars:
+            return [float(be.ctx.download(be.scalars.view(8 * s, 8), (1,), np.float64)[0]) for s in slots]
+        return [be.ctx.download(m.imm.buf.view(m.imm.offset, 4 * H * W), (H, W), np.float32) for m in mats]
+    finally:
+        be.close()

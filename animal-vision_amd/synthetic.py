@@ -35,22 +35,35 @@ def structured_frame(i: int, H: int, W: int) -> np.ndarray:
 
 
 class SyntheticVideoSource:
-    """`get_image()`-style source: n_frames frames of HxW, then None (end of stream)."""
+    """`get_image()`-style source: n_frames frames of HxW, then None (end of stream).
 
-    def __init__(self, H: int, W: int, n_frames: int, kind: str = "noise", pool: int = 8):
+    offset / stride: serve only the global frames offset, offset + stride, ... (< n_frames) -- a rank of a sharded stream
+    touches only its own frames (frame i belongs to rank i mod world).  `index` is the global index of the
+    frame last returned."""
+
+    def __init__(self, H: int, W: int, n_frames: int, kind: str = "noise", pool: int = 8, offset: int = 0, stride: int = 1):
+        if stride < 1 or not (0 <= offset < stride or stride == 1):
+            raise ValueError(f"offset {offset} / stride {stride}")
         self.H, self.W, self.n_frames, self.kind = H, W, n_frames, kind
+        self.offset, self.stride = int(offset), int(stride)
         gen = noise_frame if kind == "noise" else structured_frame
-        # A small pool of distinct frames, cycled: generating 4K noise costs more
-        # host time than the device pipeline takes to process it.
-        self._pool = [gen(i, H, W) for i in range(min(pool, max(1, n_frames)))]
-        self._i = 0
+        # A small pool of distinct frames, cycled (global frame i is pool[i % pool]): generating 4K noise costs more
+        # host time than the device pipeline takes to process it.  Only the pool entries this shard can reach are built.
+        psize = min(pool, max(1, n_frames))
+        reach = sorted({i % psize for i in range(self.offset, n_frames, self.stride)})
+        self._psize = psize
+        self._pool = {k: gen(k, H, W) for k in reach}
+        self._i = self.offset
+        self.index = -1
 
     def get_image(self):
         if self._i >= self.n_frames:
             return None
-        f = self._pool[self._i % len(self._pool)]
-        self._i += 1
+        f = self._pool[self._i % self._psize]
+        self.index = self._i
+        self._i += self.stride
         return f
 
     def reset(self):
-        self._i = 0
+        self._i = self.offset
+        self.index = -1

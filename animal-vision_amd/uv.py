@@ -21,29 +21,32 @@ EPS_DEFAULT: float = 1e-8
 
 # ---------------------------------------------------------------- host tables (NumPy, O(bands)) ----
 def D65_like(lambdas_nm: np.ndarray) -> np.ndarray:
-    """uv_helpers.py:187-192: two-Gaussian daylight SPD, mean-normalised."""
-    x = (lambdas_nm - 560.0) / 50.0
-    base = np.exp(-0.5 * x**2) + 0.3 * np.exp(-0.5 * ((lambdas_nm - 450.0) / 35.0) ** 2)
-    base /= base.mean()
-    return base.astype(np.float32)
+    """Daylight-like illuminant of uv_helpers.py:187-192: a broad lobe at 560 nm plus 0.3 of a narrower one at 450 nm,
+    scaled to unit mean over the grid (float32 in, float32 arithmetic, like the reference)."""
+    grid = np.asarray(lambdas_nm)
+
+    def lobe(centre_nm: float, width_nm: float) -> np.ndarray:
+        z = (grid - centre_nm) / width_nm
+        return np.exp(-0.5 * z**2)
+
+    spd = lobe(560.0, 50.0) + 0.3 * lobe(450.0, 35.0)
+    return (spd / spd.mean()).astype(np.float32)
 
 
 def bandpass_weights(lambdas: np.ndarray, lo: float, hi: float) -> np.ndarray:
-    """uv_helpers.py:125-139: raised-cosine window, sum-normalised; uniform 1/B when the band holds no
-    wavelength or its weights vanish (quirk Q7: what a UV band on a 400-700 nm grid degenerates to)."""
-    wl = lambdas.astype(np.float32)
-    w = np.zeros_like(wl, dtype=np.float32)
-    mask = (wl >= lo) & (wl <= hi)
-    if not np.any(mask):
-        return np.ones_like(wl, dtype=np.float32) / float(wl.size)
-    x = (wl[mask] - lo) / (hi - lo)
-    w[mask] = 0.5 * (1.0 - np.cos(2.0 * np.pi * x))
-    s = float(np.sum(w))
-    if s > 1e-12:
-        w /= s
-    else:
-        w = np.ones_like(wl, dtype=np.float32) / float(wl.size)
-    return w
+    """Band weights of uv_helpers.py:125-139 over a wavelength grid: a raised-cosine (Hann) window across [lo, hi] scaled to
+    unit sum.  Quirk Q7 made explicit: a band that contains no grid wavelength, or whose window sums to (numerically)
+    nothing, gets the UNIFORM weights 1/B -- what a UV band on a 400-700 nm grid degenerates to in the reference."""
+    grid = lambdas.astype(np.float32)
+    uniform = np.full(grid.shape, 1.0, np.float32) / float(grid.size)
+    inside = (grid >= lo) & (grid <= hi)
+    if not inside.any():
+        return uniform
+    window = np.zeros_like(grid)
+    phase = (grid[inside] - lo) / (hi - lo)
+    window[inside] = 0.5 * (1.0 - np.cos(2.0 * np.pi * phase))
+    total = float(window.sum())
+    return window / total if total > 1e-12 else uniform
 
 
 def lobe_tables(wavelengths: np.ndarray) -> Tuple[np.ndarray, float]:

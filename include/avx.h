@@ -191,6 +191,16 @@ int avx_binocular_warp_u8(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, con
 int avx_split_compose_u8(avx_ctx* ctx, const uint8_t* original_hwc, const uint8_t* modified_hwc, uint8_t* out_hwc,
                          int H, int W, int draw_seam, void* stream);
 
+/* VideoRenderer._draw_label (renderers/video.py:160-196) on a device-resident uint8 frame, in place: the 60 % black box
+ * (inside box_xyxy, inclusive corners: out = saturate_cast<uchar>(0.4 * in)), then the text as stroke segments -- black at
+ * outline_thickness, white at text_thickness (cv2.putText x 2, :194-195).  segments_host: n x 6 floats per segment
+ * {ax, ay, bx - ax, by - ay, 1 / |b - a|^2 (0 for a point), 0} in pixel coordinates, built by the host from the Hershey
+ * simplex stroke tables with the reference's geometry (renderers/labels.py).  Anti-aliasing is analytic distance coverage, not
+ * OpenCV's LINE_AA scan converter (label pixels: parity unpinned; geometry pinned).  slot (0 | 1) names which of two cached
+ * device copies of the segment table the call may reuse (a frame has two labels). */
+int avx_draw_label_u8(avx_ctx* ctx, uint8_t* img_hwc, int H, int W, const int box_xyxy[4], const float* segments_host, int n_segments,
+                      float outline_thickness, float text_thickness, int slot, void* stream);
+
 /* cv2.remap(src, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT, borderValue) on K float32 planes that share two
  * per-pixel float32 maps (anableps.py:217-226): coordinates quantised to 1/32 px like OpenCV. */
 int avx_remap_linear_planes(avx_ctx* ctx, const float* src_planes, int K, int H, int W, const float* mapx_dev,

@@ -792,11 +792,12 @@ def mantis_hue_lut(N: int) -> np.ndarray:
     ).astype(np.float32)
 
 
-def mantis_barcode(S: np.ndarray, *, winner_take_most: float = 0.35, barcode_saturation: float = 0.40):
+def mantis_barcode(S: np.ndarray, *, winner_take_most: float = 0.35, barcode_saturation: float = 0.40, _jit=None):
     """animals/mantis_shrimp.py:199-211 -> (barcode_rgb (H,W,3), S_norm (H,W,N))."""
     N = S.shape[2]
     lut = mantis_hue_lut(N)
-    S_norm = S / (np.percentile(S, 95.0) + 1e-8)
+    p95 = np.percentile(S, 95.0)
+    S_norm = S / ((p95 if _jit is None else _jit(p95)) + 1e-8)
     S_norm = np.clip(S_norm, 0.0, 1.0)
     max_idx = np.argmax(S_norm, axis=2)
     weights = S_norm / (np.sum(S_norm, axis=2, keepdims=True) + 1e-8)
@@ -809,15 +810,64 @@ def mantis_barcode(S: np.ndarray, *, winner_take_most: float = 0.35, barcode_sat
 
 
 # ---- renderers/video.py:198-245 (split compose without labels) -----------------
+def relative_jitter(seed: int, amp: float = 2.0 ** -20):
+    """The _jit callable of mantis_visualize: x -> x * (1 + amp * u), u uniform in [-1, 1] per element (tests only)."""
+    rng = np.random.default_rng(seed)
+
+    def jit(x):
+        if isinstance(x, np.ndarray):
+            return x * (1 + x.dtype.type(amp) * rng.uniform(-1.0, 1.0, x.shape).astype(x.dtype))
+        return type(x)(x * (1.0 + amp * rng.uniform(-1.0, 1.0)))
+
+    return jit
+
+
 def make_split_frame_nolabel(original: np.ndarray, modified: np.ndarray, draw_seam: bool = True) -> np.ndarray:
     """renderers/video.py:234-239: left half original, right half modified, 1-px white seam.
     (Hershey-font labels of :242-244 are cv2 drawing code: out of scope)"""
+    H, W = original.shape[:2]
+    if modified.shape[:2] != (H, W):  # :228-231
+        modified = cv_resize(np.ascontiguousarray(modified), (W, H), INTER_AREA)
     out = original.copy()
-    mid = original.shape[1] // 2
+    mid = W // 2
     out[:, mid:, :] = modified[:, mid:, :]
     if draw_seam:
         out[:, mid : mid + 1, :] = 255
     return out
+
+
+def draw_label_pixels(img: np.ndarray, box, segs: np.ndarray, outline_thickness: float, text_thickness: float) -> np.ndarray:
+    """The pixel arithmetic of csrc/labels.hip::k_draw_label in NumPy float32, operation for operation (in place on a
+    uint8 HxWx3 frame; returns it): 60 % black box (renderers/video.py:189-191: saturate_cast(0.4 * in) inside the
+    inclusive box), then black strokes at outline_thickness and white strokes at text_thickness with analytic coverage
+    clamp(t/2 + 0.5 - distance, 0, 1).  box = (x0, y0, x1, y1); segs = (n, 6) float32 {ax, ay, dx, dy, 1/len^2, 0}.
+    Geometry and segments come from the caller (the reference's layout rules are checked separately, with literal numbers,
+    in tests/test_labels.py).  OpenCV's LINE_AA rasteriser is NOT restated: label pixels are parity-unpinned."""
+    H, W, _ = img.shape
+    x0, y0, x1, y1 = (int(v) for v in box)
+    ho, ht = np.float32(0.5 * outline_thickness), np.float32(0.5 * text_thickness)
+    grow = int(float(ho) + 2.0)
+    rx0, ry0, rx1, ry1 = max(x0 - grow, 0), max(y0 - grow, 0), min(x1 + grow, W - 1), min(y1 + grow, H - 1)
+    if rx1 < rx0 or ry1 < ry0:
+        return img
+    ys, xs = np.mgrid[ry0 : ry1 + 1, rx0 : rx1 + 1]
+    px, py = xs.astype(np.float32), ys.astype(np.float32)
+    d2 = np.full(px.shape, np.float32(3.0e38), np.float32)
+    for g in np.asarray(segs, np.float32).reshape(-1, 6):
+        qx, qy = px - g[0], py - g[1]
+        t = np.clip((qx * g[2] + qy * g[3]) * g[4], np.float32(0), np.float32(1))
+        ex, ey = qx - t * g[2], qy - t * g[3]
+        d2 = np.minimum(d2, ex * ex + ey * ey)
+    d = np.sqrt(d2)
+    co = np.clip(ho + np.float32(0.5) - d, np.float32(0), np.float32(1))
+    ct = np.clip(ht + np.float32(0.5) - d, np.float32(0), np.float32(1))
+    inbox = (xs >= x0) & (xs <= x1) & (ys >= y0) & (ys <= y1)
+    v = img[ry0 : ry1 + 1, rx0 : rx1 + 1, :].astype(np.float32)
+    v = np.where(inbox[..., None], np.rint(v * np.float32(0.4)), v)
+    v = np.rint(v - v * co[..., None])
+    v = np.rint(v + (np.float32(255.0) - v) * ct[..., None])
+    img[ry0 : ry1 + 1, rx0 : rx1 + 1, :] = np.clip(v, 0, 255).astype(np.uint8)
+    return img
 
 
 # =============================================================================
@@ -832,10 +882,21 @@ def cv_resize(img: np.ndarray, dsize: Tuple[int, int], interpolation: int = INTE
     squeeze = img.ndim == 2
     a = np.ascontiguousarray(img[..., None] if squeeze else img)
     H, W, C = a.shape
-    if a.dtype == np.uint8:
-        assert interpolation == INTER_LINEAR, "uint8: only INTER_LINEAR is restated"
+    if a.dtype == np.uint8 and interpolation == INTER_AREA and not (Wd > W or Hd > H):
+        # cv::resize(8-bit, INTER_AREA), shrinking: resizeAreaFast_<uchar, int> / resizeArea_<uchar, float> run the float path's
+        # arithmetic on integer samples (block sums are exact in float32 below 2^24) and store saturate_cast<uchar> (cvRound:
+        # half to even); the 8-bit 2x2 special case (ResizeAreaFastVec) rounds (sum + 2) >> 2 instead.  PARITY UNPINNED (no OpenCV here).
+        if W == 2 * Wd and H == 2 * Hd:
+            s4 = a[0::2, 0::2].astype(np.int32) + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]
+            out = ((s4 + 2) >> 2).astype(np.uint8)
+        else:
+            f = np.empty((Hd, Wd, C), np.float32)
+            lib().cvref_resize_area_f32(_p(a.astype(np.float32)), H, W, C, _p(f), Hd, Wd)
+            out = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    elif a.dtype == np.uint8:
+        assert interpolation in (INTER_LINEAR, INTER_AREA), "uint8: INTER_LINEAR and INTER_AREA are restated"
         out = np.empty((Hd, Wd, C), np.uint8)
-        lib().cvref_resize_linear_u8(_p(a), H, W, C, _p(out), Hd, Wd)
+        lib().cvref_resize_linear_u8(_p(a), H, W, C, _p(out), Hd, Wd)  # INTER_AREA when enlarging behaves like INTER_LINEAR
     else:
         a = a.astype(np.float32, copy=False)
         out = np.empty((Hd, Wd, C), np.float32)
@@ -987,8 +1048,11 @@ def mantis_visualize(image: np.ndarray, *, hsi_scale: float = 0.25, panorama_sca
                      unsharp_sigma=1.0, unsharp_amount=0.32, evec_angle_deg=30.0, pol_linear_strength=0.55, pol_linear_gamma=1.2,
                      pol_circular_strength=0.35, orientation_mix=0.5, barcode_saturation=0.40, barcode_opacity=0.55,
                      winner_take_most=0.35, scan_row_freq=26.0, scan_row_gain=0.08, scan_soften=0.8, periph_blur_sigma=0.7,
-                     periph_radius=0.80, periph_softness=7.0):
-    """animals/mantis_shrimp.py:143-279 (cv2 branches), defaults of :42-86."""
+                     periph_radius=0.80, periph_softness=7.0, _jit=None):
+    """animals/mantis_shrimp.py:143-279 (cv2 branches), defaults of :42-86.
+    _jit (tests only, tests/_sensitivity.py): a callable applied to the band stack, the P95, the gradient angle and the blurred
+    planes -- relative float32-level jitter that shows where this arithmetic is unstable (argmax ties, arctan2 of ~0 gradients)."""
+    jit = (lambda a: a) if _jit is None else _jit
     assert isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] == 3
     dtype = image.dtype
     lambdas = np.linspace(300.0, 700.0, 81, dtype=np.float32) if lambdas is None else np.asarray(lambdas, np.float32)
@@ -1005,18 +1069,18 @@ def mantis_visualize(image: np.ndarray, *, hsi_scale: float = 0.25, panorama_sca
     else:
         hsi = classic_rgb_to_hsi_lobes(baseline_lin, lambdas)
     H, W = baseline_lin.shape[:2]
-    S = mantis_band_stack(hsi, lambdas, bands)                                                         # :167-172
-    barcode_rgb, S_norm = mantis_barcode(S, winner_take_most=winner_take_most, barcode_saturation=barcode_saturation)  # :175-211
+    S = jit(mantis_band_stack(hsi, lambdas, bands))                                                    # :167-172
+    barcode_rgb, S_norm = mantis_barcode(S, winner_take_most=winner_take_most, barcode_saturation=barcode_saturation, _jit=_jit)  # :175-211
     render = baseline_lin.copy()                                                                       # :214-220
     render[..., 0] = np.clip(render[..., 0] * (1.0 - red_kill), 0.0, 1.0)
     if haze_strength > 0.0:
         a = float(np.clip(haze_strength, 0.0, 1.0))
         render = (1.0 - a) * render + a * haze_tint[None, None, :]
     if pre_soft_sigma > 0.0:
-        render = gaussian_blur(render, pre_soft_sigma)
+        render = jit(gaussian_blur(render, pre_soft_sigma))
     broad = np.mean(S_norm, axis=2).astype(np.float32)                                                 # :224-226
-    gx, gy = cv_sobel3(broad, 1, 0), cv_sobel3(broad, 0, 1)
-    theta = np.arctan2(gy, gx).astype(np.float32)
+    gx, gy = jit(cv_sobel3(broad, 1, 0)), jit(cv_sobel3(broad, 0, 1))
+    theta = jit(np.arctan2(gy, gx).astype(np.float32))
     cos2_local, sin2_local = np.cos(2.0 * theta), np.sin(2.0 * theta)                                  # :229-242
     cos2_global, sin2_global = float(np.cos(2.0 * evec_angle)), float(np.sin(2.0 * evec_angle))
     mix = orientation_mix
@@ -1026,7 +1090,7 @@ def mantis_visualize(image: np.ndarray, *, hsi_scale: float = 0.25, panorama_sca
     align_circ = np.clip(0.5 * (sin2_mix + 1.0), 0.0, 1.0)
     pol_gain = 1.0 + pol_linear_strength * align01 + pol_circular_strength * align_circ
     if unsharp_sigma > 0.0 and unsharp_amount > 0.0:                                                   # :244-247
-        blur = gaussian_blur(render, unsharp_sigma)
+        blur = jit(gaussian_blur(render, unsharp_sigma))
         high = np.clip(render - blur, -1.0, 1.0)
         render = np.clip(render + (unsharp_amount * pol_gain[..., None]) * high, 0.0, 1.0)
     render = np.clip((1.0 - barcode_opacity) * render + barcode_opacity * barcode_rgb, 0.0, 1.0)       # :250
@@ -1039,7 +1103,7 @@ def mantis_visualize(image: np.ndarray, *, hsi_scale: float = 0.25, panorama_sca
         row_gain = 1.0 + scan_row_gain * (rows - 0.5)
         render = np.clip(render * row_gain[..., None], 0.0, 1.0)
     if periph_blur_sigma > 0.0:                                                                        # :268-275
-        periph = gaussian_blur(render, periph_blur_sigma)
+        periph = jit(gaussian_blur(render, periph_blur_sigma))
         yy = (np.linspace(-1.0, 1.0, H, dtype=np.float32))[:, None]
         xx = (np.linspace(-1.0, 1.0, W, dtype=np.float32))[None, :]
         r = np.sqrt(xx * xx + yy * yy)

@@ -134,6 +134,58 @@ for _name, _fn in dict(sqrt=np.sqrt, exp=np.exp, log=np.log, sin=np.sin, cos=np.
     setattr(NumpyBackend, _name, staticmethod(_fn))
 
 
+class JitterBackend(NumpyBackend):
+    """Sensitivity probe for the parity tests (tests/_sensitivity.py): the same eager NumPy evaluation, but the result of
+    every stage call, reduction and transcendental is multiplied by (1 + amp * u), u uniform in [-1, 1] per element --
+    a model of what a second correct float32 implementation may legitimately differ by (device transcendentals are
+    1-2 ulp off NumPy's, the device sums in another order, the reference silently promotes some chains to float64).
+    Pixels whose OUTPUT CODE moves under such jitter are the ones where the reference's own arithmetic is unstable at
+    float32 rounding level: categorical decisions (masks, argmax, floor) within rounding of their boundary, and
+    cancellations such as x / (x + y + z + 1e-8) with all terms at 1e-8 (hummingbird.py:178-185).  The baseline is
+    never jittered (its contract is bit-exact)."""
+    name = "numpy-jitter"
+
+    def __init__(self, H: int, W: int, seed: int, amp: float = 2.0 ** -20):
+        super().__init__(H, W)
+        self._rng = np.random.default_rng(seed)
+        self._amp = float(amp)
+
+    def _j(self, x):
+        if isinstance(x, (list, tuple)):
+            return type(x)(self._j(v) for v in x)
+        if isinstance(x, np.ndarray) and np.issubdtype(x.dtype, np.floating):
+            u = self._rng.uniform(-1.0, 1.0, x.shape).astype(x.dtype)
+            return x * (1 + x.dtype.type(self._amp) * u)
+        if isinstance(x, (float, np.floating)):
+            return type(x)(x * (1.0 + self._amp * self._rng.uniform(-1.0, 1.0)))
+        return x
+
+
+def _jittered(name):
+    base = getattr(NumpyBackend, name)
+
+    def call(self, *a, **k):
+        return self._j(base(self, *a, **k) if not isinstance(NumpyBackend.__dict__[name], staticmethod) else base(*a, **k))
+
+    return call
+
+
+for _name in ("min", "max", "sum", "mean", "safe_norm", "percentile", "percentiles", "blur", "blur_taps", "streak", "sobel", "remap", "down_up", "front",
+              "bands", "sqrt", "exp", "log", "sin", "cos", "tanh", "arctan2", "power"):
+    setattr(JitterBackend, _name, _jittered(_name))
+
+
+def run_jittered(species, image: np.ndarray, seed: int, amp: float = 2.0 ** -20, **kw):
+    """(baseline, out) with the jitter probe; the baseline equals run()'s."""
+    be = JitterBackend(image.shape[0], image.shape[1], seed, amp)
+    v = species.variant(image, NumpyProbes, **kw)
+    if v is None:
+        species.render(be, image)
+    else:
+        species.render(be, image, v)
+    return be.baseline_out, be.out
+
+
 class NumpyProbes:
     @staticmethod
     def median_luma(image: np.ndarray) -> float:

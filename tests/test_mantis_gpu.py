@@ -12,11 +12,13 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _check(got, want, what):
-    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
-    frac_off = float((diff > 1).mean())
-    assert frac_off <= 2e-3, (what, "fraction beyond +-1:", frac_off, "max", int(diff.max()))
-    assert float((diff > 0).mean()) <= 0.05, (what, "fraction != :", float((diff > 0).mean()))
+def _check(got, want, what, frame, kw):
+    """+-1 code everywhere except where the oracle itself is unstable under float32-level jitter (argmax ties of
+    mantis_shrimp.py:202, arctan2 of ~0 gradients at :226), with an absolute cap (tests/_sensitivity.py)."""
+    from _sensitivity import check_codes
+    from oracle import cpu_ref
+
+    return check_codes(got, want, what, lambda seed: cpu_ref.mantis_visualize(frame, _jit=cpu_ref.relative_jitter(seed), **kw)[1])
 
 
 @pytest.mark.parametrize("tag,kw", [("default", {}), ("noresample", dict(hsi_scale=1.0, panorama_scale=1.0))])
@@ -29,7 +31,7 @@ def test_mantis_vs_reference_golden(tag, kw):
         base, out = m.visualize(g[f"in_{k}"])
         assert base.dtype == np.uint8 and out.dtype == np.uint8 and base.shape == out.shape == g[f"in_{k}"].shape
         assert np.array_equal(base, g[f"{tag}_base_{k}"]), (tag, k, "baseline")
-        _check(out, g[f"{tag}_out_{k}"], (tag, k))
+        _check(out, g[f"{tag}_out_{k}"], (tag, k), g[f"in_{k}"], kw)
 
 
 @pytest.mark.parametrize("shape,kw", [
@@ -49,7 +51,7 @@ def test_mantis_vs_oracle(oracle, shape, kw):
     base, out = MantisShrimp(**kw).visualize(frame)
     wbase, wout = oracle.mantis_visualize(frame, **kw)
     assert np.array_equal(base, wbase)
-    _check(out, wout, (shape, kw))
+    _check(out, wout, (shape, kw), frame, kw)
 
 
 def test_mantis_float_frames_vs_oracle(oracle):

@@ -43,7 +43,7 @@ def test_video_renderer_surface(tmp_path):
             break
         assert f.shape == (48, 64, 3) and f.dtype == np.uint8
         frames.append(f)
-        vr.render_split_compare(f, 255 - f)
+        vr.render_split_compare(f, 255 - f, left_label=None, right_label=None)  # labels are drawn on the device (tests/test_labels.py)
     vr.close()
     assert len(frames) == 5
     out = np.load(tmp_path / "out.npy")

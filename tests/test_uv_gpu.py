@@ -72,6 +72,53 @@ def test_spectral_integrate_vs_oracle(uv, oracle):
     np.testing.assert_allclose(got16, want16, rtol=1e-5, atol=1e-7)
 
 
+def _band_matrix(uv, K, B):
+    lam = np.linspace(300.0 if B == 81 else 400.0, 700.0, B, dtype=np.float32)
+    edges = np.linspace(float(lam[0]), float(lam[-1]), K + 1)
+    return np.ascontiguousarray(np.stack([uv.bandpass_weights(lam, float(lo), float(hi)) for lo, hi in zip(edges[:-1], edges[1:])]), dtype=np.float32)
+
+
+@pytest.mark.parametrize("K,B", [(12, 31), (10, 81), (3, 32)])
+@pytest.mark.parametrize("shape", [(1, 7), (9, 23), (16, 16), (37, 53), (64, 260)])
+def test_spectral_integrate_fp16_nhwc_vs_tensordot(uv, K, B, shape):
+    """BASELINE config 5 and the MST++ hand-off: float16 NHWC cube -> K float32 planes (csrc/uv.hip::k_spectral_nhwc_h, the
+    LDS-staged kernel).  (12,31) = the config's mantis stack, (10,81) = the reference MantisShrimp default, (3,32) = the
+    32-wide padded MST++ cube.  Pixel counts below, at and across the 256-pixel tile, not multiples of it; float32
+    np.tensordot of the same float16 values is the reference arithmetic (north_star: 1e-4 relative; held to 1e-5)."""
+    rng = np.random.default_rng(K * 100 + B + shape[1])
+    H, W = shape
+    cube = rng.random((H, W, B), dtype=np.float32).astype(np.float16)
+    Wk = _band_matrix(uv, K, B) if B != 32 else rng.random((K, B), dtype=np.float32)
+    got, stats = uv.spectral_integrate(cube, Wk, return_stats=True)
+    want = np.tensordot(cube.astype(np.float32), Wk, axes=([2], [1])).transpose(2, 0, 1)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(stats[:, 0], want.reshape(K, -1).min(1), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(stats[:, 1], want.reshape(K, -1).max(1), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(stats[:, 2], want.reshape(K, -1).mean(1), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("K,B", [(12, 31), (10, 81)])
+def test_spectral_integrate_fp16_nhwc_4k_properties(uv, K, B):
+    """The same kernel at BASELINE's full size (3840x2160) through size-independent properties: (1) linearity -- planes of
+    a cube built from two pixel values tiled over the frame equal the K x 2 table computed on the CPU, at every pixel;
+    (2) the device statistics agree with the planes that came back; (3) changing the weights between calls is honoured
+    (the device-side weight table is cached against a host mirror)."""
+    H, W = 2160, 3840
+    rng = np.random.default_rng(B)
+    px = rng.random((2, B), dtype=np.float32).astype(np.float16)
+    which = (np.add.outer(np.arange(H), np.arange(W)) % 3 == 0).astype(np.int8)  # pattern not aligned to the 256-pixel tiles
+    cube = px[which]
+    for scale in (1.0, 0.5):
+        Wk = _band_matrix(uv, K, B) * np.float32(scale)
+        table = (px.astype(np.float32) @ Wk.T.astype(np.float32))  # (2, K) float32, same sum order is not needed at 1e-5
+        got, stats = uv.spectral_integrate(cube, Wk, return_stats=True)
+        want = table[which].transpose(2, 0, 1)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(stats[:, 0], got.reshape(K, -1).min(1), rtol=1e-6)
+        np.testing.assert_allclose(stats[:, 1], got.reshape(K, -1).max(1), rtol=1e-6)
+        np.testing.assert_allclose(stats[:, 2], got.reshape(K, -1).mean(1, dtype=np.float64), rtol=1e-5)
+
+
 @pytest.mark.parametrize("sigma", [0.2, 0.7, 1.0, 1.2, 3.0])
 @pytest.mark.parametrize("shape", [(36, 44), (5, 3), (70, 130, 3)])
 def test_gaussian_blur_bit_exact_with_shared_contract(uv, oracle, sigma, shape):

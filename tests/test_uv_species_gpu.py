@@ -4,7 +4,8 @@ on other frame sizes.
 
 Contract: baseline (decode -> cubic panorama warp -> encode) bit-exact; the stylised frame is a float32
 pipeline held to 1e-4 relative before the uint8 encode: codes within +-1, allowing a small fraction of samples
-beyond that where a categorical decision (argmax, threshold masks) sits within rounding of its boundary."""
+beyond that ONLY where the oracle's own arithmetic is unstable under float32-level jitter (a categorical decision within
+rounding of its boundary, a 0/0-like cancellation) -- established per frame by tests/_sensitivity.py, with an absolute cap."""
 import numpy as np
 import pytest
 
@@ -24,10 +25,14 @@ def test_species_list_complete():
     assert sorted(animals.UV_CLASS) == SPECIES
 
 
-def _check(got, want, what, frac_beyond=2e-3, frac_any=0.05):
-    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
-    assert float((diff > 1).mean()) <= frac_beyond, (what, "fraction beyond +-1:", float((diff > 1).mean()), "max", int(diff.max()))
-    assert float((diff > 0).mean()) <= frac_any, (what, "fraction != :", float((diff > 0).mean()))
+def _check(got, want, what, sp=None, frame=None, **kw):
+    """+-1 code everywhere except where the oracle itself is unstable under float32-level jitter, with an absolute cap on
+    the number of such pixels (tests/_sensitivity.py)."""
+    from _sensitivity import check_codes
+    from oracle import np_backend
+
+    rerun = None if sp is None else (lambda seed: np_backend.run_jittered(sp, frame, seed, **kw)[1])
+    return check_codes(got, want, what, rerun)
 
 
 @pytest.mark.parametrize("mod", SPECIES)
@@ -40,7 +45,7 @@ def test_species_vs_reference_golden(mod):
         base, out = sp.visualize(g[f"in_{k}"])
         assert base.dtype == np.uint8 and out.dtype == np.uint8
         assert np.array_equal(base, g[f"{mod}_base_{k}"]), (mod, k, "baseline")
-        _check(out, g[f"{mod}_out_{k}"], (mod, k))
+        _check(out, g[f"{mod}_out_{k}"], (mod, k), sp, g[f"in_{k}"])
 
 
 @pytest.mark.parametrize("mod", SPECIES)
@@ -57,13 +62,13 @@ def test_species_vs_oracle_other_sizes(mod):
         base, out = sp.visualize(frame)
         wbase, wout = np_backend.run(sp, frame)
         assert np.array_equal(base, wbase), (mod, shape)
-        _check(out, wout, (mod, shape))
+        _check(out, wout, (mod, shape), sp, frame)
     # second frame of an already-recorded size replays the plan
     frame2 = np.ascontiguousarray(frame[::-1])
     base, out = sp.visualize(frame2)
     wbase, wout = np_backend.run(sp, frame2)
     assert np.array_equal(base, wbase)
-    _check(out, wout, (mod, "replay"))
+    _check(out, wout, (mod, "replay"), sp, frame2)
 
 
 @pytest.mark.parametrize("mod", ["reindeer", "rat_uv", "kestrel", "anableps"])
@@ -91,7 +96,7 @@ def test_rat_uv_night_branch_and_auto_mode():
     g = load_golden("uv_species")
     sp = RatUV()
     for k in ("s64", "n50"):
-        _check(sp.visualize(g[f"in_{k}"], mode="night")[1], g[f"rat_uv_night_out_{k}"], ("night", k))
+        _check(sp.visualize(g[f"in_{k}"], mode="night")[1], g[f"rat_uv_night_out_{k}"], ("night", k), sp, g[f"in_{k}"], mode="night")
     dark = (g["in_s64"] // 6).astype(np.uint8)  # median luminance < 0.12: `auto` takes the night branch
     assert sp.variant(dark, np_backend.NumpyProbes) == "night"
     from animal_vision_amd.planevm import DeviceProbes
@@ -100,7 +105,7 @@ def test_rat_uv_night_branch_and_auto_mode():
     base, out = sp.visualize(dark)
     wbase, wout = np_backend.run(sp, dark)
     assert np.array_equal(base, wbase)
-    _check(out, wout, "auto->night")
+    _check(out, wout, "auto->night", sp, dark)
 
 
 def test_ew_program_basic_ops_and_reductions():

@@ -356,6 +356,66 @@ def g_mstpp():
     save("predict_torch_helpers", **o2)
 
 
+def g_mstpp_large():
+    """a25 above toy sizes: the reference module (same seeded fp16-rounded weights as g_mstpp) on structured frames of
+    256x256, 512x512 and 1920x1080 -- the normalise and k @ q^T of MS_MSA (:127-129) reduce over EVERY pixel, so the
+    Gram/norm accumulations are only exercised at size.  Stored: the whole 256x256 output (float16 container), three
+    64x64 crops of the 512x512 and 1080p outputs (float32), every block's attention matrix (the softmax output of
+    :131, captured by wrapping Tensor.softmax while the reference runs), and -- where this torch accepts CPU float16
+    autocast, the precision predict_torch.py:109 runs at -- the error of that autocast output against the float32 one
+    (the yardstick the GPU float16 path is held to).  Inputs are synthetic.structured_frame(seed, H, W) / 255 (not stored)."""
+    import time
+
+    import torch
+
+    arch = _load("_ref_mstpp", os.path.join(REF, "ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py"))
+    torch.manual_seed(0)
+    model = arch.MST_Plus_Plus().eval()
+    sd = {k: v.half().float() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    out = {}
+    real_softmax = torch.Tensor.softmax
+    for nm, seed, (h, w), crops in (("256", 5, (256, 256), None), ("512", 6, (512, 512), ((0, 0), (200, 300), (448, 448))),
+                                    ("1080p", 7, (1080, 1920), ((0, 0), (500, 900), (1016, 1856)))):
+        x = (structured_frame(seed, h, w).astype(np.float32) / 255.0).transpose(2, 0, 1)[None]
+        attn = []
+
+        def spy(self, *a, **k):
+            r = real_softmax(self, *a, **k)
+            attn.append(r.detach().float().numpy().copy())
+            return r
+
+        torch.Tensor.softmax = spy
+        t0 = time.time()
+        try:
+            with torch.no_grad():
+                y = model(torch.from_numpy(x)).numpy()[0]  # (31, h, w)
+        finally:
+            torch.Tensor.softmax = real_softmax
+        print(f"   {nm}: reference float32 forward {time.time() - t0:.1f} s, |y| mean {np.abs(y).mean():.4f} max {np.abs(y).max():.4f}")
+        assert len(attn) == 15
+        out[f"seed_{nm}"] = np.array([seed, h, w])
+        for i, a in enumerate(attn):
+            out[f"attn_{nm}_{i}"] = a[0]  # (heads, 31, 31)
+        if crops is None:
+            out[f"y_{nm}"] = y.astype(np.float16)
+        else:
+            out[f"crops_{nm}"] = np.array(crops)
+            for j, (cy, cx) in enumerate(crops):
+                out[f"y_{nm}_crop{j}"] = y[:, cy:cy + 64, cx:cx + 64].copy()
+        out[f"ymeanabs_{nm}"] = np.array([np.abs(y).mean(), np.sqrt((y.astype(np.float64) ** 2).mean())])
+        if nm != "1080p":
+            try:
+                with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+                    ya = model(torch.from_numpy(x)).float().numpy()[0]
+                d = np.abs(ya - y)
+                out[f"autocast_err_{nm}"] = np.array([d.max(), d.mean(), np.sqrt((d.astype(np.float64) ** 2).mean())])
+                print(f"   {nm}: CPU float16 autocast vs float32: max {d.max():.3e} mean {d.mean():.3e}")
+            except Exception as e:  # noqa: BLE001
+                print(f"   {nm}: CPU float16 autocast not available here: {type(e).__name__}: {e}")
+    save("mstpp_large", **out)
+
+
 def g_geometry():
     """8f row 1 helpers of the reference (uv_helpers.panorama_warp, classic_rgb_to_hsi_scaled, cat FOV helpers)
     driven with the injected resize/remap, plus the full Cat (cat.py:73-112 re-enacted: the file does not parse)."""
@@ -465,7 +525,7 @@ def g_uv_species():
 
 
 GENERATORS = {"srgb_tables": g_srgb_tables, "matrices": g_matrices, "dichromat": g_dichromat, "uv": g_uv,
-              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp, "geometry": g_geometry, "mantis": g_mantis, "uv_species": g_uv_species}
+              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp, "mstpp_large": g_mstpp_large, "geometry": g_geometry, "mantis": g_mantis, "uv_species": g_uv_species}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
