@@ -95,6 +95,9 @@ class _AvxOps:
         self._mfma = os.environ.get("AVX_MST_NO_MFMA", "") == ""  # A/B: the fused matrix-core kernels of csrc/mst_mfma.hip
         self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
         self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
+        self._tail = False  # the attention tail (pos_emb + v @ M + bias + x) in one pass -- set when the kernel exists
+        self._ffn = False   # the whole FeedForward in one kernel, hidden tile in LDS -- set when the kernel exists
+        self.FFN_FUSED_C = ()
         self._ctx = {}
 
     def ctx(self, device: torch.device):
@@ -556,3 +559,35 @@ class MSTPlusPlus(torch.nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (b, 3, H, W) in [0, 1] -> (b, 31, H, W), the reference's signature."""
         return self.forward_nhwc(x)[..., :DIM].permute(0, 3, 1, 2)
+
+
+def hbm_bytes_per_px(stage: int = 3) -> float:
+    """Algorithmic HBM bytes of ONE float16 forward pass per full-resolution pixel at the CURRENT fusion level: for every
+    launch of `MSTPlusPlus.forward_nhwc` on the GPU, the tensors it must read plus the tensors it must write (weights and
+    halo re-reads excluded), summed over the U-shaped stages.  This is the denominator of bench.py's `roofline.hbm` for the
+    MST++ route; it changes when kernels are fused, so it lives next to them.  A C-channel float16 tensor costs
+    2C bytes per pixel of ITS resolution: 1 (C = 32), 1/4 (C = 64), 1/16 (C = 128) of the full-resolution pixel count."""
+
+    def msab(c: int) -> float:
+        t = 2.0 * c  # one activation tensor
+        b = 2 * t                      # qkv + Gram: read x, write v (q, k never leave the matrix cores)
+        if _AVX._tail:
+            b += 3 * t                 # attention tail in one pass: read v, read x, write x1
+        else:
+            b += (3 * t if _AVX._posemb else 5 * t)  # pos_emb (one pass: v, x -> pe; else two depthwise passes)
+            b += 3 * t                 # projection GEMM: read v, read + write the accumulator
+        if _AVX._ffn and c in _AVX.FFN_FUSED_C:
+            b += 2 * t                 # whole FeedForward in one kernel: read x1, write x2 (the 4C hidden tile lives in LDS)
+        else:
+            b += t + 4 * t             # LayerNorm -> 1x1 -> GELU: read x, write the 4C hidden tensor
+            b += (4 * t + 2 * t) if (c in (32, 64) and _AVX._ffn2) else (4 * t + 4 * t + 4 * t + 2 * t)  # dw3x3 -> GELU -> 1x1 -> + x
+        return b
+
+    per_stage = 2 * msab(32) + 2 * msab(64) / 4 + msab(128) / 16
+    t32, t64, t128 = 64.0, 128.0 / 4, 256.0 / 16
+    convs = (2 * t32) + (3 * t32)                # embedding; mapping + x
+    convs += (t32 + t64) + (t64 + t128)          # two strided 4x4 convs
+    convs += (t128 + t64) + (2 * t64 + t64)      # transposed conv 128 -> 64, fusion 1x1 over [up | skip]
+    convs += (t64 + t32) + (2 * t32 + t32)       # transposed conv 64 -> 32, fusion 1x1
+    head = (3 + 12) + (12 + t32) + (3 * t32)     # uint8 -> float32 NCHW; conv_in 3 -> 31; conv_out + x
+    return stage * (per_stage + convs) + head

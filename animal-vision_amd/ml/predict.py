@@ -117,3 +117,44 @@ class MSTPlusPlusPredictor:
         op32.run_device(None, DeviceBuffer(ctx, out.data_ptr(), out.numel(), owned=False), 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=0,
                         hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
         return out.cpu().numpy()
+
+
+class MstHoneybeeStreamOp:
+    """The north-star route (uint8 frame -> MST++ cube -> honeybee tail -> uint8 frame) as a frame-loop operator
+    (pipeline.FramePipeline's protocol: slot_buffers(k) lends a slot's device frames, run_device(...) enqueues one frame on
+    the slot's HIP stream).  torch's kernels and libavx's ride the SAME stream: the slot's stream is made torch's current
+    stream for the duration of the call, and the cube goes from the network to csrc/uv.hip by data_ptr (no copy, no sync)."""
+
+    def __init__(self, predictor: "MSTPlusPlusPredictor", bee_op, H: int, W: int, depth: int = 3):
+        torch = predictor.torch
+        if predictor.device.type != "cuda":
+            raise RuntimeError("MST++ -> libavx hand-off needs the GPU (no CPU path)")
+        from ..runtime import DeviceBuffer
+
+        self.pred, self.H, self.W = predictor, H, W
+        self.ctx = bee_op._ctx()
+        self._t_in = [torch.empty((H, W, 3), dtype=torch.uint8, device=predictor.device) for _ in range(depth)]
+        self._t_out = [torch.empty((H, W, 3), dtype=torch.uint8, device=predictor.device) for _ in range(depth)]
+        self._bufs = [(DeviceBuffer(self.ctx, a.data_ptr(), a.numel(), owned=False), DeviceBuffer(self.ctx, b.data_ptr(), b.numel(), owned=False))
+                      for a, b in zip(self._t_in, self._t_out)]
+        self._by_in = {bi.ptr: k for k, (bi, _) in enumerate(self._bufs)}
+        self._op32 = None
+        self._bee = bee_op
+        self._streams = {}
+
+    def slot_buffers(self, k: int):
+        return self._bufs[k]
+
+    def run_device(self, d_in, d_out, n_frames: int, H: int, W: int, stream=None):
+        assert n_frames == 1 and (H, W) == (self.H, self.W)
+        torch = self.pred.torch
+        k = self._by_in[d_in.ptr]
+        ext = self._streams.get(stream)
+        if ext is None:
+            ext = self._streams.setdefault(stream, torch.cuda.ExternalStream(stream, device=self.pred.device))
+        with torch.cuda.stream(ext):
+            cube = self.pred.predict_device_nhwc(self._t_in[k])
+            if self._op32 is None:
+                self._op32 = self._bee.padded_clone(cube.shape[-1])
+            self._op32.run_device(None, d_out, 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=0, hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
+            cube.record_stream(ext)

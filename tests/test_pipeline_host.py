@@ -89,3 +89,33 @@ def test_two_rank_gloo_statistics(tmp_path):
     assert r["frames"] == 25 and r["pixels"] == 25 * 1920 * 1080 and r["ranks"] == 2
     assert r["seconds"] == 2.0  # max over ranks
     assert r["mine"] == list(range(0, 25, 2))
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a torchrun environment: the launcher itself starts two rank processes (it touches no
+    GPU), they rendezvous at 127.0.0.1 and rank 0's JSON line says n_gpus = 2.  --dry-run keeps the ranks off the GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "7"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["dry_run"] is True and r["steps"] == 7
+    # under a torchrun-style environment the process is a rank, not a launcher
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True, timeout=300, env=env1)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_ranks_fail_loudly_without_a_gpu():
+    """On a box without GPUs the ranks of `bench.py --gpus 2` must fail (no CPU fallback, no silent single-rank run) and the
+    launcher must pass the failure on."""
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("this box has a GPU: the real run is the driver's")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "rank exit codes" in out.stderr
