@@ -1,0 +1,52 @@
+// csrc/mst_common.h -- shared by the MST++ matrix-core kernels (mst_mfma.hip, mst_fused.hip).
+#pragma once
+#include <hip/hip_fp16.h>
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// GELU (exact-erf form, nn.GELU() of MST_Plus_Plus.py:48-50) for a float16 result, as x * sigmoid(x * P(x^2)):
+// Phi(x) = sigmoid(logit Phi(x)) holds exactly and logit Phi is odd and smooth, so a degree-4 polynomial P in x^2 (a weighted
+// minimax fit over |x| <= 9, the weight being the sensitivity x^2 Phi (1 - Phi) of the result to P) gives |error| <= 3.5e-6
+// absolute over all finite float16 inputs in float32 evaluation -- 1/35 of half a float16 ulp at 0.25.  Cost per element: 6
+// multiply/FMA-class operations, one v_exp_f32 and one v_rcp_f32 (the Abramowitz-Stegun 7.1.28 form it replaces: 13 + a
+// v_rcp_f32 + sign and magnitude fix-ups; these kernels are bound by exactly this arithmetic).  The coefficients carry the
+// factor -log2(e) so that the hardware's base-2 exponential applies directly; saturation is by IEEE arithmetic
+// (exp2(-inf) = 0 -> x; exp2(+inf) = inf -> rcp = 0 -> -0), no branches, no clamps.
+__device__ __forceinline__ float gelu_fast(float x) {
+    constexpr float C0 = -0x1.26a96cp+1f, C1 = -0x1.af022ep-4f, C2 = 0x1.79c67ep-12f, C3 = 0x1.7218f2p-14f, C4 = -0x1.b16328p-19f;
+    const float u = x * x;
+    float p = __builtin_fmaf(u, C4, C3);
+    p = __builtin_fmaf(p, u, C2);
+    p = __builtin_fmaf(p, u, C1);
+    p = __builtin_fmaf(p, u, C0);
+    const float e = __builtin_amdgcn_exp2f(x * p);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// The same on a pair with packed float32 arithmetic: a wave64 vector instruction holds its SIMD for 4 cycles whether it is
+// v_mul_f32 or v_pk_mul_f32 (measured: SQ_ACTIVE_INST_VALU ~ SQ_INSTS_VALU in quad-cycles), so the packed forms halve the cost
+// of everything but the two transcendentals per element.
+__device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
+    constexpr float C0 = -0x1.26a96cp+1f, C1 = -0x1.af022ep-4f, C2 = 0x1.79c67ep-12f, C3 = 0x1.7218f2p-14f, C4 = -0x1.b16328p-19f;
+    auto c2 = [](float v) { return float2_t{v, v}; };
+    const float2_t u = x * x;
+    float2_t p = __builtin_elementwise_fma(u, c2(C4), c2(C3));
+    p = __builtin_elementwise_fma(p, u, c2(C2));
+    p = __builtin_elementwise_fma(p, u, c2(C1));
+    p = __builtin_elementwise_fma(p, u, c2(C0));
+    const float2_t t = x * p;
+    const float2_t d = float2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + c2(1.0f);
+    return x * float2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
+// acc += a.f16[half] * b.f16[half] in float32 (v_fma_mix_f32: both float16 operands are converted inside the FMA; the
+// compiler only folds the conversions when float32 denormals are flushed, which these translation units do not ask for)
+__device__ __forceinline__ void fma_mix_lo(float& acc, unsigned a, unsigned b) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fma_mix_hi(float& acc, unsigned a, unsigned b) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+}

@@ -1,0 +1,261 @@
+// csrc/mst_fused.hip -- MSAB block kernels fused end to end (reference: ml/MST_plus_plus/predict_code/architecture/
+// MST_Plus_Plus.py): the activations of a block make ONE HBM round trip per half instead of one per operator.
+//
+//   avx_mst_ffn_fused   PreNorm + FeedForward + residual (:57-65, :141-158, :184):
+//                       LayerNorm -> 1x1 conv (C -> 4C) -> GELU -> depthwise 3x3 -> GELU -> 1x1 conv (4C -> C) -> + x
+//                       in one kernel.  The 4C-channel hidden tensor -- 512 of the block's 1,216 B/px at C = 32 -- never
+//                       reaches memory: a workgroup owns a 16 x 16 pixel tile and keeps the hidden map of its 18 x 18 halo
+//                       region in LDS (the 1-pixel halo is recomputed: 27 % more first-GEMM + GELU work, no HBM traffic).
+//
+// Schedule (512 threads = 8 waves, one workgroup per CU, persistent over tiles; v_mfma_f32_32x32x16_f16):
+//   phase 0  LayerNorm of the 324 halo pixels (lane pair = one pixel, float32 statistics over the 31 real channels of each
+//            32-wide group), normalised rows to LDS as float16.  The raw rows were fetched into registers BEFORE the
+//            previous tile's phase 2, so their HBM latency is off the critical path.
+//   phase 1  first GEMM + GELU: wave w owns hidden-channel tile w % 4 (its W1 fragments stay in registers) and walks the
+//            pixel groups w / 4, w / 4 + 2, ...; "channels x pixels" results (a lane ends up with 16 contiguous hidden
+//            channels of one pixel: two 16-byte LDS stores); pixels outside the image store zeros (the depthwise conv's
+//            zero padding applies to THIS map).
+//   phase 2  depthwise 3x3 + GELU + second GEMM + residual: wave w owns output rows 2w, 2w + 1 (32 pixels).  Per K-step a
+//            lane (pixel p, half h) convolves hidden channels 8 (2 s + h) ... + 7 of its pixel from nine 16-byte LDS reads
+//            (taps as float16 pairs, float32 accumulation: v_fma_mix_f32) -- and those 8 values ARE its B-operand fragment
+//            of the second GEMM's MFMA (k = 8 h + j), so the GELU'd map never touches LDS either.
+// Hidden channels are processed in passes of 128 (C = 32: one pass; C = 64: two, the second GEMM accumulating across them).
+// Rounding points follow the float16 autocast pipeline of predict_torch.py:109 (GEMM / conv results rounded to float16
+// before the next operator; LayerNorm statistics and all accumulations in float32).
+#include <hip/hip_fp16.h>
+
+#include "avx_internal.h"
+#include "mst_common.h"
+
+namespace {
+
+constexpr int kFT = 512;              // 8 waves
+constexpr int TS = 16;                // output tile side
+constexpr int HS = TS + 2;            // halo tile side
+constexpr int NHALO = HS * HS;        // 324
+constexpr int NGRP = (NHALO + 31) / 32;  // 11 pixel groups of 32
+constexpr int HPASS = 128;            // hidden channels per pass
+constexpr int HPITCH = HPASS * 2 + 16;  // bytes per pixel of the hidden tile: 68 dwords -> 16-byte reads of 16 consecutive pixels are conflict-free
+constexpr int RPITCH = 5120;            // bytes per halo ROW (18 * 272 = 4896 padded to a multiple of 256): a wave's two output rows then hit disjoint banks
+
+__device__ __forceinline__ float16_t mfma16(half8_t a, half8_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+struct Tile { int x0, y0; long b; };
+
+template <int C>
+__global__ __launch_bounds__(kFT, 2) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, const uint4* __restrict__ w1pack /*[4C/32][C/16][64]*/, const __half* __restrict__ taps /*[9][4C]*/,
+                                                          const uint4* __restrict__ w2pack /*[C/32][4C/16][64]*/, __half* __restrict__ out /*[B][H][W][C], != x*/, int B,
+                                                          int H, int W) {
+    constexpr int HID = 4 * C, NPASS = HID / HPASS, KS1 = C / 16, KS2 = HPASS / 16, NT = C / 32, YPITCH = C * 2 + 16, LNV = C / 16;
+    static_assert(C == 32 || C == 64, "31- or 62-channel blocks (stored 32 / 64 wide)");
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* yt = smem;                                       // [NGRP * 32][YPITCH]  LayerNorm'd rows, float16
+    unsigned char* ht = yt + (size_t)NGRP * 32 * YPITCH;             // [HS rows][RPITCH]: [HS px][HPITCH]  hidden map of the halo region, float16
+    __half* tapl = reinterpret_cast<__half*>(ht + (size_t)HS * RPITCH);  // [9][HID]
+    float* gl = reinterpret_cast<float*>(tapl + 9 * HID);            // [C] gamma, [C] beta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 9 * HID; i += kFT) tapl[i] = taps[i];
+    for (int i = tid; i < C; i += kFT) { gl[i] = gamma[i]; gl[C + i] = beta[i]; }
+    const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
+    const long total = (long)B * ty * tx;
+    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };
+    const float cnt = (float)(NT * 31);
+
+    // ---- phase 0, split: fetch the raw rows of this wave's halo pixel groups (wave w: groups w and w + 8) ----
+    uint4 raw[2][LNV];
+    auto fetch = [&](const Tile& t) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int g = wave + 8 * gi;
+            if (g >= NGRP) break;
+            const int q = 32 * g + p, qq = q < NHALO ? q : NHALO - 1;
+            int yy = t.y0 - 1 + qq / HS, xx = t.x0 - 1 + qq % HS;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const uint4* src = reinterpret_cast<const uint4*>(x + ((t.b * H + yy) * (size_t)W + xx) * C + h * (C / 2));
+#pragma unroll
+            for (int v = 0; v < LNV; ++v) raw[gi][v] = src[v];
+        }
+    };
+    auto layernorm = [&]() {  // lane (p, h) holds channels [h * C/2, (h + 1) * C/2) of halo pixel 32 g + p
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int g = wave + 8 * gi;
+            if (g >= NGRP) break;
+            float f[8 * LNV];
+#pragma unroll
+            for (int v = 0; v < LNV; ++v) {
+                const half8_t h8 = __builtin_bit_cast(half8_t, raw[gi][v]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[8 * v + j] = (float)h8[j];
+            }
+            auto is_pad = [&](int i) { return ((h * (C / 2) + i) & 31) == 31; };
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8 * LNV; ++i) s1 += is_pad(i) ? 0.f : f[i];
+            const float mean = (s1 + __shfl_xor(s1, 32)) / cnt;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8 * LNV; ++i) {
+                const float d = is_pad(i) ? 0.f : f[i] - mean;
+                s2 = __builtin_fmaf(d, d, s2);
+            }
+            const float rstd = rsqrtf((s2 + __shfl_xor(s2, 32)) / cnt + eps);
+            unsigned char* dst = yt + (size_t)(32 * g + p) * YPITCH + h * C;  // h * (C/2) channels * 2 bytes
+#pragma unroll
+            for (int v = 0; v < LNV; ++v) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * v + j, c = h * (C / 2) + i;
+                    o[j] = is_pad(i) ? (_Float16)0.f : (_Float16)((f[i] - mean) * rstd * gl[c] + gl[C + c]);
+                }
+                *reinterpret_cast<uint4*>(dst + 16 * v) = __builtin_bit_cast(uint4, o);
+            }
+        }
+    };
+
+    half8_t w2f[NT * KS2];  // the second GEMM's A fragments of one pass: resident for the whole launch when there is one pass
+    auto load_w2 = [&](int pass) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) w2f[n * KS2 + s] = __builtin_bit_cast(half8_t, w2pack[((size_t)n * (HID / 16) + pass * KS2 + s) * 64 + lane]);
+    };
+    if constexpr (NPASS == 1) load_w2(0);
+    long tile = blockIdx.x;
+    if (tile >= total) return;
+    Tile t = tile_of(tile);
+    fetch(t);
+    __syncthreads();  // tables are in LDS
+    layernorm();
+    for (;;) {
+        const long next = tile + gridDim.x;
+        float16_t D[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D[n][v] = 0.f;
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            __syncthreads();  // yt complete (pass 0) / ht no longer read by the previous pass's phase 2
+            // ---- phase 1: hidden = GELU(W1 y) for hidden channels [128 pass + 32 ct, + 32), pixel groups wave / 4, + 2, ... ----
+            {
+                const int ct = wave & 3;
+                half8_t w1f[KS1];
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) w1f[s] = __builtin_bit_cast(half8_t, w1pack[((size_t)(pass * 4 + ct) * KS1 + s) * 64 + lane]);
+#pragma unroll 1
+                for (int g = wave >> 2; g < NGRP; g += 2) {
+                    const int q = 32 * g + p;
+                    float16_t d;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) d[v] = 0.f;
+                    const unsigned char* ysrc = yt + (size_t)q * YPITCH + 16 * h;
+#pragma unroll
+                    for (int s = 0; s < KS1; ++s) d = mfma16(w1f[s], __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(ysrc + 32 * s)), d);
+                    if (q < NHALO) {
+                        const int yy = t.y0 - 1 + q / HS, xx = t.x0 - 1 + q % HS;
+                        const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                        half8_t o0, o1;
+#pragma unroll
+                        for (int v = 0; v < 16; v += 2) {
+                            const float2_t gv = gelu_fast2(float2_t{(float)(_Float16)d[v], (float)(_Float16)d[v + 1]});
+                            const _Float16 a = inside ? (_Float16)gv.x : (_Float16)0.f, b2 = inside ? (_Float16)gv.y : (_Float16)0.f;
+                            if (v < 8) { o0[v] = a; o0[v + 1] = b2; } else { o1[v - 8] = a; o1[v - 7] = b2; }
+                        }
+                        unsigned char* dst = ht + (size_t)(q / HS) * RPITCH + (size_t)(q % HS) * HPITCH + (32 * ct + 16 * h) * 2;
+                        reinterpret_cast<uint4*>(dst)[0] = __builtin_bit_cast(uint4, o0);
+                        reinterpret_cast<uint4*>(dst)[1] = __builtin_bit_cast(uint4, o1);
+                    }
+                }
+            }
+            __syncthreads();  // ht complete
+            if (pass == NPASS - 1 && next < total) fetch(tile_of(next));  // next tile's raw rows: in flight during phase 2
+            if constexpr (NPASS > 1) load_w2(pass);
+            // ---- phase 2: depthwise 3x3 + GELU + W2, this wave's 32 output pixels (rows 2 wave, 2 wave + 1) ----
+            {
+                const int r = 2 * wave + (p >> 4), c = p & 15;
+                const unsigned char* hbase = ht + (size_t)r * RPITCH + (size_t)c * HPITCH + 16 * h;  // top-left tap of this pixel, this lane's channel octet
+                const unsigned char* tbase = reinterpret_cast<const unsigned char*>(tapl) + (size_t)(pass * HPASS + 8 * h) * 2;
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) {
+                    float acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const uint4 hv = *reinterpret_cast<const uint4*>(hbase + (size_t)(tap / 3) * RPITCH + (size_t)(tap % 3) * HPITCH + 32 * s);
+                        const uint4 wv = *reinterpret_cast<const uint4*>(tbase + (size_t)tap * HID * 2 + 32 * s);
+                        fma_mix_lo(acc[0], hv.x, wv.x); fma_mix_hi(acc[1], hv.x, wv.x);
+                        fma_mix_lo(acc[2], hv.y, wv.y); fma_mix_hi(acc[3], hv.y, wv.y);
+                        fma_mix_lo(acc[4], hv.z, wv.z); fma_mix_hi(acc[5], hv.z, wv.z);
+                        fma_mix_lo(acc[6], hv.w, wv.w); fma_mix_hi(acc[7], hv.w, wv.w);
+                    }
+                    half8_t bf;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const float2_t gv = gelu_fast2(float2_t{(float)(_Float16)acc[j], (float)(_Float16)acc[j + 1]});
+                        bf[j] = (_Float16)gv.x;
+                        bf[j + 1] = (_Float16)gv.y;
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        D[n] = mfma16(w2f[n * KS2 + s], bf, D[n]);
+                }
+            }
+        }
+        // ---- epilogue: + x (the block's residual, :184), float16, 32 contiguous bytes per lane and output tile ----
+        {
+            const int yo = t.y0 + 2 * wave + (p >> 4), xo = t.x0 + (p & 15);
+            if (yo < H && xo < W) {
+                const size_t off = ((t.b * H + yo) * (size_t)W + xo) * C + 16 * h;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const half8_t r0 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(x + off + 32 * n)[0]);
+                    const half8_t r1 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(x + off + 32 * n)[1]);
+                    half8_t o0, o1;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)(D[n][v] + (float)r0[v]); o1[v] = (_Float16)(D[n][8 + v] + (float)r1[v]); }
+                    reinterpret_cast<uint4*>(out + off + 32 * n)[0] = __builtin_bit_cast(uint4, o0);
+                    reinterpret_cast<uint4*>(out + off + 32 * n)[1] = __builtin_bit_cast(uint4, o1);
+                }
+            }
+        }
+        if (next >= total) break;
+        tile = next;
+        t = tile_of(tile);
+        layernorm();  // yt is free: every wave is past the last pass's first barrier, after which nobody reads it
+    }
+}
+
+}  // namespace
+
+extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
+                                 const void* w2pack, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && gamma && beta && w1pack && taps_9xhid && w2pack && out && B > 0 && H > 0 && W > 0, "avx_mst_ffn_fused: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_ffn_fused: C=%d (32 or 64: 31-channel groups stored 32 wide)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)w1pack | (uintptr_t)w2pack | (uintptr_t)out | (uintptr_t)taps_9xhid)) & 15u) == 0,
+                "avx_mst_ffn_fused: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, x != out, "avx_mst_ffn_fused: neighbouring tiles read each other's halo: the output cannot be the input");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    const long cap = ctx->num_cus;  // one 8-wave workgroup per CU (the hidden tile fills most of the LDS)
+    const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * RPITCH + (size_t)9 * 4 * C * 2 + sizeof(float) * 2 * C;
+    if (C == 32) {
+        auto k = k_mst_ffn_fused<32>;
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack,
+                           (const __half*)taps_9xhid, (const uint4*)w2pack, (__half*)out, B, H, W);
+    } else {
+        auto k = k_mst_ffn_fused<64>;
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack,
+                           (const __half*)taps_9xhid, (const uint4*)w2pack, (__half*)out, B, H, W);
+    }
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}

@@ -24,53 +24,13 @@
 #include <hip/hip_fp16.h>
 
 #include "avx_internal.h"
+#include "mst_common.h"
 
 namespace {
-
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef float float16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kT = 256;  // 4 waves, each marching over its own 32-pixel tiles
 
 __device__ __forceinline__ float16_t mfma(half4_t a, half4_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0); }
-
-__device__ __forceinline__ float gelu_erf_h(float x) {  // exact-erf GELU for a float16 result (same form as csrc/mst.hip)
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
-}
-
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-// Exact-erf GELU on a pair, for a float16 result: erf by Abramowitz-Stegun 7.1.28, 1 - (1 + a1 z + ... + a6 z^6)^-16
-// (|error| <= 3e-7, far below half a float16 ulp of the output): packed multiplies / FMAs and ONE transcendental (v_rcp, 1 ulp: `__frcp_rn` expands to a 10-instruction correctly-rounded division)
-// per element -- 7.1.26 (csrc/mst.hip) needs a v_rcp and a v_exp, and quarter-rate transcendentals are what bound this kernel.
-__device__ __forceinline__ float2_t gelu_erf_h2(float2_t x) {
-    // coefficients a_i / sqrt(2)^i: the polynomial is evaluated in |x| directly
-    constexpr double kS = 0.70710678118654752440;
-    constexpr float A1 = (float)(0.0705230784 * kS), A2 = (float)(0.0422820123 * kS * kS), A3 = (float)(0.0092705272 * kS * kS * kS),
-                    A4 = (float)(0.0001520143 * kS * kS * kS * kS), A5 = (float)(0.0002765672 * kS * kS * kS * kS * kS),
-                    A6 = (float)(0.0000430638 * kS * kS * kS * kS * kS * kS);
-    auto c2 = [](float v) { return float2_t{v, v}; };
-    const float2_t ax = __builtin_elementwise_abs(x);
-    float2_t pz = __builtin_elementwise_fma(ax, c2(A6), c2(A5));
-    pz = __builtin_elementwise_fma(pz, ax, c2(A4));
-    pz = __builtin_elementwise_fma(pz, ax, c2(A3));
-    pz = __builtin_elementwise_fma(pz, ax, c2(A2));
-    pz = __builtin_elementwise_fma(pz, ax, c2(A1));
-    pz = __builtin_elementwise_fma(pz, ax, c2(1.0f));
-    pz = pz * pz; pz = pz * pz; pz = pz * pz; pz = pz * pz;  // ^16 (overflows to +inf for |x| > ~17: 1/inf = 0, erf = 1)
-    const float2_t r = float2_t{__builtin_amdgcn_rcpf(pz.x), __builtin_amdgcn_rcpf(pz.y)};
-    const float2_t e = c2(1.0f) - r;                                            // erf(|x| / sqrt 2)
-    const float2_t se = float2_t{__builtin_copysignf(e.x, x.x), __builtin_copysignf(e.y, x.y)};  // erf is odd: one v_bfi each
-    // 0.5 x (1 + erf) as fma(hx, se, hx).  (Not "x < 0 ? r : 2 - r": more accurate in the far negative tail, but it feeds
-    // subnormal products to the packed multiplies, which measured 10-27 % slower across the kernels that use this function.)
-    const float2_t hx = x * 0.5f;
-    return __builtin_elementwise_fma(hx, se, hx);
-}
 
 // lane (p = lane & 31, h = lane >> 5) loads channels [h*C/2, (h+1)*C/2) of pixel tile*32 + p; rows past n read as zero
 template <int C>
@@ -262,7 +222,7 @@ __global__ __launch_bounds__(kT) void k_mst_ffn1(const __half* __restrict__ x, c
             _Float16 o[16];
 #pragma unroll
             for (int v = 0; v < 16; v += 2) {
-                const float2_t g = gelu_erf_h2(float2_t{(float)(_Float16)d[v], (float)(_Float16)d[v + 1]});
+                const float2_t g = gelu_fast2(float2_t{(float)(_Float16)d[v], (float)(_Float16)d[v + 1]});
                 o[v] = (_Float16)g.x;
                 o[v + 1] = (_Float16)g.y;
             }
@@ -366,7 +326,7 @@ __global__ __launch_bounds__(kT, MINW) void k_mst_ffn2(const __half* __restrict_
             half8_t o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float2_t g = gelu_erf_h2(acc[r][q]);
+                const float2_t g = gelu_fast2(acc[r][q]);
                 o[2 * q] = (_Float16)g.x;
                 o[2 * q + 1] = (_Float16)g.y;
             }
@@ -665,7 +625,7 @@ __global__ __launch_bounds__(kT) void k_mst_posemb(const __half* __restrict__ v,
                 half8_t o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float2_t g = gelu_erf_h2(acc[o2][q]);
+                    const float2_t g = gelu_fast2(acc[o2][q]);
                     o[2 * q] = inside ? (_Float16)g.x : (_Float16)0.f;
                     o[2 * q + 1] = inside ? (_Float16)g.y : (_Float16)0.f;
                 }

@@ -84,6 +84,29 @@ def pack_fragments(w_kn: torch.Tensor, transposed: bool) -> torch.Tensor:
 _FRAG_INDEX: Dict[tuple, torch.Tensor] = {}
 
 
+def pack_fragments16(w_kn: torch.Tensor) -> torch.Tensor:
+    """(K x N) float16 weight of `y = x @ w` as the A operand of v_mfma_f32_32x32x16_f16 ("channels x pixels" results,
+    csrc/mst_fused.hip): [N/32][K/16][64 lanes][8]; lane (m = lane % 32, h = lane // 32), element j of step s carries input
+    channel 16 s + 8 h + j (natural K order) of output channel 32 t + perm(m), perm(m) = 16 ((m % 8) // 4) + 4 (m // 8) + m % 4 --
+    the row permutation that leaves a result lane with 16 CONTIGUOUS output channels (D row = (reg & 3) + 8 (reg >> 2) + 4 h)."""
+    K, N = w_kn.shape
+    assert K % 16 == 0 and N % 32 == 0
+    dev = w_kn.device
+    key = (K, N, "k16", str(dev))
+    idx = _FRAG_INDEX.get(key)
+    if idx is None:
+        lane = torch.arange(64, device=dev)
+        m, h = lane % 32, lane // 32
+        col = 16 * ((m % 8) // 4) + 4 * (m // 8) + m % 4
+        s = torch.arange(K // 16, device=dev)
+        j = torch.arange(8, device=dev)
+        k = (16 * s[:, None, None] + 8 * h[None, :, None] + j[None, None, :])[None]                    # (1, K/16, 64, 8)
+        n = 32 * torch.arange(N // 32, device=dev)[:, None, None, None] + col[None, None, :, None]      # (N/32, 1, 64, 1)
+        idx = (k * N + n).contiguous()
+        _FRAG_INDEX[key] = idx
+    return torch.take(w_kn.contiguous(), idx)
+
+
 class _AvxOps:
     """Binds the hand-written gfx950 kernels of csrc/mst.hip for CUDA tensors (data_ptr hand-off on torch's
     current stream).  AVX_MST_TORCH_ONLY=1 keeps every op in torch (A/B and debugging)."""
@@ -96,8 +119,8 @@ class _AvxOps:
         self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
         self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
         self._tail = False  # the attention tail (pos_emb + v @ M + bias + x) in one pass -- set when the kernel exists
-        self._ffn = False   # the whole FeedForward in one kernel, hidden tile in LDS -- set when the kernel exists
-        self.FFN_FUSED_C = ()
+        self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
+        self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64").split(",") if v)
         self._ctx = {}
 
     def ctx(self, device: torch.device):
@@ -229,6 +252,19 @@ class _AvxOps:
         ctx._check(lib.avx_mst_rowgemm_add(ctx._h, a.data_ptr(), wpack.data_ptr(), a2.data_ptr() if a2 is not None else None,
                                            wpack2.data_ptr() if a2 is not None else None, add.data_ptr() if add is not None else None, out.data_ptr(), rows, c,
                                            torch.cuda.current_stream(a.device).cuda_stream))
+        return out
+
+    def ffn_fused(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1p: torch.Tensor, taps: torch.Tensor, w2p: torch.Tensor,
+                  eps: float = 1e-5) -> torch.Tensor:
+        """x + FeedForward(LayerNorm(x)) on (b, h, w, c) float16 in ONE kernel, the 4c hidden tile in LDS (csrc/mst_fused.hip)."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_ffn_fused(ctx._h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w1p.data_ptr(), taps.data_ptr(), w2p.data_ptr(),
+                                         out.data_ptr(), b, h, w, c, torch.cuda.current_stream(x.device).cuda_stream))
         return out
 
     def dw_gemm_add(self, hidden: torch.Tensor, w_c9: torch.Tensor, w2pack: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -477,6 +513,12 @@ class MSTPlusPlus(torch.nn.Module):
         g32 = self._prep(p + ".g32", lambda: self._w(p + ".norm.weight", (0,)).float().contiguous())
         b32 = self._prep(p + ".b32", lambda: self._w(p + ".norm.bias", (0,)).float().contiguous())
         w2 = self._prep(p + ".w2", lambda: self._w(p + ".fn.net.4.weight", (0, 1)).reshape(c, 4 * c).t().contiguous())
+        if _AVX.fused_ok(x) and _AVX._ffn and c in _AVX.FFN_FUSED_C:  # the whole FeedForward + residual in one kernel: the hidden tensor stays in LDS
+            w1q = self._prep(p + ".w1.frag16", lambda: pack_fragments16(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous()))
+            w2q = self._prep(p + ".w2.frag16", lambda: pack_fragments16(w2))
+            key = p + ".fn.net.2.weight"
+            t9 = self._prep(key + ".t9h", lambda: self._w(key, (0,)).reshape(4 * c, 9).t().contiguous())  # [9][4c], tap-major, the model's own float16 values
+            return _AVX.ffn_fused(x, g32, b32, w1q, t9, w2q)
         if _AVX.fused_ok(x):  # LayerNorm -> 1x1 conv -> GELU on the matrix cores, the hidden tensor is written once
             w1p = self._prep(p + ".w1.frag", lambda: pack_fragments(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous(), True))
             y = _AVX.ln_gemm_gelu(x.reshape(b * h * w, c), g32, b32, w1p).reshape(b, h, w, 4 * c)

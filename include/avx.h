@@ -344,6 +344,15 @@ int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const 
 int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, const void* w2pack, const void* residual, void* out, int B, int H,
                         int W, int C, void* stream);
 
+/* The whole second half of an MSAB block in one kernel (MST_Plus_Plus.py:57-65 PreNorm, :141-158 FeedForward, :184 residual):
+ * out = x + W2 gelu(dw3x3(gelu(W1 layernorm(x)))) on a (B, H, W, C) float16 tensor, C = 32 or 64 (31-channel groups stored
+ * 32 wide; LayerNorm statistics over the real channels).  The 4C-channel hidden map lives in LDS only (16 x 16 pixel tiles,
+ * 1-pixel halo recomputed).  w1pack / w2pack: the 1x1 convs' weights as v_mfma_f32_32x32x16_f16 A fragments
+ * ([N/32][K/16][64][8] float16, ml/mst_plus_plus.py::pack_fragments16); taps_9xhid: the depthwise 3x3 weights, float16,
+ * tap-major [9][4C].  out must not alias x (tiles read their neighbours' rows). */
+int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
+                      const void* w2pack, void* out, int B, int H, int W, int C, void* stream);
+
 /* out = [add +] a @ W [+ a2 @ W2] for (rows x C) float16 tensors and C x C weights in fragment order (out may alias
  * add; a2 / W2 and add may be NULL): MS_MSA's `proj(attn @ v)` collapsed to one matrix per frame (:132-135)
  * accumulated onto pos_emb(v) + x, and the decoder's 1x1 fusion conv over [up | skip] (:257) without the concatenation. */

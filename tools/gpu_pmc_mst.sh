@@ -14,6 +14,8 @@ SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ
 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS
 TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TA_BUSY TA_FLAT_READ_WAVEFRONTS TA_FLAT_WRITE_WAVEFRONTS
+FETCH_SIZE
+WRITE_SIZE
 GROUPS
 python - <<'PY' | tee gpurun_out/pmc_mst/summary.txt
 import csv, glob, collections, re
@@ -34,6 +36,28 @@ for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive
         for r in rs:
             if int(r["Dispatch_Id"]) in keep:
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# HBM traffic of ONE frame of the route: FETCH_SIZE / WRITE_SIZE (KB) summed over every dispatch between the last two k_map_encode
+# launches (one per frame); bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: gfx950 tallies 128-B reads as 64 B)
+tot = {}
+for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
+    if not rows:
+        continue
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    marks = [i for i, r in enumerate(rows) if "k_map_encode" in r["Kernel_Name"]]
+    if len(marks) >= 2:
+        win = rows[marks[-2] + 1: marks[-1] + 1]
+        tot[rows[0]["Counter_Name"]] = sum(float(r["Counter_Value"]) for r in win)
+        per = collections.defaultdict(float)
+        for r in win:
+            mm = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
+            per[mm.group(1) if mm else r["Kernel_Name"][:40]] += float(r["Counter_Value"])
+        print("== per-frame", rows[0]["Counter_Name"], "KB by kernel:", ", ".join(f"{k}={v:.0f}" for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]))
+if len(tot) == 2:
+    import json
+    b = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024
+    print(f"== HBM traffic per frame: FETCH_SIZE {tot['FETCH_SIZE']:.0f} KB (x2), WRITE_SIZE {tot['WRITE_SIZE']:.0f} KB -> {b/1e9:.3f} GB")
+    json.dump({"FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"], "hbm_bytes_per_frame": b}, open("gpurun_out/pmc_mst/traffic.json", "w"))
 for k in sorted(agg):
     d = agg[k]
     m = {c: sum(v) / len(v) for c, v in d.items()}
