@@ -230,6 +230,174 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_ffn_fused(const __half* __restri
     }
 }
 
+
+// ---- attention tail: pos_emb(v) + v @ M + bias + x in one pass (MS_MSA :104-106, :132-137; MSAB :183) ------------------------
+// After the Gram pass the first half of a block is out = proj(attn @ v) + pos_emb(v) + x with proj(attn @ v) == v @ M + bias
+// (M = blockdiag(attn^T) W_proj^T, one C x C matrix per frame, avx_mst_attn_pack16) and pos_emb = depthwise 3x3 -> GELU ->
+// depthwise 3x3.  One workgroup per 16 x 16 pixel tile: v on the 20 x 20 halo region goes to LDS once (zeros outside the image),
+// the GELU'd first conv on 18 x 18 stays in LDS, the second conv, the C x C product (MFMA, B operand = the v row already in LDS),
+// bias and residual meet in registers: v and x are read once, out is written once (192 B/px at C = 32 where the pos_emb kernel
+// plus the projection GEMM moved 384).  A lane (pixel p, half h) owns channels [h C/2, (h + 1) C/2) of its pixel in BOTH the
+// second conv and the MFMA result (the K order and the output-row order of the M fragments are chosen for that).
+constexpr int VS = TS + 4, MS = TS + 2;
+
+template <int C, int MINW>
+__global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __restrict__ v /*[B][H][W][C]*/, const __half* __restrict__ x /*[B][H][W][C]*/,
+                                                             const uint4* __restrict__ mpack /*[C/32][C/16][64]*/, const __half* __restrict__ taps1 /*[9][C]*/,
+                                                             const __half* __restrict__ taps2 /*[9][C]*/, const float* __restrict__ bias /*[C]*/,
+                                                             __half* __restrict__ out, int B, int H, int W) {
+    constexpr int NO = C / 8, NS = C / 16, NT = C / 32, PP = C * 2 + 16;
+    constexpr int VRP = (VS * PP + 255) / 256 * 256, MRP = (MS * PP + 255) / 256 * 256;
+    constexpr int NFILL = (VS * VS * NO + kFT - 1) / kFT;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* vt = smem;                                  // [VS][VRP]: [VS px][PP]  v on the halo region
+    unsigned char* mt = vt + (size_t)VS * VRP;                 // [MS][MRP]: [MS px][PP]  gelu(dw1(v))
+    __half* t2l = reinterpret_cast<__half*>(mt + (size_t)MS * MRP);  // [9][C] second conv's taps
+    __half* t1l = t2l + 9 * C;                                 // [9][C] first conv's taps
+    float* bl = reinterpret_cast<float*>(t1l + 9 * C);         // [C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 9 * C; i += kFT) { t2l[i] = taps2[i]; t1l[i] = taps1[i]; }
+    for (int i = tid; i < C; i += kFT) bl[i] = bias ? bias[i] : 0.f;
+    const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
+    const long total = (long)B * ty * tx;
+    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };
+    // phase B role: a wave keeps ONE channel octet (its first-conv taps are wave-uniform LDS reads: broadcasts) and walks pixels of the 18 x 18 map
+    const int oct = wave % NO, part = wave / NO, nparts = 8 / NO, per = (MS * MS + nparts - 1) / nparts;
+    half8_t mf[NT * NS];
+#pragma unroll
+    for (int i = 0; i < NT * NS; ++i) mf[i] = __builtin_bit_cast(half8_t, mpack[(size_t)i * 64 + lane]);
+
+    uint4 pre[NFILL];
+    auto fetch = [&](const Tile& t) {
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            const int it = tid + k * kFT, q = it / NO, part16 = it % NO;
+            const int yy = t.y0 - 2 + q / VS, xx = t.x0 - 2 + q % VS;
+            const bool ok = it < VS * VS * NO && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            uint4 r = *reinterpret_cast<const uint4*>(v + ((t.b * H + yc) * (size_t)W + xc) * C + 8 * part16);
+            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
+            pre[k] = r;
+        }
+    };
+    auto fill = [&]() {
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            const int it = tid + k * kFT, q = it / NO, part16 = it % NO;
+            if (it < VS * VS * NO) *reinterpret_cast<uint4*>(vt + (size_t)(q / VS) * VRP + (size_t)(q % VS) * PP + 16 * part16) = pre[k];
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile >= total) return;
+    Tile t = tile_of(tile);
+    fetch(t);
+    for (;;) {
+        fill();
+        __syncthreads();  // vt complete (and the tables, first time round)
+        // ---- phase B: mid = gelu(dw1(v)) on the 18 x 18 region, zero outside the image ----
+#pragma unroll 1
+        for (int q = part * per + lane; q < (part + 1) * per && q < MS * MS; q += 64) {
+            const int my = q / MS, mx = q % MS;
+            const unsigned char* src = vt + (size_t)my * VRP + (size_t)mx * PP + 16 * oct;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const uint4 hv = *reinterpret_cast<const uint4*>(src + (size_t)(tap / 3) * VRP + (size_t)(tap % 3) * PP);
+                const uint4 wv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(t1l) + (size_t)tap * C * 2 + 16 * oct);
+                fma_mix_lo(acc[0], hv.x, wv.x); fma_mix_hi(acc[1], hv.x, wv.x);
+                fma_mix_lo(acc[2], hv.y, wv.y); fma_mix_hi(acc[3], hv.y, wv.y);
+                fma_mix_lo(acc[4], hv.z, wv.z); fma_mix_hi(acc[5], hv.z, wv.z);
+                fma_mix_lo(acc[6], hv.w, wv.w); fma_mix_hi(acc[7], hv.w, wv.w);
+            }
+            const int yy = t.y0 - 1 + my, xx = t.x0 - 1 + mx;
+            const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float2_t gv = gelu_fast2(float2_t{(float)(_Float16)acc[j], (float)(_Float16)acc[j + 1]});
+                o[j] = inside ? (_Float16)gv.x : (_Float16)0.f;
+                o[j + 1] = inside ? (_Float16)gv.y : (_Float16)0.f;
+            }
+            *reinterpret_cast<uint4*>(mt + (size_t)my * MRP + (size_t)mx * PP + 16 * oct) = __builtin_bit_cast(uint4, o);
+        }
+        __syncthreads();  // mt complete
+        const long next = tile + gridDim.x;
+        if (next < total) fetch(tile_of(next));  // in flight during phase C
+        // ---- phase C: dw2(mid) + v @ M + bias + x for this wave's 32 pixels (rows 2 wave, 2 wave + 1) ----
+        {
+            const int r = 2 * wave + (p >> 4), c = p & 15;
+            const int yo = t.y0 + r, xo = t.x0 + c;
+            const bool live = yo < H && xo < W;
+            const size_t off = ((t.b * H + (live ? yo : 0)) * (size_t)W + (live ? xo : 0)) * C + h * (C / 2);
+            uint4 xr[2 * NT];
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) xr[i] = reinterpret_cast<const uint4*>(x + off)[i];
+            float16_t D[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int vv = 0; vv < 16; ++vv) D[n][vv] = 0.f;
+            float pe[NS][8];
+            const unsigned char* msrc = mt + (size_t)r * MRP + (size_t)c * PP + (size_t)h * C;        // octet h * NS + s: + 16 s bytes
+            const unsigned char* vsrc = vt + (size_t)(r + 2) * VRP + (size_t)(c + 2) * PP + (size_t)h * C;
+            const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(t2l) + (size_t)h * C;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pe[s][j] = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const uint4 hv = *reinterpret_cast<const uint4*>(msrc + (size_t)(tap / 3) * MRP + (size_t)(tap % 3) * PP + 16 * s);
+                    const uint4 wv = *reinterpret_cast<const uint4*>(tsrc + (size_t)tap * C * 2 + 16 * s);
+                    fma_mix_lo(pe[s][0], hv.x, wv.x); fma_mix_hi(pe[s][1], hv.x, wv.x);
+                    fma_mix_lo(pe[s][2], hv.y, wv.y); fma_mix_hi(pe[s][3], hv.y, wv.y);
+                    fma_mix_lo(pe[s][4], hv.z, wv.z); fma_mix_hi(pe[s][5], hv.z, wv.z);
+                    fma_mix_lo(pe[s][6], hv.w, wv.w); fma_mix_hi(pe[s][7], hv.w, wv.w);
+                }
+                const half8_t bv = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(vsrc + 16 * s));
+#pragma unroll
+                for (int n = 0; n < NT; ++n) D[n] = mfma16(mf[n * NS + s], bv, D[n]);
+            }
+            if (live) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const half8_t r0 = __builtin_bit_cast(half8_t, xr[2 * n]), r1 = __builtin_bit_cast(half8_t, xr[2 * n + 1]);
+                    const float* bb = bl + h * (C / 2) + 16 * n;
+                    half8_t o0, o1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        o0[j] = (_Float16)(D[n][j] + (float)(_Float16)pe[2 * n][j] + bb[j] + (float)r0[j]);
+                        o1[j] = (_Float16)(D[n][8 + j] + (float)(_Float16)pe[2 * n + 1][j] + bb[8 + j] + (float)r1[j]);
+                    }
+                    reinterpret_cast<uint4*>(out + off)[2 * n] = __builtin_bit_cast(uint4, o0);
+                    reinterpret_cast<uint4*>(out + off)[2 * n + 1] = __builtin_bit_cast(uint4, o1);
+                }
+            }
+        }
+        if (next >= total) break;
+        tile = next;
+        t = tile_of(tile);
+        __syncthreads();  // everyone is done reading vt / mt
+    }
+}
+
+template <int C, int MINW>
+int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpack, const void* taps1, const void* taps2, const float* bias, void* out, int B,
+                     int H, int W, hipStream_t s) {
+    constexpr int PP = C * 2 + 16, VRP = (VS * PP + 255) / 256 * 256, MRP = (MS * PP + 255) / 256 * 256;
+    const size_t lds = (size_t)VS * VRP + (size_t)MS * MRP + (size_t)2 * 9 * C * 2 + sizeof(float) * C;
+    const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    const long cap = (long)ctx->num_cus * (MINW / 2);
+    auto k = k_mst_attn_tail<C, MINW>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), lds, s, (const __half*)v, (const __half*)x, (const uint4*)mpack,
+                       (const __half*)taps1, (const __half*)taps2, bias, (__half*)out, B, H, W);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 }  // namespace
 
 extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
@@ -258,4 +426,18 @@ extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma
     }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
+}
+
+extern "C" int avx_mst_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpack16, const void* taps1_9xc, const void* taps2_9xc, const float* bias,
+                                 void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, v && x && mpack16 && taps1_9xc && taps2_9xc && out && B > 0 && H > 0 && W > 0, "avx_mst_attn_tail: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_attn_tail: C=%d (32 or 64)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)v | (uintptr_t)x | (uintptr_t)mpack16 | (uintptr_t)out | (uintptr_t)taps1_9xc | (uintptr_t)taps2_9xc)) & 15u) == 0,
+                "avx_mst_attn_tail: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, v != out, "avx_mst_attn_tail: tiles read their neighbours' rows of v: the output cannot be v (it may be x)");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    if (C == 32) return launch_attn_tail<32, 4>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s);
+    return launch_attn_tail<64, 2>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s);
 }

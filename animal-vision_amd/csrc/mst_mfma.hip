@@ -456,7 +456,7 @@ int launch_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const voi
 // k_mst_rowgemm_add ("channels x pixels" fragments, see the header).
 __global__ __launch_bounds__(256) void k_mst_attn_pack(const float* __restrict__ gram /*[HD][32][32]*/, const float* __restrict__ nq, const float* __restrict__ nk,
                                                        const float* __restrict__ rescale /*[HD]*/, const float* __restrict__ wpt /*[C][C] = W_proj^T*/, int C,
-                                                       __half* __restrict__ mpack /*[C/32][C/8][64][4]*/) {
+                                                       __half* __restrict__ mpack /*[C/32][C/8][64][4] | layout 1: [C/32][C/16][64][8]*/, int layout) {
     __shared__ float A[4][32][33];
     const int HD = C / 32, KS = C / 8, tid = threadIdx.x;
     for (int idx = tid; idx < HD * 1024; idx += 256) {
@@ -477,10 +477,19 @@ __global__ __launch_bounds__(256) void k_mst_attn_pack(const float* __restrict__
     __syncthreads();
     {  // every block repeats the (tiny) softmax above and then packs its own 256 entries of M
         const int idx = blockIdx.x * 256 + tid;
-        const int e = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % KS, t = (idx >> 8) / KS;
-        const int hh = lane >> 5, m = lane & 31;
-        const int k = hh * (C / 2) + 4 * s + e;                                    // input channel (row of M)
-        const int n = 32 * t + 16 * ((m & 7) >> 2) + 4 * (m >> 3) + (m & 3);       // output channel (column of M)
+        int k, n;
+        if (layout == 0) {  // v_mfma_f32_32x32x8_f16 fragments of k_mst_rowgemm_add
+            const int e = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % KS, t = (idx >> 8) / KS;
+            const int hh = lane >> 5, m = lane & 31;
+            k = hh * (C / 2) + 4 * s + e;                                    // input channel (row of M)
+            n = 32 * t + 16 * ((m & 7) >> 2) + 4 * (m >> 3) + (m & 3);       // output channel (column of M)
+        } else {  // v_mfma_f32_32x32x16_f16 fragments of k_mst_attn_tail (csrc/mst_fused.hip): lane half hh carries input channels
+                  // [hh C/2, (hh + 1) C/2) in steps of 8, and a result lane (pixel, hd) ends up with output channels hd C/2 + 16 t + v
+            const int e = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) % (C / 16), t = (idx >> 9) / (C / 16);
+            const int hh = lane >> 5, m = lane & 31;
+            k = hh * (C / 2) + 8 * s + e;
+            n = ((m >> 2) & 1) * (C / 2) + 16 * t + (m & 3) + 4 * (m >> 3);
+        }
         const int hd = k >> 5, j = k & 31;
         float acc = 0.f;
         for (int i = 0; i < 32; ++i) acc = __builtin_fmaf(A[hd][i][j], wpt[(size_t)(hd * 32 + i) * C + n], acc);
@@ -837,16 +846,26 @@ int avx_mst_rowgemm_add(avx_ctx* ctx, const void* a, const void* wpack, const vo
     return launch_rowgemm_add<128>(ctx, a, wpack, a2, wpack2, add, out, rows, s);
 }
 
-int avx_mst_attn_pack(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
-                      void* stream) {
+static int attn_pack_impl(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
+                          int layout, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, gram && nq && nk && rescale && wproj_t && mpack, "avx_mst_attn_pack: NULL pointer");
     AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_attn_pack: C=%d (32, 64 or 128)", C);
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
-    hipLaunchKernelGGL(k_mst_attn_pack, dim3((unsigned)(C * C / 256)), dim3(256), 0, s, gram, nq, nk, rescale, wproj_t, C, (__half*)mpack);
+    hipLaunchKernelGGL(k_mst_attn_pack, dim3((unsigned)(C * C / 256)), dim3(256), 0, s, gram, nq, nk, rescale, wproj_t, C, (__half*)mpack, layout);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
+}
+
+int avx_mst_attn_pack(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
+                      void* stream) {
+    return attn_pack_impl(ctx, gram, nq, nk, rescale, wproj_t, C, mpack, 0, stream);
+}
+
+int avx_mst_attn_pack16(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
+                        void* stream) {
+    return attn_pack_impl(ctx, gram, nq, nk, rescale, wproj_t, C, mpack, 1, stream);
 }
 
 int avx_mst_conv3x3_add(avx_ctx* ctx, const void* x, const void* wpack, const void* add, void* out, int B, int H, int W, int C, void* stream) {

@@ -118,7 +118,7 @@ class _AvxOps:
         self._mfma = os.environ.get("AVX_MST_NO_MFMA", "") == ""  # A/B: the fused matrix-core kernels of csrc/mst_mfma.hip
         self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
         self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
-        self._tail = False  # the attention tail (pos_emb + v @ M + bias + x) in one pass -- set when the kernel exists
+        self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64").split(",") if v)
         self._ctx = {}
@@ -238,6 +238,30 @@ class _AvxOps:
         out = torch.empty((c // 32, c // 8, 64, 4), dtype=torch.float16, device=gram.device)
         ctx._check(lib.avx_mst_attn_pack(ctx._h, gram.data_ptr(), nq.data_ptr(), nk.data_ptr(), rescale.data_ptr(), wproj_t.data_ptr(), c, out.data_ptr(),
                                          torch.cuda.current_stream(gram.device).cuda_stream))
+        return out
+
+    def attn_pack16(self, gram: torch.Tensor, nq: torch.Tensor, nk: torch.Tensor, rescale: torch.Tensor, wproj_t: torch.Tensor) -> torch.Tensor:
+        """attn_pack in the K = 16 fragment order avx_mst_attn_tail takes (csrc/mst_mfma.hip::k_mst_attn_pack, layout 1)."""
+        from .._lib import lib
+
+        c = nq.numel()
+        ctx = self.ctx(gram.device)
+        out = torch.empty((c // 32, c // 16, 64, 8), dtype=torch.float16, device=gram.device)
+        ctx._check(lib.avx_mst_attn_pack16(ctx._h, gram.data_ptr(), nq.data_ptr(), nk.data_ptr(), rescale.data_ptr(), wproj_t.data_ptr(), c, out.data_ptr(),
+                                           torch.cuda.current_stream(gram.device).cuda_stream))
+        return out
+
+    def attn_tail(self, v: torch.Tensor, x: torch.Tensor, mpack16: torch.Tensor, taps1: torch.Tensor, taps2: torch.Tensor, bias: torch.Tensor,
+                  out: torch.Tensor = None) -> torch.Tensor:
+        """pos_emb(v) + v @ M + bias + x on one (h, w, c) float16 frame in one pass (csrc/mst_fused.hip::k_mst_attn_tail)."""
+        from .._lib import lib
+
+        h, w, c = v.shape
+        assert v.is_contiguous() and x.is_contiguous() and x.shape == v.shape
+        out = torch.empty_like(v) if out is None else out
+        ctx = self.ctx(v.device)
+        ctx._check(lib.avx_mst_attn_tail(ctx._h, v.data_ptr(), x.data_ptr(), mpack16.data_ptr(), taps1.data_ptr(), taps2.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                         1, h, w, c, torch.cuda.current_stream(v.device).cuda_stream))
         return out
 
     def rowgemm_add(self, a: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor = None, a2: torch.Tensor = None, wpack2: torch.Tensor = None) -> torch.Tensor:
@@ -457,6 +481,15 @@ class MSTPlusPlus(torch.nn.Module):
             wpt = self._prep(p + ".proj.t32", lambda: self._w(p + ".proj.weight", (0, 1)).t().float().contiguous())
             bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
             vi = v.reshape(b, h, w, c)
+            if _AVX._tail and c in (32, 64):  # v @ M + bias + pos_emb(v) + x in ONE pass over v and x (the block's `msa(x) + x`, :183)
+                k1, k2 = p + ".pos_emb.0.weight", p + ".pos_emb.2.weight"
+                t1 = self._prep(k1 + ".t9h", lambda: self._w(k1, (0,)).reshape(c, 9).t().contiguous())  # [9][c] float16, tap-major
+                t2 = self._prep(k2 + ".t9h", lambda: self._w(k2, (0,)).reshape(c, 9).t().contiguous())
+                xc = x.contiguous()
+                out = torch.empty_like(xc)
+                for i in range(b):
+                    _AVX.attn_tail(vi[i], xc[i], _AVX.attn_pack16(gram[i], nq[i], nk[i], resc, wpt), t1, t2, bias32, out[i])
+                return out
             # the block's `msa(x) + x` (:183): pos_emb's second conv adds x and the bias, the projection GEMM accumulates onto it in place
             if _AVX._posemb:
                 k1, k2 = p + ".pos_emb.0.weight", p + ".pos_emb.2.weight"
@@ -613,7 +646,7 @@ def hbm_bytes_per_px(stage: int = 3) -> float:
     def msab(c: int) -> float:
         t = 2.0 * c  # one activation tensor
         b = 2 * t                      # qkv + Gram: read x, write v (q, k never leave the matrix cores)
-        if _AVX._tail:
+        if _AVX._tail and c in (32, 64):
             b += 3 * t                 # attention tail in one pass: read v, read x, write x1
         else:
             b += (3 * t if _AVX._posemb else 5 * t)  # pos_emb (one pass: v, x -> pe; else two depthwise passes)

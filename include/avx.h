@@ -344,6 +344,16 @@ int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const 
 int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, const void* w2pack, const void* residual, void* out, int B, int H,
                         int W, int C, void* stream);
 
+/* The tail of the first half of an MSAB block in one pass (MS_MSA :104-106, :132-137; MSAB :183):
+ * out = v @ M + bias + dw3x3(gelu(dw3x3(v))) + x on (B, H, W, C) float16 tensors, C = 32 or 64, with M the per-frame C x C matrix
+ * of avx_mst_attn_pack16 (so B frames must share M: the host calls it per frame).  v on the tile's 20 x 20 halo region and the
+ * GELU'd first conv live in LDS; v and x are read once, out written once.  taps*_9xc: depthwise weights, float16, tap-major
+ * [9][C].  out may be x, not v. */
+int avx_mst_attn_pack16(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
+                        void* stream);
+int avx_mst_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpack16, const void* taps1_9xc, const void* taps2_9xc, const float* bias,
+                      void* out, int B, int H, int W, int C, void* stream);
+
 /* The whole second half of an MSAB block in one kernel (MST_Plus_Plus.py:57-65 PreNorm, :141-158 FeedForward, :184 residual):
  * out = x + W2 gelu(dw3x3(gelu(W1 layernorm(x)))) on a (B, H, W, C) float16 tensor, C = 32 or 64 (31-channel groups stored
  * 32 wide; LayerNorm statistics over the real channels).  The 4C-channel hidden map lives in LDS only (16 x 16 pixel tiles,
