@@ -20,9 +20,13 @@
 //            (taps as float16 pairs, float32 accumulation: v_fma_mix_f32) -- and those 8 values ARE its B-operand fragment
 //            of the second GEMM's MFMA (k = 8 h + j), so the GELU'd map never touches LDS either.
 // Hidden channels are processed in passes of 128 (C = 32: one pass; C = 64: two, the second GEMM accumulating across them).
-// Rounding points follow the float16 autocast pipeline of predict_torch.py:109 (GEMM / conv results rounded to float16
-// before the next operator; LayerNorm statistics and all accumulations in float32).
+// Rounding: what reaches LDS or memory is float16 (as in the autocast pipeline of predict_torch.py:109); LayerNorm statistics and
+// all accumulations are float32, and a GELU takes its argument straight from the float32 accumulator (the reference rounds the
+// conv / GEMM result to float16 first: one rounding less here, and two conversions per element less in kernels that are bound
+// by exactly this arithmetic; the forward pass is held to the reference's float32 output, tests/test_mstpp.py).
 #include <hip/hip_fp16.h>
+
+#include <cstdlib>
 
 #include "avx_internal.h"
 #include "mst_common.h"
@@ -34,20 +38,22 @@ constexpr int TS = 16;                // output tile side
 constexpr int HS = TS + 2;            // halo tile side
 constexpr int NHALO = HS * HS;        // 324
 constexpr int NGRP = (NHALO + 31) / 32;  // 11 pixel groups of 32
-constexpr int HPASS = 128;            // hidden channels per pass
-constexpr int HPITCH = HPASS * 2 + 16;  // bytes per pixel of the hidden tile: 68 dwords -> 16-byte reads of 16 consecutive pixels are conflict-free
-constexpr int RPITCH = 5120;            // bytes per halo ROW (18 * 272 = 4896 padded to a multiple of 256): a wave's two output rows then hit disjoint banks
+// Hidden channels are processed in passes of HPASS (128 or 64).  Per pixel the hidden tile takes HPASS * 2 + 16 bytes (68 or 36
+// dwords: 16-byte reads of 16 consecutive pixels are conflict-free) and a halo ROW is padded to a multiple of 256 bytes, so the
+// two output rows of a wave hit disjoint banks.  HPASS = 64 halves the tile: two workgroups fit a CU (4 waves per SIMD), and
+// one's barriers and LDS waits are covered by the other's arithmetic.
 
 __device__ __forceinline__ float16_t mfma16(half8_t a, half8_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 struct Tile { int x0, y0; long b; };
 
-template <int C>
-__global__ __launch_bounds__(kFT, 2) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
+template <int C, int HPASS, int MINW>
+__global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, const uint4* __restrict__ w1pack /*[4C/32][C/16][64]*/, const __half* __restrict__ taps /*[9][4C]*/,
                                                           const uint4* __restrict__ w2pack /*[C/32][4C/16][64]*/, __half* __restrict__ out /*[B][H][W][C], != x*/, int B,
                                                           int H, int W) {
     constexpr int HID = 4 * C, NPASS = HID / HPASS, KS1 = C / 16, KS2 = HPASS / 16, NT = C / 32, YPITCH = C * 2 + 16, LNV = C / 16;
+    constexpr int HPITCH = HPASS * 2 + 16, RPITCH = (HS * HPITCH + 255) / 256 * 256, NCT = HPASS / 32;  // channel tiles of 32 per pass
     static_assert(C == 32 || C == 64, "31- or 62-channel blocks (stored 32 / 64 wide)");
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* yt = smem;                                       // [NGRP * 32][YPITCH]  LayerNorm'd rows, float16
@@ -140,14 +146,14 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_ffn_fused(const __half* __restri
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; ++pass) {
             __syncthreads();  // yt complete (pass 0) / ht no longer read by the previous pass's phase 2
-            // ---- phase 1: hidden = GELU(W1 y) for hidden channels [128 pass + 32 ct, + 32), pixel groups wave / 4, + 2, ... ----
+            // ---- phase 1: hidden = GELU(W1 y) for hidden channels [HPASS pass + 32 ct, + 32), ct = wave % NCT, pixel groups wave / NCT, + 8 / NCT, ... ----
             {
-                const int ct = wave & 3;
+                const int ct = wave % NCT;
                 half8_t w1f[KS1];
 #pragma unroll
-                for (int s = 0; s < KS1; ++s) w1f[s] = __builtin_bit_cast(half8_t, w1pack[((size_t)(pass * 4 + ct) * KS1 + s) * 64 + lane]);
+                for (int s = 0; s < KS1; ++s) w1f[s] = __builtin_bit_cast(half8_t, w1pack[((size_t)(pass * NCT + ct) * KS1 + s) * 64 + lane]);
 #pragma unroll 1
-                for (int g = wave >> 2; g < NGRP; g += 2) {
+                for (int g = wave / NCT; g < NGRP; g += 8 / NCT) {
                     const int q = 32 * g + p;
                     float16_t d;
 #pragma unroll
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_ffn_fused(const __half* __restri
                         half8_t o0, o1;
 #pragma unroll
                         for (int v = 0; v < 16; v += 2) {
-                            const float2_t gv = gelu_fast2(float2_t{(float)(_Float16)d[v], (float)(_Float16)d[v + 1]});
+                            const float2_t gv = gelu_fast2(float2_t{d[v], d[v + 1]});
                             const _Float16 a = inside ? (_Float16)gv.x : (_Float16)0.f, b2 = inside ? (_Float16)gv.y : (_Float16)0.f;
                             if (v < 8) { o0[v] = a; o0[v + 1] = b2; } else { o1[v - 8] = a; o1[v - 7] = b2; }
                         }
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_ffn_fused(const __half* __restri
                     half8_t bf;
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
-                        const float2_t gv = gelu_fast2(float2_t{(float)(_Float16)acc[j], (float)(_Float16)acc[j + 1]});
+                        const float2_t gv = gelu_fast2(float2_t{acc[j], acc[j + 1]});
                         bf[j] = (_Float16)gv.x;
                         bf[j + 1] = (_Float16)gv.y;
                     }
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
             half8_t o;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                const float2_t gv = gelu_fast2(float2_t{(float)(_Float16)acc[j], (float)(_Float16)acc[j + 1]});
+                const float2_t gv = gelu_fast2(float2_t{acc[j], acc[j + 1]});
                 o[j] = inside ? (_Float16)gv.x : (_Float16)0.f;
                 o[j + 1] = inside ? (_Float16)gv.y : (_Float16)0.f;
             }
@@ -411,19 +417,21 @@ extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
-    const long cap = ctx->num_cus;  // one 8-wave workgroup per CU (the hidden tile fills most of the LDS)
-    const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * RPITCH + (size_t)9 * 4 * C * 2 + sizeof(float) * 2 * C;
-    if (C == 32) {
-        auto k = k_mst_ffn_fused<32>;
-        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack,
-                           (const __half*)taps_9xhid, (const uint4*)w2pack, (__half*)out, B, H, W);
-    } else {
-        auto k = k_mst_ffn_fused<64>;
-        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack,
-                           (const __half*)taps_9xhid, (const uint4*)w2pack, (__half*)out, B, H, W);
+    const char* hp = getenv("AVX_MST_FFN_HPASS");  // A/B: 128 = one 8-wave workgroup per CU, 64 (C = 32 only) = two
+    const bool small = C == 32 && !(hp && atoi(hp) == 128);
+    const int hpass = small ? 64 : 128, hpitch = hpass * 2 + 16, rpitch = (HS * hpitch + 255) / 256 * 256;
+    const long cap = (long)ctx->num_cus * (small ? 2 : 1);
+    const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * rpitch + (size_t)9 * 4 * C * 2 + sizeof(float) * 2 * C;
+    const dim3 grid((unsigned)(total < cap ? total : cap));
+#define AVX_FFN(CV, HP, MW)                                                                                                                      \
+    {                                                                                                                                            \
+        auto k = k_mst_ffn_fused<CV, HP, MW>;                                                                                                    \
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
+        hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid,      \
+                           (const uint4*)w2pack, (__half*)out, B, H, W);                                                                         \
     }
+    if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2) else AVX_FFN(64, 128, 2)
+#undef AVX_FFN
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -7,7 +7,7 @@ timeout -k 10 400 python -m pytest tests/test_mstpp.py -m gpu -q -x -rP -p no:ca
 grep -E "passed|failed|part [0-9]|attention matrices|Error|error" gpurun_out/mst_tests.log | tail -30
 for wl in honeybee_mst_1080p honeybee_mst_4k; do
   for var in ${AB:-AVX_MST_NO_FFN_FUSED}; do
-    env $var=1 timeout -k 10 300 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > gpurun_out/ab_${wl}_off_${var}.json 2>/dev/null || echo "bench failed ($wl, $var off)"
+    env $var=${ABVAL:-1} timeout -k 10 300 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > gpurun_out/ab_${wl}_off_${var}.json 2>/dev/null || echo "bench failed ($wl, $var off)"
   done
   timeout -k 10 300 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > gpurun_out/ab_${wl}_on.json 2>/dev/null || echo "bench failed ($wl on)"
   python - <<PY
