@@ -54,7 +54,8 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                                                           int H, int W) {
     constexpr int HID = 4 * C, NPASS = HID / HPASS, KS1 = C / 16, KS2 = HPASS / 16, NT = C / 32, YPITCH = C * 2 + 16, LNV = C / 16;
     constexpr int HPITCH = HPASS * 2 + 16, RPITCH = (HS * HPITCH + 255) / 256 * 256, NCT = HPASS / 32;  // channel tiles of 32 per pass
-    static_assert(C == 32 || C == 64, "31- or 62-channel blocks (stored 32 / 64 wide)");
+    static_assert(C == 32 || C == 64 || C == 128, "31-, 62- or 124-channel blocks (stored 32 / 64 / 128 wide)");
+    constexpr bool PREFETCH = C <= 64;  // the next tile's raw rows wait in registers during phase 2 (C = 128: 64 registers that the accumulators need)
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* yt = smem;                                       // [NGRP * 32][YPITCH]  LayerNorm'd rows, float16
     unsigned char* ht = yt + (size_t)NGRP * 32 * YPITCH;             // [HS rows][RPITCH]: [HS px][HPITCH]  hidden map of the halo region, float16
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 }
             }
             __syncthreads();  // ht complete
-            if (pass == NPASS - 1 && next < total) fetch(tile_of(next));  // next tile's raw rows: in flight during phase 2
+            if (PREFETCH && pass == NPASS - 1 && next < total) fetch(tile_of(next));  // next tile's raw rows: in flight during phase 2
             if constexpr (NPASS > 1) load_w2(pass);
             // ---- phase 2: depthwise 3x3 + GELU + W2, this wave's 32 output pixels (rows 2 wave, 2 wave + 1) ----
             {
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
         if (next >= total) break;
         tile = next;
         t = tile_of(tile);
+        if (!PREFETCH) fetch(t);
         layernorm();  // yt is free: every wave is past the last pass's first barrier, after which nobody reads it
     }
 }
@@ -410,7 +412,7 @@ extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma
                                  const void* w2pack, void* out, int B, int H, int W, int C, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, x && gamma && beta && w1pack && taps_9xhid && w2pack && out && B > 0 && H > 0 && W > 0, "avx_mst_ffn_fused: NULL pointer or empty tensor");
-    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_ffn_fused: C=%d (32 or 64: 31-channel groups stored 32 wide)", C);
+    AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_ffn_fused: C=%d (32, 64 or 128: 31-channel groups stored 32 wide)", C);
     AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)w1pack | (uintptr_t)w2pack | (uintptr_t)out | (uintptr_t)taps_9xhid)) & 15u) == 0,
                 "avx_mst_ffn_fused: pointers must be 16-byte aligned");
     AVX_REQUIRE(ctx, x != out, "avx_mst_ffn_fused: neighbouring tiles read each other's halo: the output cannot be the input");
@@ -419,7 +421,7 @@ extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma
     const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
     const char* hp = getenv("AVX_MST_FFN_HPASS");  // A/B: 128 = one 8-wave workgroup per CU, 64 (C = 32 only) = two
     const bool small = C == 32 && !(hp && atoi(hp) == 128);
-    const int hpass = small ? 64 : 128, hpitch = hpass * 2 + 16, rpitch = (HS * hpitch + 255) / 256 * 256;
+    const int hpass = (small || C == 128) ? 64 : 128, hpitch = hpass * 2 + 16, rpitch = (HS * hpitch + 255) / 256 * 256;
     const long cap = (long)ctx->num_cus * (small ? 2 : 1);
     const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * rpitch + (size_t)9 * 4 * C * 2 + sizeof(float) * 2 * C;
     const dim3 grid((unsigned)(total < cap ? total : cap));
@@ -430,7 +432,7 @@ extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma
         hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid,      \
                            (const uint4*)w2pack, (__half*)out, B, H, W);                                                                         \
     }
-    if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2) else AVX_FFN(64, 128, 2)
+    if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2) else if (C == 64) AVX_FFN(64, 128, 2) else AVX_FFN(128, 64, 2)
 #undef AVX_FFN
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;

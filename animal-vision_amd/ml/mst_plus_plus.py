@@ -120,7 +120,7 @@ class _AvxOps:
         self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
         self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
-        self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64").split(",") if v)
+        self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
         self._ctx = {}
 
     def ctx(self, device: torch.device):
