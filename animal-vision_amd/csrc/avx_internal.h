@@ -31,6 +31,7 @@ struct avx_ws {
     struct tab { uint64_t key; void* dev; };
     tab geom_tabs[64] = {};          // immutable resampling tables cached by (kind, component, source size, target size)
     int n_geom_tabs = 0;
+    void* bee_small = nullptr;       // honeybee tail, recompute form (uv.hip): per-frame partials, statistics, histograms, select states, percentiles
     void* d_ew = nullptr;            // per-block partial reductions of elementwise programs (ew.hip)
     size_t ew_cap = 0;
 };

@@ -66,8 +66,12 @@ __device__ __forceinline__ void block_stats_store(const float (&mn)[KMAX], const
 //      receptor curves).  4 pixels (12 bytes = 3 aligned dwords) per thread. --------------------------
 template <int KMAX>
 __global__ __launch_bounds__(kT) void k_rgb_to_planes(const uint8_t* __restrict__ in, size_t n, const float* __restrict__ lut_g,
-                                                      const float* __restrict__ mat /*K x 3 device*/, int K, float* __restrict__ out,
+                                                      const float* __restrict__ mat /*K x 3 device*/, int K, float* __restrict__ out /*NULL: statistics only*/,
                                                       Stat3* partials) {
+    // blockIdx.y = frame of a batch (frames, planes and partials back to back)
+    in += (size_t)blockIdx.y * n * 3;
+    if (out) out += (size_t)blockIdx.y * n * K;
+    partials += (size_t)blockIdx.y * gridDim.x * K;
     __shared__ float lut[256];
     __shared__ float m[KMAX * 3];
     for (int i = threadIdx.x; i < 256; i += kT) lut[i] = lut_g[i];
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(kT) void k_rgb_to_planes(const uint8_t* __restrict_
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; sm[k] = 0.0; }
     const size_t nq = n / 4;
-    const bool aligned = ((uintptr_t)in & 3u) == 0 && ((uintptr_t)out & 15u) == 0 && (n % 4 == 0);
+    const bool aligned = ((uintptr_t)in & 3u) == 0 && ((uintptr_t)out & 15u) == 0 && (n % 4 == 0) && ((n * K) % 4 == 0);
     for (size_t q = (size_t)blockIdx.x * kT + threadIdx.x; q < nq + 1; q += (size_t)gridDim.x * kT) {
         const size_t p0 = q * 4;
         const int cnt = q < nq ? 4 : (int)(n - p0);
@@ -107,9 +111,11 @@ __global__ __launch_bounds__(kT) void k_rgb_to_planes(const uint8_t* __restrict_
                     v[p] = fma_t(c2[p], m[3 * k + 2], fma_t(c1[p], m[3 * k + 1], c0[p] * m[3 * k]));
                     if (p < cnt) { mn[k] = fminf(mn[k], v[p]); mx[k] = fmaxf(mx[k], v[p]); sm[k] += (double)v[p]; }
                 }
-                float* o = out + (size_t)k * n + p0;
-                if (cnt == 4 && aligned) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                else for (int p = 0; p < cnt; ++p) o[p] = v[p];
+                if (out) {
+                    float* o = out + (size_t)k * n + p0;
+                    if (cnt == 4 && aligned) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    else for (int p = 0; p < cnt; ++p) o[p] = v[p];
+                }
             }
         }
     }
@@ -216,9 +222,11 @@ __global__ __launch_bounds__(kT) void k_plane_stats(const float* __restrict__ pl
 // next pass divides by: adapt 0: 1 | 1 white_patch: max(max, eps) | 2 gray_world: max(mean, eps)
 // | 3 safe_norm: (max - min), with stats.x = min subtracted first (uv_helpers.py:47-53).
 __global__ void k_finalize_stats(const Stat3* partials, int nblocks, int K, size_t n, int adapt, float eps, float4* stats) {
-    // one wave per plane; lanes stride over the block partials, fixed-shape shuffle tree (deterministic)
+    // one wave per plane; lanes stride over the block partials, fixed-shape shuffle tree (deterministic); blockIdx.x = frame of a batch
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= K) return;
+    partials += (size_t)blockIdx.x * nblocks * K;
+    stats += (size_t)blockIdx.x * 4;
     float a = 3.4e38f, b = -3.4e38f;
     double c = 0.0;
     for (int i = lane; i < nblocks; i += 64) { const Stat3 s = partials[(size_t)i * K + k]; a = fminf(a, s.mn); b = fmaxf(b, s.mx); c += s.sum; }
@@ -732,6 +740,312 @@ __global__ __launch_bounds__(kT) void k_lobes_cube(const void* __restrict__ in, 
     }
 }
 
+
+// ---- honeybee tail, recompute form ------------------------------------------------------------------------------------
+// The passes above stream K float32 planes through HBM between every two stages (~100 B/px per frame for the default opponent
+// mapping: catches out, blur in / out, radius + L out, three radix-select reads of both, map in).  Everything between the
+// frame and its order statistics is cheap arithmetic on a 3 x 3 neighbourhood, so this form RECOMPUTES it in every pass from the
+// uint8 frame (3 B/px) instead of storing it: one statistics pass (k_rgb_to_planes without an output), three radix-select
+// passes whose "array" is the tile pipeline below, one map + encode pass -- 18 B/px, no plane ever written, and the frames of
+// a batch share each launch (blockIdx.y = frame: five launches per STEP, not thirty per frame).
+// The tile pipeline is the arithmetic of the plane kernels operation for operation (decode table, FMA-chain matrix, rescale,
+// k_plane_blur_t<1>'s row / column passes with BORDER_REFLECT_101), so every pass sees bit-identical values and the result
+// equals the plane route's.  SRC 1 reads raw catches from planes instead (an HSI cube's catches are not cheap to recompute).
+struct BeeArgs {
+    const uint8_t* in; const float* raw; uint8_t* out; float* out_f;
+    int H, W; const float* lut; const float* mat; const float4* stats; int scale_mode; float t0, t1, t2;
+    int mode, n_jobs, pass, shift, bits;
+    SelState* st; uint32_t* hist; uint32_t* ticket; double* pct;          // per frame: kSelMax states, kSelMax x 2048 bins, 1 ticket, 8 doubles
+    unsigned long long rank0; float gamma; int has_next;
+    float eps; float M[9]; const float* enc_thr; const uint8_t* coarse; uint32_t lo_key;
+};
+
+__device__ __forceinline__ void map_rgb(int mode, float U, float B, float G, const double* pct, float eps, const float* M, float (&rgb)[3]) {
+    if (mode == 2) {  // map_opponent, uv_mappers.py:53-64 (see k_map_encode for the dtype notes)
+        const float O1 = G - B, O2 = B - U;
+        const float L = ((U + B) + G) / 3.0f;
+        const float angle = atan2f(O2, O1);
+        const float hue = (angle + 3.14159265358979323846f) / 6.28318530717958647692f;
+        const float radius = __fsqrt_rn(O1 * O1 + O2 * O2);
+        const float sat = clip01f(radius / ((float)pct[0] + eps));
+        const float val = clip01f(L / ((float)pct[1] + eps));
+        const float h6 = hue * 6.0f;
+        const float fi = floorf(h6);
+        const int ii = (int)fi;
+        const double f = (double)h6 - (double)ii;
+        const float p = val * (1.0f - sat);
+        const float q = (float)((double)val * (1.0 - f * (double)sat));
+        const float t = (float)((double)val * (1.0 - (1.0 - f) * (double)sat));
+        const int im = ((ii % 6) + 6) % 6;
+        rgb[0] = im == 0 ? val : im == 1 ? q : im == 2 ? p : im == 3 ? p : im == 4 ? t : val;
+        rgb[1] = im == 0 ? t : im == 1 ? val : im == 2 ? val : im == 3 ? q : im == 4 ? p : p;
+        rgb[2] = im == 0 ? p : im == 1 ? p : im == 2 ? t : im == 3 ? val : im == 4 ? val : q;
+    } else if (mode == 0) {
+        falsecolor(U, B, G, pct, eps, rgb);
+    } else if (mode == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = fma_t(G, M[3 * c + 2], fma_t(B, M[3 * c + 1], U * M[3 * c]));
+    } else {
+        purple_yellow_soft(U, pct[0], 1e-8f, rgb);
+    }
+}
+
+// the last workgroup of a radix pass: pick the bin holding the rank, narrow the prefix, on the last pass resolve x[k], x[k+1] and
+// NumPy's float32 lerp (the logic of k_sel_pass's tail, for one job)
+__device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int bits, unsigned long long rank0, float gamma, int has_next, double* out) {
+    __shared__ unsigned long long csum[kT];
+    __shared__ int first_after[kT / 64];
+    __shared__ int sel_chunk, sel_bin;
+    __shared__ unsigned long long sel_rank;
+    __shared__ uint32_t sel_cnt;
+    const int nb = 1 << bits, t = threadIdx.x, per = nb / kT;
+    const bool last_pass = pass == 2;
+    const uint32_t prefix = pass == 0 ? 0u : st->prefix, mask = pass == 0 ? 0u : st->mask;
+    uint32_t loc[8];
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) loc[i] = i < per ? __hip_atomic_load(&hist[t * per + (i < per ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += loc[i];
+    __syncthreads();
+    csum[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < kT; o <<= 1) {
+        const unsigned long long v = t >= o ? csum[t - o] : 0ull;
+        __syncthreads();
+        csum[t] += v;
+        __syncthreads();
+    }
+    const unsigned long long r = pass == 0 ? rank0 : st->rank;
+    const unsigned long long incl = csum[t], excl = incl - sum;
+    if (t == 0) sel_chunk = kT - 1;
+    __syncthreads();
+    if (excl <= r && r < incl) sel_chunk = t;
+    __syncthreads();
+    if (t == sel_chunk) {
+        unsigned long long cum = excl;
+        int i = 0;
+        for (; i < per; ++i) {
+            if (cum + loc[i] > r) break;
+            cum += loc[i];
+        }
+        if (i == per) i = per - 1;
+        const int b = t * per + i;
+        st->prefix = prefix | ((uint32_t)b << shift);
+        st->mask = mask | ((uint32_t)(nb - 1) << shift);
+        st->rank = r - cum;
+        if (pass == 0) st->next_above = 0xffffffffu;
+        if (last_pass) { st->key_lo = prefix | (uint32_t)b; st->cnt_in_bin = loc[i]; sel_bin = b; sel_rank = r - cum; sel_cnt = loc[i]; }
+    }
+    if (last_pass) {
+        __syncthreads();
+        int f = 0x7fffffff;
+        for (int i = per - 1; i >= 0; --i)
+            if (loc[i] && t * per + i > sel_bin) f = t * per + i;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(f, o); f = v < f ? v : f; }
+        if ((t & 63) == 0) first_after[t >> 6] = f;
+        __syncthreads();
+        if (t == 0) {
+            int m = first_after[0];
+            for (int w = 1; w < kT / 64; ++w) m = first_after[w] < m ? first_after[w] : m;
+            const uint32_t next_above = __hip_atomic_load(&st->next_above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t next_key = m != 0x7fffffff ? (prefix | (uint32_t)m) : next_above;
+            const uint32_t key_lo = prefix | (uint32_t)sel_bin;
+            const float lo = key2f(key_lo);
+            float hi = lo;
+            if (has_next && sel_rank + 1 >= sel_cnt) hi = next_key == 0xffffffffu ? lo : key2f(next_key);
+            const float diff = hi - lo;
+            float res = lo + diff * gamma;
+            if (gamma >= 0.5f) res = hi - diff * (1.0f - gamma);
+            *out = (double)res;
+        }
+    }
+    for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
+    __syncthreads();
+}
+
+// SRC: 0 uint8 frames (decode table + K x 3 matrix), 1 raw catch planes.  R: blur radius 0 | 1.  STAGE: 0 one radix-select pass
+// (NJ order statistics per frame), 1 map + encode.
+template <int SRC, int R, int STAGE, int NJ>
+__global__ __launch_bounds__(kT) void k_bee_tile(const BeeArgs a) {
+    constexpr int TW = 32, TH = 32, AH = TH + 2 * R, AW = TW + 2 * R, AWP = (AW + 3) & ~3;
+    __shared__ __align__(16) float A[3][AH * AWP];
+    __shared__ __align__(16) float Bm[R ? 3 : 1][R ? AH * TW : 1];
+    __shared__ float lut[256];
+    __shared__ uint32_t h[STAGE == 0 ? NJ : 1][STAGE == 0 ? 2048 : 1];
+    __shared__ float thr[STAGE == 1 ? 256 : 1];
+    __shared__ uint8_t coarse[STAGE == 1 ? kCoarseTableBytes : 1];
+    __shared__ uint32_t wmin[kT / 64];
+    __shared__ int is_last;
+    const int t = threadIdx.x, f = blockIdx.y;
+    const size_t n = (size_t)a.H * a.W;
+    if (SRC == 0)
+        for (int i = t; i < 256; i += kT) lut[i] = a.lut[i];
+    if (STAGE == 0)
+        for (int i = t; i < NJ * 2048; i += kT) (&h[0][0])[i] = 0;
+    if (STAGE == 1) {
+        for (int i = t; i < 256; i += kT) thr[i] = a.enc_thr[i];
+        for (int i = t; i < kCoarseTableBytes; i += kT) coarse[i] = a.coarse[i];
+    }
+    float m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = SRC == 0 ? a.mat[i] : 0.f;
+    float4 st[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st[k] = a.scale_mode ? a.stats[(size_t)f * 4 + k] : make_float4(0.f, 0.f, 0.f, 1.f);
+    const uint8_t* in = a.in + (size_t)f * n * 3;
+    const float* raw = a.raw + (size_t)f * n * 3;
+    const double* pct = a.pct + (size_t)f * 8;
+    SelState* sst = a.st + (size_t)f * kSelMax;
+    const bool last_pass = a.pass == 2, find_next = STAGE == 0 && last_pass && a.has_next;
+    uint32_t prefix[NJ], mask[NJ], above[NJ], best[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        prefix[j] = (STAGE == 0 && a.pass != 0) ? sst[j].prefix : 0u;
+        mask[j] = (STAGE == 0 && a.pass != 0) ? sst[j].mask : 0u;
+        above[j] = prefix[j] | ~mask[j];
+        best[j] = 0xffffffffu;
+    }
+    const int nb = 1 << a.bits;
+    auto visit = [&](int j, float v) {
+        const uint32_t k = f2key(v);
+        if ((k & mask[j]) == prefix[j]) atomicAdd(&h[STAGE == 0 ? j : 0][(k >> a.shift) & (nb - 1)], 1u);
+        else if (find_next && k > above[j] && k < best[j]) best[j] = k;
+    };
+    __syncthreads();
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    // catches of a tile and its halo, rescaled (reflect-101 at the frame border).  A thread's loads for the NEXT tile are issued
+    // before the current tile's passes and consumed after them: with one pixel per trip and no prefetch the loop waited out a memory
+    // round trip per pixel (6.6 us per tile).
+    constexpr int NIT = (AH * AW + kT - 1) / kT;
+    float src[NIT][3];
+    auto fetch = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x, x0 = tx * TW, y0 = ty * TH;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = t + it * kT, ii = i < AH * AW ? i : AH * AW - 1;
+            const int ly = ii / AW, lx = ii - ly * AW;
+            const int gy = reflect101(y0 - R + ly, a.H), gx = reflect101(x0 - R + lx, a.W);
+            const size_t px = (size_t)gy * a.W + gx;
+            if (SRC == 0) {
+                const uint8_t* q = in + px * 3;
+                src[it][0] = __uint_as_float((uint32_t)q[0]); src[it][1] = __uint_as_float((uint32_t)q[1]); src[it][2] = __uint_as_float((uint32_t)q[2]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) src[it][k] = raw[(size_t)k * n + px];
+            }
+        }
+    };
+    if ((int)blockIdx.x < tiles_x * tiles_y) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x, x0 = tx * TW, y0 = ty * TH;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = t + it * kT;
+            if (i >= AH * AW) break;
+            const int ly = i / AW, lx = i - ly * AW;
+            float v[3];
+            if (SRC == 0) {
+                const float c0 = lut[__float_as_uint(src[it][0])], c1 = lut[__float_as_uint(src[it][1])], c2 = lut[__float_as_uint(src[it][2])];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[k] = fma_t(c2, m[3 * k + 2], fma_t(c1, m[3 * k + 1], c0 * m[3 * k]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[k] = src[it][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A[k][ly * AWP + lx] = rescale(v[k], a.scale_mode, st[k]);
+        }
+        if (tile + (int)gridDim.x < tiles_x * tiles_y) fetch(tile + gridDim.x);
+        __syncthreads();
+        if (R) {  // row pass of k_plane_blur_t<1>: s = w[x] t0; s = fma(w[x + 1], t1, s); s = fma(w[x + 2], t2, s)
+            for (int i = t; i < 3 * AH * (TW / 4); i += kT) {
+                const int k = i / (AH * (TW / 4)), r2 = i - k * (AH * (TW / 4)), ly = r2 / (TW / 4), g = r2 - ly * (TW / 4);
+                const float* wp = &A[k][ly * AWP + 4 * g];
+                float w[8];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) w[q] = wp[q];
+                float o[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) o[x] = fma_t(w[x + 2], a.t2, fma_t(w[x + 1], a.t1, w[x] * a.t0));
+                *reinterpret_cast<float4*>(&Bm[R ? k : 0][R ? ly * TW + 4 * g : 0]) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            __syncthreads();
+        }
+        {  // column pass (centre tap, then fma(x[+1] + x[-1], t2, s)) and this pass's use of (U, B, G): thread = column x, rows 4 yq .. + 3
+            const int x = t & 31, yq = t >> 5;
+            float w[3][6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int q = 0; q < (R ? 6 : 4); ++q) w[k][q] = R ? Bm[R ? k : 0][(4 * yq + q) * TW + x] : A[k][(4 * yq + q) * AWP + x];
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy) {
+                const int y = 4 * yq + yy;
+                if (y0 + y >= a.H || x0 + x >= a.W) continue;
+                float ubg[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ubg[k] = R ? fma_t(w[k][yy + 2] + w[k][yy], a.t2, w[k][yy + 1] * a.t1) : w[k][yy];
+                const float U = ubg[0], B = ubg[1], G = ubg[2];
+                if (STAGE == 0) {
+                    if (a.mode == 2) {
+                        const float O1 = G - B, O2 = B - U;
+                        visit(0, __fsqrt_rn(O1 * O1 + O2 * O2));
+                        if (NJ > 1) visit(NJ > 1 ? 1 : 0, ((U + B) + G) / 3.0f);
+                    } else {
+                        visit(0, U);
+                        if (NJ > 2) { visit(NJ > 2 ? 1 : 0, B); visit(NJ > 2 ? 2 : 0, G); }
+                    }
+                } else {
+                    float rgb[3];
+                    map_rgb(a.mode, U, B, G, pct, a.eps, a.M, rgb);
+                    const size_t px = (size_t)(y0 + y) * a.W + x0 + x;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (a.out_f) {
+                            const float l = rgb[c] < 0.f ? 0.f : (rgb[c] > 1.f ? 1.f : rgb[c]);
+                            a.out_f[((size_t)f * n + px) * 3 + c] = l <= 0.0031308f ? l * 12.92f : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f;
+                        } else {
+                            a.out[((size_t)f * n + px) * 3 + c] = (uint8_t)quantize_coarse<float, kCoarseNFix>(rgb[c], thr, coarse, a.lo_key);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (STAGE == 1) return;
+    // ---- end of a radix pass: successor candidates, histogram flush, ticket, and the last workgroup of this FRAME picks ----
+    uint32_t* hist = a.hist + (size_t)f * kSelMax * 2048;
+    if (find_next) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            uint32_t b = best[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(b, o); b = v < b ? v : b; }
+            __syncthreads();
+            if ((t & 63) == 0) wmin[t >> 6] = b;
+            __syncthreads();
+            if (t == 0) {
+                for (int w = 1; w < kT / 64; ++w) b = wmin[w] < b ? wmin[w] : b;
+                if (b != 0xffffffffu) atomicMin(&sst[j].next_above, b);
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < NJ; ++j)
+        for (int i = t; i < nb; i += kT)
+            if (h[STAGE == 0 ? j : 0][i]) atomicAdd(&hist[j * 2048 + i], h[STAGE == 0 ? j : 0][i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) is_last = atomicAdd(a.ticket + f, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    for (int j = 0; j < NJ; ++j) sel_pick(hist + j * 2048, sst + j, a.pass, a.shift, a.bits, a.rank0, a.gamma, a.has_next, a.pct + (size_t)f * 8 + j);
+    if (t == 0) a.ticket[f] = 0;
+}
+
 int grid_for(avx_ctx* ctx, size_t items) {
     const size_t want = (items + kT - 1) / kT;
     const size_t cap = (size_t)ctx->num_cus * 8;
@@ -828,6 +1142,95 @@ int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, i
     a.in = in; a.out = out; a.K = K; a.H = H; a.W = W; a.r = ksize / 2; a.stats = nullptr; a.scale_mode = 0;
     for (int i = 0; i < ksize && i < AVX_MAX_KSIZE; ++i) a.taps[i] = ksize == 1 ? 1.0f : (float)taps_host[i];
     return launch_plane_blur(ctx, a, s);
+}
+
+
+// Host side of the recompute form: batches of up to kBeeMaxFrames frames share every launch.
+constexpr int kBeeMaxFrames = 32;
+static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W, const avx_honeybee_desc* d, hipStream_t s) {
+    const size_t n = (size_t)H * W;
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const int g = grid_for(ctx, n);  // blocks per frame of the statistics pass (<= 8 per CU)
+    const size_t part_bytes = (size_t)ctx->num_cus * 8 * 3 * sizeof(Stat3);
+    const size_t per_frame = part_bytes + 4 * sizeof(float4) + (size_t)kSelMax * 2048 * 4 + kSelMax * sizeof(SelState) + 64 + 8 * sizeof(double);
+    if (!ws->bee_small) {
+        AVX_HIP(ctx, hipMalloc(&ws->bee_small, per_frame * kBeeMaxFrames + 256));
+        AVX_HIP(ctx, hipMemsetAsync(ws->bee_small, 0, per_frame * kBeeMaxFrames + 256, s));  // histograms and tickets start at zero; the kernels leave them so
+    }
+    char* p = (char*)ws->bee_small;
+    Stat3* partials = (Stat3*)p; p += part_bytes * kBeeMaxFrames;
+    float4* stats = (float4*)p; p += 4 * sizeof(float4) * kBeeMaxFrames;
+    uint32_t* hist = (uint32_t*)p; p += (size_t)kSelMax * 2048 * 4 * kBeeMaxFrames;
+    SelState* sel = (SelState*)p; p += kSelMax * sizeof(SelState) * kBeeMaxFrames;
+    uint32_t* ticket = (uint32_t*)p; p += 64 * kBeeMaxFrames;
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    double* pct = (double*)p;
+    float* mat = nullptr;
+    int rc = d->source == 0 ? avx_const_upload(ctx, ws, 0, d->rgb_matrix, sizeof(float) * 9, s, (void**)&mat)
+                            : avx_const_upload(ctx, ws, 0, d->weights_host, sizeof(float) * 3 * d->bands, s, (void**)&mat);
+    if (rc) return rc;
+    float* raw = nullptr;
+    if (d->source == 1) {
+        const int fb = n_frames < kBeeMaxFrames ? n_frames : kBeeMaxFrames;
+        if ((rc = avx_ensure_scratch(ctx, ws, sizeof(float) * n * 3 * fb + 256))) return rc;
+        raw = (float*)ws->d_scratch;
+    }
+    const int R = d->blur_ksize / 2, mode = d->mapping;
+    const int nj = mode == 2 ? 2 : (mode == 0 ? 3 : (mode == 3 ? 1 : 0));
+    const double q = mode == 3 ? 98.0 : 95.0;
+    const float vi = (float)(n - 1) * ((float)q / 100.0f);  // NumPy evaluates the virtual index in float32 (run_percentiles)
+    float lo = floorf(vi);
+    if (lo < 0) lo = 0;
+    if (lo > (float)(n - 1)) lo = (float)(n - 1);
+    const long tiles = (long)((W + 31) / 32) * ((H + 31) / 32);
+    for (int f0 = 0; f0 < n_frames; f0 += kBeeMaxFrames) {
+        const int F = n_frames - f0 < kBeeMaxFrames ? n_frames - f0 : kBeeMaxFrames;
+        // 1) catches: statistics only (uint8 frames) or planes + statistics (HSI cubes), then the von Kries denominators
+        if (d->source == 0) {
+            hipLaunchKernelGGL(k_rgb_to_planes<3>, dim3(g, F), dim3(kT), 0, s, in_hwc + (size_t)f0 * n * 3, n, ctx->d_decode_lut, mat, 3, (float*)nullptr, partials);
+        } else {
+            const size_t esz = d->hsi_dtype == 0 ? 4 : 2;
+            for (int f = 0; f < F; ++f) {
+                const char* cube = (const char*)d->hsi + (size_t)(f0 + f) * n * d->bands * esz;
+                hipLaunchKernelGGL(k_spectral_integrate<3>, dim3(g), dim3(kT), sizeof(float) * 3 * d->bands, s, (const void*)cube, d->hsi_layout, d->hsi_dtype, n,
+                                   d->bands, mat, 3, raw + (size_t)f * 3 * n, partials + (size_t)f * g * 3);
+            }
+        }
+        hipLaunchKernelGGL(k_finalize_stats, dim3(F), dim3(1024), 0, s, partials, g, 3, n, d->adaptation, d->eps, stats);
+        BeeArgs a{};
+        a.in = in_hwc ? in_hwc + (size_t)f0 * n * 3 : nullptr; a.raw = raw; a.H = H; a.W = W; a.lut = ctx->d_decode_lut; a.mat = mat; a.stats = stats;
+        a.out = out_hwc + (size_t)f0 * n * 3;
+        a.out_f = d->out_float ? reinterpret_cast<float*>(out_hwc) + (size_t)f0 * n * 3 : nullptr;
+        a.scale_mode = d->adaptation ? 1 : 0;
+        a.t0 = R ? (float)d->blur_taps_host[0] : 1.f; a.t1 = R ? (float)d->blur_taps_host[1] : 1.f; a.t2 = R ? (float)d->blur_taps_host[2] : 1.f;
+        a.mode = mode; a.n_jobs = nj; a.st = sel; a.hist = hist; a.ticket = ticket; a.pct = pct;
+        a.rank0 = (unsigned long long)lo; a.gamma = vi - lo; a.has_next = (size_t)lo + 1 < n ? 1 : 0;
+        a.eps = d->eps;
+        for (int i = 0; i < 9; ++i) a.M[i] = d->custom_matrix[i];
+        a.enc_thr = ctx->d_enc_thr_f32; a.coarse = ctx->d_coarse_f32; a.lo_key = ctx->coarse_lo_key[0];
+        long per = ((long)ctx->num_cus * 3 + F - 1) / F;
+        const int gx = (int)(tiles < per ? tiles : (per < 1 ? 1 : per));
+        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+#define AVX_BEE(SRCV, RV, STG, NJV) hipLaunchKernelGGL((k_bee_tile<SRCV, RV, STG, NJV>), dim3(gx, F), dim3(kT), 0, s, a)
+#define AVX_BEE_SR(STG, NJV)                                                                         \
+        {                                                                                            \
+            if (d->source == 0) { if (R) AVX_BEE(0, 1, STG, NJV); else AVX_BEE(0, 0, STG, NJV); }    \
+            else { if (R) AVX_BEE(1, 1, STG, NJV); else AVX_BEE(1, 0, STG, NJV); }                   \
+        }
+        // 2) the order statistics the mapping needs: three radix passes over the recomputed values
+        for (int ps = 0; ps < 3 && nj > 0; ++ps) {
+            a.pass = ps; a.shift = shifts[ps]; a.bits = bits[ps];
+            if (nj == 1) AVX_BEE_SR(0, 1) else if (nj == 2) AVX_BEE_SR(0, 2) else AVX_BEE_SR(0, 3)
+        }
+        // 3) map + encode
+        a.pass = 0; a.shift = 0; a.bits = 11;
+        AVX_BEE_SR(1, 1)
+#undef AVX_BEE_SR
+#undef AVX_BEE
+        AVX_HIP(ctx, hipGetLastError());
+    }
+    return AVX_OK;
 }
 
 extern "C" {
@@ -970,6 +1373,15 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
     hipStream_t s0 = avx_pick_stream(ctx, stream);
     const size_t n = (size_t)H * W;
     const int g = grid_for(ctx, n);
+    {   // the recompute form (k_bee_tile): every mapping but falsecolor_uv_mixed (a second order statistic over its own output), blur k <= 3
+        // Measured (MI355X, opponent mapping, device-resident batches): 26.1 vs 20.2 GP/s at 1080p (8 frames per step), 29.4 vs 32.2 at 4K
+        // (4 frames): the tile pipeline is bound by its arithmetic (three IEEE divisions, a square root and the 3 x 3 passes per pixel and
+        // pass), not by bytes, so it wins where the plane route is launch-bound and loses where that route streams.  AVX_BEE_FUSED=1 / 0 pins it.
+        const char* pin = getenv("AVX_BEE_FUSED");
+        const bool want = pin && *pin ? atoi(pin) != 0 : n <= (size_t)2500000;
+        if (want && d->mapping != 4 && !debug_planes && (d->blur_ksize == 0 || d->blur_ksize == 1 || d->blur_ksize == 3))
+            return honeybee_recompute(ctx, in_hwc, out_hwc, n_frames, H, W, d, s0);
+    }
     // Frame lanes: the frames of a batch are independent and no kernel of this tail fills the GPU at video sizes, so frame f
     // runs on internal stream f % lanes with that stream's own workspace (AVX_UV_LANES pins the count; 1 = the caller's
     // stream only, which is also what a single frame uses).

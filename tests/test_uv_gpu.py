@@ -218,3 +218,31 @@ def test_honeybee_planes_and_1080p_vs_oracle(uv, oracle):
     # the HSI-cube source (what the MST++ route feeds) agrees with the folded-RGB source
     out2 = bee._operator()(frame, hsi=hsi, hsi_layout="nhwc")
     _u8_close(out2, want)
+
+
+@pytest.mark.parametrize("mapping", ["opponent", "falsecolor", "custom_matrix", "uv_purple_yellow"])
+@pytest.mark.parametrize("adaptation", ["white_patch", "gray_world", None])
+def test_honeybee_recompute_form_equals_plane_form(uv, oracle, mapping, adaptation, monkeypatch):
+    """csrc/uv.hip has two schedules of the honeybee tail: planes streamed between stage kernels, and the recompute form
+    (k_bee_tile: every pass re-derives the blurred catches from the uint8 frame, the frames of a batch share each launch).
+    They run the same arithmetic, so a batch through both must agree byte for byte -- frames whose sides are not multiples
+    of the 32-pixel tile, a batch of three, and a no-blur variant -- and both agree with the oracle to +-1 code."""
+    from animal_vision_amd.animals import HoneyBee
+    from animal_vision_amd.synthetic import structured_frame
+
+    M = np.array([[0.9, 0.1, 0.0], [0.05, 0.8, 0.2], [0.4, 0.0, 0.7]], np.float32)
+    for (H, W), sigma in (((70, 101), 0.2), ((33, 31), 0.2), ((64, 64), 0.0)):
+        frames = np.stack([structured_frame(k, H, W) for k in range(3)])
+        outs = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("AVX_BEE_FUSED", fused)
+            op = HoneyBee(adaptation=adaptation, mapping_mode=mapping, custom_matrix=M, blur_sigma_px=sigma)._operator()
+            ctx = op._ctx()
+            d_in, d_out = ctx.upload(frames), ctx.malloc(frames.nbytes)
+            op.run_device(d_in, d_out, 3, H, W)
+            outs[fused] = ctx.download(d_out, frames.shape, np.uint8)
+            d_in.free(); d_out.free()
+        assert np.array_equal(outs["1"], outs["0"]), (mapping, adaptation, (H, W), int(np.abs(outs["1"].astype(int) - outs["0"].astype(int)).max()))
+        for k in range(3):
+            _, want = oracle.honeybee_visualize(frames[k], adaptation=adaptation, mapping_mode=mapping, custom_matrix=M, blur_sigma_px=sigma)
+            _u8_close(outs["1"][k], want, max_frac=5e-3)
