@@ -406,6 +406,80 @@ int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpa
     return AVX_OK;
 }
 
+
+// ---- dense 3x3 conv (31 -> 31 channels, zero padding 1) [+ add] through an LDS halo tile: MST.embedding / mapping + x / conv_out + x ----
+// (:199, :228, :277).  The register-only form (csrc/mst_mfma.hip::k_mst_conv3x3) fetches every tap's row from L2 per wave -- nine
+// reads of each pixel, 470 MB of fetch traffic per 1080p launch against 133 MB of input; here a workgroup stages its 18 x 18 halo
+// region once (next tile's rows in flight during the MFMAs) and the nine taps are 16-byte LDS reads.  Implicit GEMM, K = 9 x 32.
+template <int MINW>
+__global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __restrict__ x /*[B][H][W][32]*/, const uint4* __restrict__ wpack /*[9][2][64]*/,
+                                                               const __half* __restrict__ add /*or NULL*/, __half* __restrict__ out, int B, int H, int W) {
+    constexpr int C = 32, PP = C * 2 + 16, RP = (HS * PP + 255) / 256 * 256, NFILL = (HS * HS * 4 + kFT - 1) / kFT;
+    __shared__ __align__(16) unsigned char xt[HS * RP];
+    __shared__ uint4 wl[18 * 64];  // the 18 A fragments (9 taps x 2 K-steps): in registers they cost 72 VGPRs and a wave of occupancy
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 18 * 64; i += kFT) wl[i] = wpack[i];
+    const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
+    const long total = (long)B * ty * tx;
+    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };
+    uint4 pre[NFILL];
+    auto fetch = [&](const Tile& t) {
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            const int it = tid + k * kFT, q = it >> 2, part = it & 3;
+            const int yy = t.y0 - 1 + q / HS, xx = t.x0 - 1 + q % HS;
+            const bool ok = it < HS * HS * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            uint4 r = *reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + 8 * part);
+            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
+            pre[k] = r;
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile >= total) return;
+    Tile t = tile_of(tile);
+    fetch(t);
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            const int it = tid + k * kFT, q = it >> 2, part = it & 3;
+            if (it < HS * HS * 4) *reinterpret_cast<uint4*>(xt + (size_t)(q / HS) * RP + (size_t)(q % HS) * PP + 16 * part) = pre[k];
+        }
+        __syncthreads();
+        const long next = tile + gridDim.x;
+        if (next < total) fetch(tile_of(next));
+        {
+            const int r = 2 * wave + (p >> 4), c = p & 15;
+            const int yo = t.y0 + r, xo = t.x0 + c;
+            const bool live = yo < H && xo < W;
+            const size_t off = ((t.b * H + (live ? yo : 0)) * (size_t)W + (live ? xo : 0)) * C + 16 * h;
+            uint4 ar[2] = {uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}};
+            if (add) { ar[0] = reinterpret_cast<const uint4*>(add + off)[0]; ar[1] = reinterpret_cast<const uint4*>(add + off)[1]; }
+            float16_t d;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[v] = 0.f;
+            const unsigned char* src = xt + (size_t)r * RP + (size_t)c * PP + 16 * h;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    d = mfma16(__builtin_bit_cast(half8_t, wl[(2 * tap + s2) * 64 + lane]), __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(src + (size_t)(tap / 3) * RP + (size_t)(tap % 3) * PP + 32 * s2)), d);
+            if (live) {
+                const half8_t r0 = __builtin_bit_cast(half8_t, ar[0]), r1 = __builtin_bit_cast(half8_t, ar[1]);
+                half8_t o0, o1;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)(d[v] + (float)r0[v]); o1[v] = (_Float16)(d[8 + v] + (float)r1[v]); }
+                reinterpret_cast<uint4*>(out + off)[0] = __builtin_bit_cast(uint4, o0);
+                reinterpret_cast<uint4*>(out + off)[1] = __builtin_bit_cast(uint4, o1);
+            }
+        }
+        if (next >= total) break;
+        tile = next;
+        t = tile_of(tile);
+        __syncthreads();  // everyone is done reading xt
+    }
+}
+
 }  // namespace
 
 extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
@@ -450,4 +524,20 @@ extern "C" int avx_mst_attn_tail(avx_ctx* ctx, const void* v, const void* x, con
     hipStream_t s = avx_pick_stream(ctx, stream);
     if (C == 32) return launch_attn_tail<32, 4>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s);
     return launch_attn_tail<64, 2>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s);
+}
+
+extern "C" int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack16 && out && B > 0 && H > 0 && W > 0, "avx_mst_conv3x3_lds: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32, "avx_mst_conv3x3_lds: C=%d (32: the 31-channel full-resolution convs)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack16 | (uintptr_t)add | (uintptr_t)out)) & 15u) == 0, "avx_mst_conv3x3_lds: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, x != out, "avx_mst_conv3x3_lds: in-place convolution is not possible");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    const long cap = (long)ctx->num_cus * 3;
+    hipLaunchKernelGGL(k_mst_conv3x3_lds<6>, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (const __half*)add,
+                       (__half*)out, B, H, W);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
 }

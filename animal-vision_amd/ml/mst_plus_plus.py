@@ -118,6 +118,7 @@ class _AvxOps:
         self._mfma = os.environ.get("AVX_MST_NO_MFMA", "") == ""  # A/B: the fused matrix-core kernels of csrc/mst_mfma.hip
         self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
         self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
+        self._conv_lds = os.environ.get("AVX_MST_NO_CONV_LDS", "") == ""  # A/B: the dense 3x3 convs through an LDS halo tile
         self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
@@ -225,6 +226,19 @@ class _AvxOps:
         out = torch.empty_like(x)
         ctx = self.ctx(x.device)
         ctx._check(lib.avx_mst_conv3x3_add(ctx._h, x.data_ptr(), wpack.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), b, h, w, c,
+                                           torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
+    def conv3x3_lds(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:
+        """conv3x3 through an LDS halo tile (csrc/mst_fused.hip::k_mst_conv3x3_lds): every input pixel is fetched once."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        x = x.contiguous()
+        add = add.contiguous() if add is not None else None
+        out = torch.empty_like(x)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_conv3x3_lds(ctx._h, x.data_ptr(), wpack16.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), b, h, w, c,
                                            torch.cuda.current_stream(x.device).cuda_stream))
         return out
 
@@ -454,6 +468,9 @@ class MSTPlusPlus(torch.nn.Module):
     # ---- blocks (x is NHWC, channel groups 32 wide) -------------------------------------------------
     def _conv3(self, x: torch.Tensor, key: str, add: torch.Tensor = None) -> torch.Tensor:
         """31 -> 31 channel 3x3 conv (padding 1) [+ add]: MFMA implicit GEMM for float16 on the GPU, F.conv2d otherwise."""
+        if _AVX.fused_ok(x) and x.shape[-1] == 32 and _AVX._conv_lds:
+            wq = self._prep(key + ".frag9k16", lambda: torch.stack([pack_fragments16(self._w(key, (0, 1))[:, :, t // 3, t % 3].t().contiguous()) for t in range(9)]).contiguous())
+            return _AVX.conv3x3_lds(x, wq, add)
         if _AVX.fused_ok(x) and x.shape[-1] == 32:
             wp = self._prep(key + ".frag9", lambda: torch.stack([pack_fragments(self._w(key, (0, 1))[:, :, t // 3, t % 3].t().contiguous(), True) for t in range(9)]).contiguous())
             return _AVX.conv3x3(x, wp, add)

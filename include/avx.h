@@ -344,6 +344,10 @@ int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const 
 int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, const void* w2pack, const void* residual, void* out, int B, int H,
                         int W, int C, void* stream);
 
+/* avx_mst_conv3x3_add through an LDS halo tile (16 x 16 pixels, every input pixel fetched once): wpack16 = the nine taps' C x C
+ * weights as v_mfma_f32_32x32x16_f16 A fragments ([9][2][64][8] float16, ml/mst_plus_plus.py::pack_fragments16 per tap). */
+int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int B, int H, int W, int C, void* stream);
+
 /* The tail of the first half of an MSAB block in one pass (MS_MSA :104-106, :132-137; MSAB :183):
  * out = v @ M + bias + dw3x3(gelu(dw3x3(v))) + x on (B, H, W, C) float16 tensors, C = 32 or 64, with M the per-frame C x C matrix
  * of avx_mst_attn_pack16 (so B frames must share M: the host calls it per frame).  v on the tile's 20 x 20 halo region and the
