@@ -131,6 +131,16 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             for (int s = 0; s < KS2; ++s) w2f[n * KS2 + s] = __builtin_bit_cast(half8_t, w2pack[((size_t)n * (HID / 16) + pass * KS2 + s) * 64 + lane]);
     };
     if constexpr (NPASS == 1) load_w2(0);
+    // phase 1 items of this wave (pixel groups wave / NCT + j * 8 / NCT): where a lane's pixel sits in the hidden tile and in the image
+    constexpr int NITEM = (NGRP + 8 / NCT - 1) / (8 / NCT);
+    int p1_g[NITEM], p1_dst[NITEM], p1_dy[NITEM], p1_dx[NITEM];
+#pragma unroll
+    for (int j = 0; j < NITEM; ++j) {
+        const int g = wave / NCT + j * (8 / NCT), q = 32 * g + p, qc = q < NHALO ? q : 0;
+        p1_g[j] = g < NGRP ? g : -1;
+        p1_dst[j] = (g < NGRP && q < NHALO) ? (qc / HS) * RPITCH + (qc % HS) * HPITCH + 32 * h : -1;
+        p1_dy[j] = qc / HS - 1; p1_dx[j] = qc % HS - 1;
+    }
     long tile = blockIdx.x;
     if (tile >= total) return;
     Tile t = tile_of(tile);
@@ -153,28 +163,29 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 half8_t w1f[KS1];
 #pragma unroll
                 for (int s = 0; s < KS1; ++s) w1f[s] = __builtin_bit_cast(half8_t, w1pack[((size_t)(pass * NCT + ct) * KS1 + s) * 64 + lane]);
-#pragma unroll 1
-                for (int g = wave / NCT; g < NGRP; g += 8 / NCT) {
-                    const int q = 32 * g + p;
+#pragma unroll
+                for (int j = 0; j < NITEM; ++j) {
+                    if (p1_g[j] < 0) continue;  // wave-uniform
                     float16_t d;
 #pragma unroll
                     for (int v = 0; v < 16; ++v) d[v] = 0.f;
-                    const unsigned char* ysrc = yt + (size_t)q * YPITCH + 16 * h;
+                    const unsigned char* ysrc = yt + (size_t)(32 * p1_g[j] + p) * YPITCH + 16 * h;
 #pragma unroll
                     for (int s = 0; s < KS1; ++s) d = mfma16(w1f[s], __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(ysrc + 32 * s)), d);
-                    if (q < NHALO) {
-                        const int yy = t.y0 - 1 + q / HS, xx = t.x0 - 1 + q % HS;
-                        const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                    if (p1_dst[j] >= 0) {
+                        const int yy = t.y0 + p1_dy[j], xx = t.x0 + p1_dx[j];
+                        const uint32_t keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;  // zeros outside the image
                         half8_t o0, o1;
 #pragma unroll
                         for (int v = 0; v < 16; v += 2) {
                             const float2_t gv = gelu_fast2(float2_t{d[v], d[v + 1]});
-                            const _Float16 a = inside ? (_Float16)gv.x : (_Float16)0.f, b2 = inside ? (_Float16)gv.y : (_Float16)0.f;
-                            if (v < 8) { o0[v] = a; o0[v + 1] = b2; } else { o1[v - 8] = a; o1[v - 7] = b2; }
+                            if (v < 8) { o0[v] = (_Float16)gv.x; o0[v + 1] = (_Float16)gv.y; } else { o1[v - 8] = (_Float16)gv.x; o1[v - 7] = (_Float16)gv.y; }
                         }
-                        unsigned char* dst = ht + (size_t)(q / HS) * RPITCH + (size_t)(q % HS) * HPITCH + (32 * ct + 16 * h) * 2;
-                        reinterpret_cast<uint4*>(dst)[0] = __builtin_bit_cast(uint4, o0);
-                        reinterpret_cast<uint4*>(dst)[1] = __builtin_bit_cast(uint4, o1);
+                        uint4 u0 = __builtin_bit_cast(uint4, o0), u1 = __builtin_bit_cast(uint4, o1);
+                        u0.x &= keep; u0.y &= keep; u0.z &= keep; u0.w &= keep; u1.x &= keep; u1.y &= keep; u1.z &= keep; u1.w &= keep;
+                        unsigned char* dst = ht + p1_dst[j] + 64 * ct;
+                        reinterpret_cast<uint4*>(dst)[0] = u0;
+                        reinterpret_cast<uint4*>(dst)[1] = u1;
                     }
                 }
             }
@@ -275,26 +286,43 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
 #pragma unroll
     for (int i = 0; i < NT * NS; ++i) mf[i] = __builtin_bit_cast(half8_t, mpack[(size_t)i * 64 + lane]);
 
+    // which halo pixel / 16-byte part a thread stages, and where it lands in LDS, does not depend on the tile: computed once
     uint4 pre[NFILL];
+    int f_dy[NFILL], f_dx[NFILL], f_off[NFILL], f_lds[NFILL];
+#pragma unroll
+    for (int k = 0; k < NFILL; ++k) {
+        const int it = tid + k * kFT, itc = it < VS * VS * NO ? it : 0, q = itc / NO, part16 = itc % NO;
+        f_dy[k] = q / VS - 2; f_dx[k] = q % VS - 2; f_off[k] = 8 * part16;
+        f_lds[k] = it < VS * VS * NO ? (q / VS) * VRP + (q % VS) * PP + 16 * part16 : -1;
+    }
     auto fetch = [&](const Tile& t) {
 #pragma unroll
         for (int k = 0; k < NFILL; ++k) {
-            const int it = tid + k * kFT, q = it / NO, part16 = it % NO;
-            const int yy = t.y0 - 2 + q / VS, xx = t.x0 - 2 + q % VS;
-            const bool ok = it < VS * VS * NO && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yy = t.y0 + f_dy[k], xx = t.x0 + f_dx[k];
+            const bool ok = f_lds[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
             const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            uint4 r = *reinterpret_cast<const uint4*>(v + ((t.b * H + yc) * (size_t)W + xc) * C + 8 * part16);
+            uint4 r = *reinterpret_cast<const uint4*>(v + ((t.b * H + yc) * (size_t)W + xc) * C + f_off[k]);
             r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
             pre[k] = r;
         }
     };
     auto fill = [&]() {
 #pragma unroll
-        for (int k = 0; k < NFILL; ++k) {
-            const int it = tid + k * kFT, q = it / NO, part16 = it % NO;
-            if (it < VS * VS * NO) *reinterpret_cast<uint4*>(vt + (size_t)(q / VS) * VRP + (size_t)(q % VS) * PP + 16 * part16) = pre[k];
-        }
+        for (int k = 0; k < NFILL; ++k)
+            if (f_lds[k] >= 0) *reinterpret_cast<uint4*>(vt + f_lds[k]) = pre[k];
     };
+    // phase B items of this lane (pixels of the 18 x 18 map: part * per + lane + 64 i): LDS offsets and image offsets, once
+    constexpr int NB = (((MS * MS + (8 / NO) - 1) / (8 / NO)) + 63) / 64;
+    int b_src[NB], b_dst[NB], b_dy[NB], b_dx[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int q = part * per + lane + 64 * i;
+        const bool ok = q < (part + 1) * per && q < MS * MS;
+        const int qc = ok ? q : 0, my = qc / MS, mx = qc % MS;
+        b_src[i] = ok ? my * VRP + mx * PP + 16 * oct : -1;
+        b_dst[i] = my * MRP + mx * PP + 16 * oct;
+        b_dy[i] = my - 1; b_dx[i] = mx - 1;
+    }
     long tile = blockIdx.x;
     if (tile >= total) return;
     Tile t = tile_of(tile);
@@ -303,32 +331,35 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
         fill();
         __syncthreads();  // vt complete (and the tables, first time round)
         // ---- phase B: mid = gelu(dw1(v)) on the 18 x 18 region, zero outside the image ----
-#pragma unroll 1
-        for (int q = part * per + lane; q < (part + 1) * per && q < MS * MS; q += 64) {
-            const int my = q / MS, mx = q % MS;
-            const unsigned char* src = vt + (size_t)my * VRP + (size_t)mx * PP + 16 * oct;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (b_src[i] < 0) continue;
+            const unsigned char* src = vt + b_src[i];
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const uint4 hv = *reinterpret_cast<const uint4*>(src + (size_t)(tap / 3) * VRP + (size_t)(tap % 3) * PP);
+                const uint4 hv = *reinterpret_cast<const uint4*>(src + (tap / 3) * VRP + (tap % 3) * PP);
                 const uint4 wv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(t1l) + (size_t)tap * C * 2 + 16 * oct);
                 fma_mix_lo(acc[0], hv.x, wv.x); fma_mix_hi(acc[1], hv.x, wv.x);
                 fma_mix_lo(acc[2], hv.y, wv.y); fma_mix_hi(acc[3], hv.y, wv.y);
                 fma_mix_lo(acc[4], hv.z, wv.z); fma_mix_hi(acc[5], hv.z, wv.z);
                 fma_mix_lo(acc[6], hv.w, wv.w); fma_mix_hi(acc[7], hv.w, wv.w);
             }
-            const int yy = t.y0 - 1 + my, xx = t.x0 - 1 + mx;
+            const int yy = t.y0 + b_dy[i], xx = t.x0 + b_dx[i];
             const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
             half8_t o;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 const float2_t gv = gelu_fast2(float2_t{acc[j], acc[j + 1]});
-                o[j] = inside ? (_Float16)gv.x : (_Float16)0.f;
-                o[j + 1] = inside ? (_Float16)gv.y : (_Float16)0.f;
+                o[j] = (_Float16)gv.x;
+                o[j + 1] = (_Float16)gv.y;
             }
-            *reinterpret_cast<uint4*>(mt + (size_t)my * MRP + (size_t)mx * PP + 16 * oct) = __builtin_bit_cast(uint4, o);
+            uint4 ov = __builtin_bit_cast(uint4, o);
+            const uint32_t keep = inside ? 0xffffffffu : 0u;  // the second conv's zero padding applies to THIS map
+            ov.x &= keep; ov.y &= keep; ov.z &= keep; ov.w &= keep;
+            *reinterpret_cast<uint4*>(mt + b_dst[i]) = ov;
         }
         __syncthreads();  // mt complete
         const long next = tile + gridDim.x;
