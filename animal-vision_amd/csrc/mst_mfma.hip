@@ -686,16 +686,24 @@ int launch_posemb(avx_ctx* ctx, const void* v, const float* w1, const float* w2,
 // Kernel size == stride: output pixel (2y + dy, 2x + dx) depends on input pixel (y, x) alone, through tap (dy, dx) -- four
 // independent C x C/2 GEMMs whose results interleave in the output.  A wave takes 32 consecutive input pixels of a row and
 // writes, per tap and output-channel tile, 32 contiguous bytes per lane at the scattered output pixel.
+// With `skip` / `wskip` the decoder's 1x1 fusion conv over [up | skip] (:257) rides along: its `up` half is folded into the taps on
+// the host (W_tap @ W_up^T, a C x C/2 matrix per tap; bias likewise) and its `skip` half is a second product on the output pixel's
+// own skip row -- `up` and the concatenation never exist, and the level's input is read once instead of being written and re-read.
 template <int C>
 __global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ x /*[B][H][W][C]*/, const uint2* __restrict__ wpack /*[4][C/64][C/8][64]*/,
-                                                     const float* __restrict__ bias /*[C/2]*/, __half* __restrict__ out /*[B][2H][2W][C/2]*/, int B, int H, int W) {
-    constexpr int KS = C / 8, CO = C / 2, NT = CO / 32;
+                                                     const float* __restrict__ bias /*[C/2]*/, const __half* __restrict__ skip /*[B][2H][2W][C/2] or NULL*/,
+                                                     const uint2* __restrict__ wskip /*[C/64][C/16][64]*/, __half* __restrict__ out /*[B][2H][2W][C/2]*/, int B,
+                                                     int H, int W) {
+    constexpr int KS = C / 8, CO = C / 2, NT = CO / 32, KSS = CO / 8;
     extern __shared__ __align__(16) unsigned char smem[];
     uint2* wl = reinterpret_cast<uint2*>(smem);
     float* bl = reinterpret_cast<float*>(smem + (size_t)4 * NT * KS * 64 * sizeof(uint2));
+    uint2* wsl = reinterpret_cast<uint2*>(bl + CO);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 4 * NT * KS * 64; i += kT) wl[i] = wpack[i];
     for (int i = tid; i < CO; i += kT) bl[i] = bias[i];
+    if (skip)
+        for (int i = tid; i < NT * KSS * 64; i += kT) wsl[i] = wskip[i];
     __syncthreads();
     const int xt = (W + 31) / 32;
     const long total = (long)B * H * xt;
@@ -718,7 +726,17 @@ __global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ 
         if constexpr (C > 64) asm volatile("" ::: "memory");  // weight fragments stay in LDS
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {
-            const size_t opix = ((size_t)(b * 2 * H + 2 * y + (tap >> 1)) * (size_t)(2 * W) + (size_t)(2 * xw + (tap & 1)));
+            const size_t opix = ((size_t)(b * 2 * H + 2 * y + (tap >> 1)) * (size_t)(2 * W) + (size_t)(2 * (xw < W ? xw : W - 1) + (tap & 1)));
+            half4_t sf[KSS];
+            if (skip) {  // lane (p, h): channels [h CO/2, (h + 1) CO/2) of the OUTPUT pixel's skip row
+                const uint4* src = reinterpret_cast<const uint4*>(skip + opix * CO + h * (CO / 2));
+#pragma unroll
+                for (int q = 0; q < CO / 16; ++q) {
+                    const half8_t h8 = __builtin_bit_cast(half8_t, src[q]);
+                    sf[2 * q] = half4_t{h8[0], h8[1], h8[2], h8[3]};
+                    sf[2 * q + 1] = half4_t{h8[4], h8[5], h8[6], h8[7]};
+                }
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float16_t d;
@@ -726,6 +744,10 @@ __global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ 
                 for (int v = 0; v < 16; ++v) d[v] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) d = mfma(__builtin_bit_cast(half4_t, wl[((tap * NT + t) * KS + s) * 64 + lane]), xf[s], d);
+                if (skip) {
+#pragma unroll
+                    for (int s = 0; s < KSS; ++s) d = mfma(__builtin_bit_cast(half4_t, wsl[(t * KSS + s) * 64 + lane]), sf[s], d);
+                }
                 _Float16 o[16];
 #pragma unroll
                 for (int v = 0; v < 16; ++v) o[v] = (_Float16)(d[v] + bl[32 * t + 16 * h + v]);
@@ -903,7 +925,19 @@ int avx_mst_posemb(avx_ctx* ctx, const void* v, const float* w1_c9, const float*
     return launch_posemb<128, 4, 16>(ctx, v, w1_c9, w2_c9, residual, bias, out, B, H, W, s);
 }
 
+static int convt2x2_impl(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, const void* skip, const void* wskip, void* out, int B, int H, int W,
+                         int C, void* stream);
 int avx_mst_convt2x2(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, void* out, int B, int H, int W, int C, void* stream) {
+    return convt2x2_impl(ctx, x, wpack, bias, nullptr, nullptr, out, B, H, W, C, stream);
+}
+int avx_mst_convt2x2_fuse(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, const void* skip, const void* wskip, void* out, int B, int H,
+                          int W, int C, void* stream) {
+    if (ctx && !(skip && wskip)) return avx_fail(ctx, AVX_ERR_INVALID, "avx_mst_convt2x2_fuse: skip / wskip is NULL");
+    if (ctx && ((((uintptr_t)skip | (uintptr_t)wskip)) & 15u)) return avx_fail(ctx, AVX_ERR_INVALID, "avx_mst_convt2x2_fuse: pointers must be 16-byte aligned");
+    return convt2x2_impl(ctx, x, wpack, bias, skip, wskip, out, B, H, W, C, stream);
+}
+static int convt2x2_impl(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, const void* skip, const void* wskip, void* out, int B, int H, int W,
+                         int C, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, x && wpack && bias && out && B > 0 && H > 0 && W > 0, "avx_mst_convt2x2: NULL pointer or empty tensor");
     AVX_REQUIRE(ctx, C == 64 || C == 128, "avx_mst_convt2x2: C=%d (64 or 128 input channels)", C);
@@ -915,13 +949,15 @@ int avx_mst_convt2x2(avx_ctx* ctx, const void* x, const void* wpack, const float
     const long cap = (long)ctx->num_cus * (C == 128 ? 2 : 8);
     if (blocks > cap) blocks = cap;
     if (C == 64) {
-        const size_t lds = (size_t)4 * 1 * 8 * 64 * sizeof(uint2) + sizeof(float) * 32;
+        const size_t lds = (size_t)4 * 1 * 8 * 64 * sizeof(uint2) + sizeof(float) * 32 + (size_t)1 * 4 * 64 * sizeof(uint2);
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mst_convt2x2<64>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (__half*)out, B, H, W);
+        hipLaunchKernelGGL(k_mst_convt2x2<64>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (const __half*)skip,
+                           (const uint2*)wskip, (__half*)out, B, H, W);
     } else {
-        const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(uint2) + sizeof(float) * 64;
+        const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(uint2) + sizeof(float) * 64 + (size_t)2 * 8 * 64 * sizeof(uint2);
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mst_convt2x2<128>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (__half*)out, B, H, W);
+        hipLaunchKernelGGL(k_mst_convt2x2<128>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (const __half*)skip,
+                           (const uint2*)wskip, (__half*)out, B, H, W);
     }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;

@@ -119,6 +119,7 @@ class _AvxOps:
         self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
         self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
         self._conv_lds = os.environ.get("AVX_MST_NO_CONV_LDS", "") == ""  # A/B: the dense 3x3 convs through an LDS halo tile
+        self._upfuse = os.environ.get("AVX_MST_NO_UPFUSE", "") == ""  # A/B: transposed conv + fusion conv in one pass
         self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
@@ -191,16 +192,21 @@ class _AvxOps:
                                             torch.cuda.current_stream(x2.device).cuda_stream))
         return out
 
-    def convt2x2(self, x: torch.Tensor, wpack: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-        """ConvTranspose2d(c -> c/2, 2, stride 2) + bias on (b, h, w, c) float16 -> (b, 2h, 2w, c/2) (csrc/mst_mfma.hip)."""
+    def convt2x2(self, x: torch.Tensor, wpack: torch.Tensor, bias: torch.Tensor, skip: torch.Tensor = None, wskip: torch.Tensor = None) -> torch.Tensor:
+        """ConvTranspose2d(c -> c/2, 2, stride 2) + bias on (b, h, w, c) float16 -> (b, 2h, 2w, c/2) (csrc/mst_mfma.hip); with
+        skip / wskip: + skip @ W_skip^T in the same pass (the decoder's fusion conv, its `up` half folded into wpack by the caller)."""
         from .._lib import lib
 
         b, h, w, c = x.shape
         x = x.contiguous()
         out = torch.empty((b, 2 * h, 2 * w, c // 2), dtype=torch.float16, device=x.device)
         ctx = self.ctx(x.device)
-        ctx._check(lib.avx_mst_convt2x2(ctx._h, x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), out.data_ptr(), b, h, w, c,
-                                        torch.cuda.current_stream(x.device).cuda_stream))
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        if skip is None:
+            ctx._check(lib.avx_mst_convt2x2(ctx._h, x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), out.data_ptr(), b, h, w, c, st))
+        else:
+            assert skip.is_contiguous() and skip.shape == out.shape
+            ctx._check(lib.avx_mst_convt2x2_fuse(ctx._h, x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), skip.data_ptr(), wskip.data_ptr(), out.data_ptr(), b, h, w, c, st))
         return out
 
     def posemb(self, v: torch.Tensor, w1_c9: torch.Tensor, w2_c9: torch.Tensor, residual: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
@@ -608,6 +614,20 @@ class MSTPlusPlus(torch.nn.Module):
         fea = self._msab(fea, p + ".bottleneck", heads)
         for i in range(2):
             kw = f"{p}.decoder_layers.{i}.0.weight"
+            if _AVX.fused_ok(fea) and fea.shape[-1] in (64, 128) and _AVX._upfuse:
+                # transposed conv + the fusion conv's [up | skip] product in ONE pass: the conv's `up` half folded into the four taps
+                # (W_tap @ W_up^T: exact in real arithmetic, one float16 rounding less than the reference's up -> cat -> conv)
+                ch = fea.shape[-1] // 2
+                wfk = f"{p}.fuse{i}"
+                wf_ = self._prep(wfk, lambda: self._w(f"{p}.decoder_layers.{i}.1.weight", (0, 1)).reshape(ch, 2 * ch).t().contiguous())
+                gt = self._prep(kw + ".upfuse4", lambda: torch.stack([pack_fragments((self._w(kw, (0, 1))[:, :, t // 2, t % 2].float() @ wf_[:ch].float()).half().contiguous(), True)
+                                                                     for t in range(4)]).contiguous())
+                gb = self._prep(kw + ".upfuse.bias", lambda: (self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)).float() @ wf_[:ch].float()).contiguous())
+                wbot_ = self._prep(f"{p}.fuse{i}.bot", lambda: pack_fragments(wf_[ch:].contiguous(), True))
+                heads //= 2
+                fea = _AVX.convt2x2(fea, gt, gb, skips[1 - i].contiguous(), wbot_)
+                fea = self._msab(fea, f"{p}.decoder_layers.{i}.2", heads)
+                continue
             if _AVX.fused_ok(fea) and fea.shape[-1] in (64, 128):  # four 1x1 products on the matrix cores (kernel size == stride)
                 wt = self._prep(kw + ".frag4", lambda: torch.stack([pack_fragments(self._w(kw, (0, 1))[:, :, t // 2, t % 2].contiguous(), True) for t in range(4)]).contiguous())
                 bt = self._prep(kw + ".bias32", lambda: self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)).float().contiguous())
@@ -679,7 +699,10 @@ def hbm_bytes_per_px(stage: int = 3) -> float:
     t32, t64, t128 = 64.0, 128.0 / 4, 256.0 / 16
     convs = (2 * t32) + (3 * t32)                # embedding; mapping + x
     convs += (t32 + t64) + (t64 + t128)          # two strided 4x4 convs
-    convs += (t128 + t64) + (2 * t64 + t64)      # transposed conv 128 -> 64, fusion 1x1 over [up | skip]
-    convs += (t64 + t32) + (2 * t32 + t32)       # transposed conv 64 -> 32, fusion 1x1
+    if _AVX._upfuse:
+        convs += (t128 + t64 + t64) + (t64 + t32 + t32)   # transposed conv + fusion conv in one pass: read x and skip, write the level's input
+    else:
+        convs += (t128 + t64) + (2 * t64 + t64)      # transposed conv 128 -> 64, fusion 1x1 over [up | skip]
+        convs += (t64 + t32) + (2 * t32 + t32)       # transposed conv 64 -> 32, fusion 1x1
     head = (3 + 12) + (12 + t32) + (3 * t32)     # uint8 -> float32 NCHW; conv_in 3 -> 31; conv_out + x
     return stage * (per_stage + convs) + head

@@ -391,6 +391,11 @@ int avx_mst_posemb(avx_ctx* ctx, const void* v, const float* w1_c9, const float*
 /* ConvTranspose2d(C -> C/2, kernel 2, stride 2) + bias on B x H x W x C float16 -> B x 2H x 2W x C/2 (MST decoder, :214,
  * :256): four independent C x C/2 products, one per output-pixel parity.  wpack: 4 taps (dy*2 + dx) in fragment order. */
 int avx_mst_convt2x2(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, void* out, int B, int H, int W, int C, void* stream);
+/* The same with the decoder's 1x1 fusion conv over [up | skip] (:257) folded in: wpack / bias carry the taps composed with the
+ * conv's `up` half (W_tap @ W_up^T, b @ W_up^T, built by the host), `skip` is the (B, 2H, 2W, C/2) skip tensor and wskip the conv's
+ * `skip` half in fragment order ([C/64][C/16][64] x 4 float16, pack_fragments(..., True)): out = convT'(x) + skip @ W_skip^T. */
+int avx_mst_convt2x2_fuse(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, const void* skip, const void* wskip, void* out, int B, int H,
+                          int W, int C, void* stream);
 
 /* nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False) on a channels-last (B,H,W,C) tensor (pos_emb :104-106,
  * FeedForward :147), float32 accumulate; w_c9: C x 9 float32 (weight.reshape(C, 9)); gelu_out: exact-erf GELU. */
