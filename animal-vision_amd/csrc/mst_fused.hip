@@ -511,6 +511,54 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
     }
 }
 
+
+// ---- uint8 frame -> conv_in output (MST_Plus_Plus.conv_in :275, 3 -> 31 channels, 3x3, zero padding 1) in one kernel --------------------
+// Replaces: uint8 -> float32 / 255 -> NCHW -> reflect pad to the predictor's stride (predict_torch.py:171-183) -> float16 -> channels-last
+// copy -> a MIOpen convolution (five elementwise launches and a library conv: ~1 ms per 4K frame).  A thread owns one output pixel: its 27
+// inputs (float16-rounded like autocast's conv input, reflect-padded coordinates, zeros beyond the padded frame) stay in registers
+// and meet the 27 x 32 weights as wave-uniform scalar operands; 32 float32 accumulators, one 64-byte row out.
+__global__ __launch_bounds__(256) void k_mst_conv_in_u8(const uint8_t* __restrict__ frame /*[H][W][3]*/, const float* __restrict__ w /*[27][32]: k = (ky*3+kx)*3+c*/,
+                                                        __half* __restrict__ out /*[Hp][Wp][32]*/, int H, int W, int pt, int pl, int Hp, int Wp) {
+    __shared__ __align__(16) float wl[27 * 32];  // wave-uniform 16-byte LDS reads (broadcasts): as scalar operands the 864 weights spill the SGPR file
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const size_t total = (size_t)Hp * Wp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / Wp), x = (int)(i - (size_t)y * Wp);
+        float in[27];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = yy >= 0 && yy < Hp && xx >= 0 && xx < Wp;  // the conv's zero padding applies to the PADDED frame
+            int sy = (ok ? yy : 0) - pt, sx = (ok ? xx : 0) - pl;       // reflect (no edge repeat) back into the frame
+            sy = sy < 0 ? -sy : (sy >= H ? 2 * (H - 1) - sy : sy);
+            sx = sx < 0 ? -sx : (sx >= W ? 2 * (W - 1) - sx : sx);
+            const uint8_t* q = frame + ((size_t)sy * W + sx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) in[3 * t + c] = ok ? (float)(_Float16)((float)q[c] / 255.0f) : 0.f;
+        }
+        uint4* dst = reinterpret_cast<uint4*>(out + i * 32);
+#pragma unroll 1
+        for (int v = 0; v < 4; ++v) {  // 8 output channels at a time: a bounded set of weights in flight (unrolled, the compiler hoists all 864)
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                const float4 wa = *reinterpret_cast<const float4*>(wl + k * 32 + 8 * v), wb = *reinterpret_cast<const float4*>(wl + k * 32 + 8 * v + 4);
+                acc[0] = __builtin_fmaf(in[k], wa.x, acc[0]); acc[1] = __builtin_fmaf(in[k], wa.y, acc[1]);
+                acc[2] = __builtin_fmaf(in[k], wa.z, acc[2]); acc[3] = __builtin_fmaf(in[k], wa.w, acc[3]);
+                acc[4] = __builtin_fmaf(in[k], wb.x, acc[4]); acc[5] = __builtin_fmaf(in[k], wb.y, acc[5]);
+                acc[6] = __builtin_fmaf(in[k], wb.z, acc[6]); acc[7] = __builtin_fmaf(in[k], wb.w, acc[7]);
+            }
+            half8_t o8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o8[j] = (_Float16)acc[j];
+            dst[v] = __builtin_bit_cast(uint4, o8);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
@@ -569,6 +617,23 @@ extern "C" int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpac
     const long cap = (long)ctx->num_cus * 3;
     hipLaunchKernelGGL(k_mst_conv3x3_lds<6>, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (const __half*)add,
                        (__half*)out, B, H, W);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+extern "C" int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right,
+                                  const float* w_27x32_dev, void* out, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, frame_hwc && w_27x32_dev && out && H > 1 && W > 1, "avx_mst_conv_in_u8: NULL pointer or a frame too small to reflect");
+    AVX_REQUIRE(ctx, pad_top >= 0 && pad_bottom >= 0 && pad_left >= 0 && pad_right >= 0 && pad_top < H && pad_bottom < H && pad_left < W && pad_right < W,
+                "avx_mst_conv_in_u8: reflect padding must be smaller than the frame");
+    AVX_REQUIRE(ctx, ((uintptr_t)out & 15u) == 0, "avx_mst_conv_in_u8: out must be 16-byte aligned");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    const int Hp = H + pad_top + pad_bottom, Wp = W + pad_left + pad_right;
+    const size_t total = (size_t)Hp * Wp;
+    const size_t want = (total + 255) / 256, cap = (size_t)ctx->num_cus * 16;
+    hipLaunchKernelGGL(k_mst_conv_in_u8, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, frame_hwc, w_27x32_dev, (__half*)out, H, W, pad_top, pad_left, Hp, Wp);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -119,6 +119,7 @@ class _AvxOps:
         self._ffn2 = os.environ.get("AVX_MST_NO_FFN2", "") == ""  # A/B: the fused depthwise-conv + second GEMM kernel
         self._posemb = os.environ.get("AVX_MST_NO_POSEMB", "") == ""  # A/B: pos_emb's two depthwise convs in one pass
         self._conv_lds = os.environ.get("AVX_MST_NO_CONV_LDS", "") == ""  # A/B: the dense 3x3 convs through an LDS halo tile
+        self._conv_in = os.environ.get("AVX_MST_NO_CONV_IN", "") == ""  # A/B: uint8 frame -> conv_in output in one kernel
         self._upfuse = os.environ.get("AVX_MST_NO_UPFUSE", "") == ""  # A/B: transposed conv + fusion conv in one pass
         self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
@@ -233,6 +234,20 @@ class _AvxOps:
         ctx = self.ctx(x.device)
         ctx._check(lib.avx_mst_conv3x3_add(ctx._h, x.data_ptr(), wpack.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), b, h, w, c,
                                            torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
+    def conv_in_u8(self, frame: torch.Tensor, pads, w_27x32: torch.Tensor) -> torch.Tensor:
+        """uint8 (H, W, 3) frame -> conv_in's output (1, H + pads, W + pads, 32) float16 in one kernel (csrc/mst_fused.hip::k_mst_conv_in_u8):
+        / 255, float16 rounding, reflect pad (top, bottom, left, right), 3x3 conv with zero padding."""
+        from .._lib import lib
+
+        H, W, _ = frame.shape
+        t, b, l, r = pads
+        frame = frame.contiguous()
+        out = torch.empty((1, H + t + b, W + l + r, 32), dtype=torch.float16, device=frame.device)
+        ctx = self.ctx(frame.device)
+        ctx._check(lib.avx_mst_conv_in_u8(ctx._h, frame.data_ptr(), H, W, t, b, l, r, w_27x32.data_ptr(), out.data_ptr(),
+                                          torch.cuda.current_stream(frame.device).cuda_stream))
         return out
 
     def conv3x3_lds(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:
@@ -652,6 +667,25 @@ class MSTPlusPlus(torch.nn.Module):
         return self._conv3(fea, p + ".mapping.weight", add=x)
 
     @torch.no_grad()
+    def forward_from_u8(self, frame: torch.Tensor, pads) -> torch.Tensor:
+        """uint8 (H, W, 3) device frame -> (1, Hp, Wp, 32) cube on the reflect-padded frame (pads = (top, bottom, left, right), a
+        multiple of 8 in both directions afterwards): conv_in fused with the input preparation, then the body of forward_nhwc."""
+        w27 = self._prep("conv_in.w27x32", lambda: self._w("conv_in.weight", (0,)).permute(2, 3, 1, 0).reshape(27, PAD).float().contiguous())
+        x = _AVX.conv_in_u8(frame, pads, w27)
+        assert x.shape[1] % 8 == 0 and x.shape[2] % 8 == 0, "pad the frame to a multiple of 8 (predict_torch.py pads to 16)"
+        return self._body(x)
+
+    def _body(self, x: torch.Tensor) -> torch.Tensor:
+        hfe = x
+        for s in range(self.stage):
+            hfe = self._mst(hfe, f"body.{s}")
+        return self._conv3(hfe, "conv_out.weight", add=x)
+
+    def can_fuse_conv_in(self) -> bool:
+        ref = self._p("conv_in.weight")
+        return _AVX.enabled and _AVX._mfma and _AVX._conv_in and ref.is_cuda and ref.dtype == torch.float16
+
+    @torch.no_grad()
     def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
         """x: (b, 3, H, W) in [0, 1] -> (b, H, W, 32) channels-last, bands 0..30 + one zero padding channel (the layout
         the device hand-off consumes).  Same pad-to-8 / crop as MST_Plus_Plus.forward :279-293."""
@@ -661,11 +695,7 @@ class MSTPlusPlus(torch.nn.Module):
             x = F.pad(x, [0, pad_w, 0, pad_h], mode="reflect")
         x = x.to(self._p("conv_in.weight").dtype).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)  # NHWC view
         x = self._conv_nhwc(x, self._w("conv_in.weight", (0,)), padding=1)
-        hfe = x
-        for s in range(self.stage):
-            hfe = self._mst(hfe, f"body.{s}")
-        hfe = self._conv3(hfe, "conv_out.weight", add=x)
-        return hfe[:, :h_inp, :w_inp, :]
+        return self._body(x)[:, :h_inp, :w_inp, :]
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -704,5 +734,5 @@ def hbm_bytes_per_px(stage: int = 3) -> float:
     else:
         convs += (t128 + t64) + (2 * t64 + t64)      # transposed conv 128 -> 64, fusion 1x1 over [up | skip]
         convs += (t64 + t32) + (2 * t32 + t32)       # transposed conv 64 -> 32, fusion 1x1
-    head = (3 + 12) + (12 + t32) + (3 * t32)     # uint8 -> float32 NCHW; conv_in 3 -> 31; conv_out + x
+    head = ((3 + t32) if _AVX._conv_in else (3 + 12) + (12 + t32)) + (3 * t32)   # uint8 frame -> conv_in output (one kernel, else float32 NCHW + conv); conv_out + x
     return stage * (per_stage + convs) + head

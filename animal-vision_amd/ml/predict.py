@@ -77,8 +77,11 @@ class MSTPlusPlusPredictor:
         zero padding channel (64-byte pixels; fp16 when half).  This is what the libavx hand-off consumes."""
         torch = self.torch
         H, W, _ = frame_dev.shape
-        x = frame_dev.to(torch.float32).div_(255.0).permute(2, 0, 1).unsqueeze(0)  # 1x3xHxW
         t, b, l, r = pad_amounts(H, W, self.stride)
+        if self.half and frame_dev.dtype == torch.uint8 and self.stride % 8 == 0 and max(t, b) < H and max(l, r) < W and H > 1 and W > 1 and self.model.can_fuse_conv_in():
+            y = self.model.forward_from_u8(frame_dev, (t, b, l, r))  # / 255, float16, reflect pad and conv_in in ONE kernel
+            return y[0, t : t + H, l : l + W, :].contiguous()
+        x = frame_dev.to(torch.float32).div_(255.0).permute(2, 0, 1).unsqueeze(0)  # 1x3xHxW
         if t or b or l or r:
             x = torch.nn.functional.pad(x, [l, r, t, b], mode="reflect")
         y = self.model.forward_nhwc(x.half() if self.half else x)
@@ -91,6 +94,9 @@ class MSTPlusPlusPredictor:
     def predict(self, image: np.ndarray) -> np.ndarray:
         """predict_rgb_to_hsi_torch for one image: HxWx3 (uint8 or float) -> HxWx31 float32."""
         torch = self.torch
+        if self.device.type == "cuda" and image.dtype == np.uint8:  # the device route (what the honeybee hand-off runs): same kernels, same cube
+            frame = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)
+            return self.predict_device_nhwc(frame)[..., :31].float().cpu().numpy()
         x01, pads = pad_to_multiple_reflect(to_float01(image), self.stride)
         xt = torch.from_numpy(np.ascontiguousarray(x01.transpose(2, 0, 1))[None]).to(self.device)
         y = self.model(xt.half() if self.half else xt.float())

@@ -344,6 +344,12 @@ int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const 
 int avx_mst_dw_gemm_add(avx_ctx* ctx, const void* hidden, const float* w_c9, const void* w2pack, const void* residual, void* out, int B, int H,
                         int W, int C, void* stream);
 
+/* uint8 RGB frame -> the output of MST_Plus_Plus.conv_in (:275) in one kernel: x = frame / 255 rounded to float16, reflect-padded by
+ * (pad_top, pad_bottom, pad_left, pad_right) like predict_torch.py:171-183, 3x3 conv with zero padding, 31 channels stored 32 wide:
+ * out (H + pads, W + pads, 32) float16.  w_27x32_dev: device float32 [27][32], row k = (ky * 3 + kx) * 3 + c, column = output channel. */
+int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right,
+                       const float* w_27x32_dev, void* out, void* stream);
+
 /* avx_mst_conv3x3_add through an LDS halo tile (16 x 16 pixels, every input pixel fetched once): wpack16 = the nine taps' C x C
  * weights as v_mfma_f32_32x32x16_f16 A fragments ([9][2][64][8] float16, ml/mst_plus_plus.py::pack_fragments16 per tap). */
 int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int B, int H, int W, int C, void* stream);
