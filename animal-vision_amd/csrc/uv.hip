@@ -162,8 +162,8 @@ __global__ __launch_bounds__(kT) void k_spectral_integrate(const void* __restric
 // contiguous span of its 256 pixels in LDS with 16-byte loads and each thread then walks its own pixel there.
 // Weights arrive band-major and zero-padded to KP ([B][KP]): for one band the KP weights are wave-uniform and
 // contiguous, i.e. scalar loads feeding the FMAs as SGPR operands.  Same FMA order over b as the generic kernel.
-template <int KP>
-__global__ __launch_bounds__(kT) void k_spectral_nhwc_h(const __half* __restrict__ cube, size_t n, int B, const float* __restrict__ wT /*[B][KP]*/, int K,
+template <int KP, int NV>
+__global__ __launch_bounds__(kT, NV > 4 ? 2 : 1) void k_spectral_nhwc_h(const __half* __restrict__ cube, size_t n, int B, const float* __restrict__ wT /*[B][KP]*/, int K,
                                                         float* __restrict__ out, Stat3* partials) {
     extern __shared__ __align__(16) unsigned char tile_raw[];
     const __half* tile = reinterpret_cast<const __half*>(tile_raw);
@@ -172,17 +172,64 @@ __global__ __launch_bounds__(kT) void k_spectral_nhwc_h(const __half* __restrict
 #pragma unroll
     for (int k = 0; k < KP; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; sm[k] = 0.0; }
     const int t = threadIdx.x;
+    // Software pipeline (NV > 0): the next tile's 16-byte vectors are fetched into registers while this tile is integrated from
+    // LDS (a tile is 256 * B * 2 bytes = NV vectors per thread: 4 for B <= 32, 11 for B <= 88; wider cubes take the plain path,
+    // NV = 0), so the HBM round trip of a tile is covered by the arithmetic of the previous one, not by other workgroups alone.
+    // Loads past the tile's end are clamped to its last vector rather than predicated: the array stays in registers.
+    constexpr bool piped = NV > 0;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pre[NV > 0 ? NV : 1];
+#define AVX_FETCH(P0)                                                                                                              \
+    {                                                                                                                              \
+        const size_t q0_ = (P0);                                                                                                   \
+        const int np_ = (int)(n - q0_ < (size_t)kT ? n - q0_ : kT);                                                                \
+        const int last_ = (int)(((size_t)np_ * B * 2) / 16) - 1;                                                                   \
+        const u32x4* src_ = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(cube) + q0_ * B * 2);            \
+        if (last_ >= 0) {                                                                                                          \
+            _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                                                       \
+                const int i_ = t + k * kT;                                                                                         \
+                pre[k] = __builtin_nontemporal_load(src_ + (i_ < last_ ? i_ : last_));                                             \
+            }                                                                                                                      \
+        }                                                                                                                          \
+    }
+    float acc[KP];
+    bool have = false;
+    size_t put_at = 0;
+#define AVX_PUT()                                                                                                                  \
+    {                                                                                                                              \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k)                                                                             \
+            if (k < K) {                                                                                                           \
+                __builtin_nontemporal_store(acc[k], out + (size_t)k * n + put_at);                                                 \
+                mn[k] = fminf(mn[k], acc[k]); mx[k] = fmaxf(mx[k], acc[k]); sm[k] += (double)acc[k];                               \
+            }                                                                                                                      \
+    }
+    if (piped && (size_t)blockIdx.x * kT < n) AVX_FETCH((size_t)blockIdx.x * kT)
     for (size_t p0 = (size_t)blockIdx.x * kT; p0 < n; p0 += (size_t)gridDim.x * kT) {
         const int np = (int)(n - p0 < (size_t)kT ? n - p0 : kT);
         const size_t bytes = (size_t)np * B * 2;
         const unsigned char* src = reinterpret_cast<const unsigned char*>(cube) + p0 * B * 2;  // 16-byte aligned: p0 % 256 == 0
         __syncthreads();  // the previous tile is no longer read
         const int nvec = (int)(bytes / 16);
-        for (int i = t; i < nvec; i += kT) reinterpret_cast<uint4*>(tile_raw)[i] = reinterpret_cast<const uint4*>(src)[i];
+        if (piped) {
+            if (nvec > 0) {  // clamped like the fetch: the surplus lanes rewrite the tile's last vector with its own value
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int i = t + k * kT;
+                    reinterpret_cast<u32x4*>(tile_raw)[i < nvec - 1 ? i : nvec - 1] = pre[k];
+                }
+            }
+        } else {
+            for (int i = t; i < nvec; i += kT) reinterpret_cast<uint4*>(tile_raw)[i] = reinterpret_cast<const uint4*>(src)[i];
+        }
         for (int i = nvec * 16 + t * 2; i < (int)bytes; i += kT * 2) *reinterpret_cast<uint16_t*>(tile_raw + i) = *reinterpret_cast<const uint16_t*>(src + i);
         __syncthreads();
-        if (t < np) {
-            float acc[KP];
+        // the previous tile's catches are stored here, ahead of the next fetch: the wait for that fetch at the top of the loop is then
+        // not also a wait for stores issued after it (one in-order counter covers both), and the stores get a whole tile of arithmetic to drain
+        if (have) AVX_PUT()
+        if (piped && p0 + (size_t)gridDim.x * kT < n) AVX_FETCH(p0 + (size_t)gridDim.x * kT)
+        have = t < np;
+        put_at = p0 + t;
+        if (have) {
 #pragma unroll
             for (int k = 0; k < KP; ++k) acc[k] = 0.0f;
             const __half* px = tile + (size_t)t * B;
@@ -193,14 +240,11 @@ __global__ __launch_bounds__(kT) void k_spectral_nhwc_h(const __half* __restrict
 #pragma unroll
                 for (int k = 0; k < KP; ++k) acc[k] = fma_t(x, wb[k], acc[k]);
             }
-#pragma unroll
-            for (int k = 0; k < KP; ++k)
-                if (k < K) {
-                    out[(size_t)k * n + p0 + t] = acc[k];
-                    mn[k] = fminf(mn[k], acc[k]); mx[k] = fmaxf(mx[k], acc[k]); sm[k] += (double)acc[k];
-                }
         }
     }
+    if (have) AVX_PUT()
+#undef AVX_PUT
+#undef AVX_FETCH
     block_stats_store<KP>(mn, mx, sm, K, partials);
 }
 
@@ -1281,12 +1325,17 @@ int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype,
         const size_t tiles = (n + kT - 1) / kT, cap = (size_t)ctx->num_cus * 8;
         g = (int)(tiles < cap ? tiles : cap);
         const __half* c = (const __half*)hsi;
-#define AVX_SPEC(KPV)                                                                                                                        \
+        // AVX_SPEC_PIPE=0 pins the plain (un-pipelined) tile loop
+        static const bool pipe_on = [] { const char* e = getenv("AVX_SPEC_PIPE"); return !(e && e[0] == '0'); }();
+        const int nv = !pipe_on ? 0 : B <= 32 ? 4 : B <= 88 ? 11 : 0;
+#define AVX_SPEC2(KPV, NVV)                                                                                                                  \
         {                                                                                                                                    \
-            AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_spectral_nhwc_h<KPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-            hipLaunchKernelGGL(k_spectral_nhwc_h<KPV>, dim3(g), dim3(kT), lds, s, c, n, B, dwT, K, out_planes, u.partials);                \
+            AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_spectral_nhwc_h<KPV, NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_spectral_nhwc_h<KPV, NVV>), dim3(g), dim3(kT), lds, s, c, n, B, dwT, K, out_planes, u.partials);           \
         }
+#define AVX_SPEC(KPV) { if (nv == 4) AVX_SPEC2(KPV, 4) else if (nv == 11) AVX_SPEC2(KPV, 11) else AVX_SPEC2(KPV, 0) }
         if (KP == 4) AVX_SPEC(4) else if (KP == 8) AVX_SPEC(8) else if (KP == 12) AVX_SPEC(12) else AVX_SPEC(16)
+#undef AVX_SPEC2
 #undef AVX_SPEC
     } else {
         float* dmat = nullptr;  // cached: uploaded only when the weights change
