@@ -1191,6 +1191,41 @@ int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, i
 
 // Host side of the recompute form: batches of up to kBeeMaxFrames frames share every launch.
 constexpr int kBeeMaxFrames = 32;
+// float16 NHWC cube -> K float32 planes + per-workgroup statistics through k_spectral_nhwc_h (the staged, HBM-rate kernel).  The grid is
+// grid_for(ctx, n) -- what k_finalize_stats is then told; same pixel-to-thread assignment and FMA order over b as k_spectral_integrate.
+static int launch_spectral_nhwc_h(avx_ctx* ctx, hipStream_t s, const __half* c, size_t n, int B, const float* weights_host, int K, float* out_planes,
+                                  Stat3* partials, int* g_out) {
+    const int KP = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : 16));
+    float wT[129 * 16];
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < KP; ++k) wT[b * KP + k] = k < K ? weights_host[(size_t)k * B + b] : 0.0f;
+    // weights are constants of the caller's pipeline: device copy + host mirror in constant slot 1 of the stream's workspace,
+    // compared byte for byte and re-uploaded (stream-ordered) only when they change (avx_const_upload)
+    avx_ws* wsp = avx_workspace(ctx, s);
+    if (!wsp) return AVX_ERR_NOMEM;
+    float* dwT = nullptr;
+    {
+        const int rcu = avx_const_upload(ctx, wsp, 1, wT, sizeof(float) * B * KP, s, (void**)&dwT);
+        if (rcu) return rcu;
+    }
+    const size_t lds = (size_t)kT * B * 2 + 16;
+    const int g = grid_for(ctx, n);
+    if (g_out) *g_out = g;
+    // AVX_SPEC_PIPE=0 pins the plain (un-pipelined) tile loop
+    static const bool pipe_on = [] { const char* e = getenv("AVX_SPEC_PIPE"); return !(e && e[0] == '0'); }();
+    const int nv = !pipe_on ? 0 : B <= 32 ? 4 : B <= 88 ? 11 : 0;
+#define AVX_SPEC2(KPV, NVV)                                                                                                                  \
+    {                                                                                                                                        \
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_spectral_nhwc_h<KPV, NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+        hipLaunchKernelGGL((k_spectral_nhwc_h<KPV, NVV>), dim3(g), dim3(kT), lds, s, c, n, B, dwT, K, out_planes, partials);                 \
+    }
+#define AVX_SPEC(KPV) { if (nv == 4) AVX_SPEC2(KPV, 4) else if (nv == 11) AVX_SPEC2(KPV, 11) else AVX_SPEC2(KPV, 0) }
+    if (KP == 4) AVX_SPEC(4) else if (KP == 8) AVX_SPEC(8) else if (KP == 12) AVX_SPEC(12) else AVX_SPEC(16)
+#undef AVX_SPEC2
+#undef AVX_SPEC
+    return AVX_OK;
+}
+
 static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n_frames, int H, int W, const avx_honeybee_desc* d, hipStream_t s) {
     const size_t n = (size_t)H * W;
     avx_ws* ws = avx_workspace(ctx, s);
@@ -1237,6 +1272,11 @@ static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_
             const size_t esz = d->hsi_dtype == 0 ? 4 : 2;
             for (int f = 0; f < F; ++f) {
                 const char* cube = (const char*)d->hsi + (size_t)(f0 + f) * n * d->bands * esz;
+                if (d->hsi_layout == 0 && d->hsi_dtype == 1 && ((uintptr_t)cube & 15u) == 0 && d->bands <= 129) {  // what an MST++-style model hands over
+                    const int rcs = launch_spectral_nhwc_h(ctx, s, (const __half*)cube, n, d->bands, d->weights_host, 3, raw + (size_t)f * 3 * n, partials + (size_t)f * g * 3, nullptr);
+                    if (rcs) return rcs;
+                    continue;
+                }
                 hipLaunchKernelGGL(k_spectral_integrate<3>, dim3(g), dim3(kT), sizeof(float) * 3 * d->bands, s, (const void*)cube, d->hsi_layout, d->hsi_dtype, n,
                                    d->bands, mat, 3, raw + (size_t)f * 3 * n, partials + (size_t)f * g * 3);
             }
@@ -1308,35 +1348,7 @@ int avx_spectral_integrate(avx_ctx* ctx, const void* hsi, int layout, int dtype,
     const size_t n = (size_t)H * W;
     int g = grid_for(ctx, n);
     if (layout == 0 && dtype == 1 && ((uintptr_t)hsi & 15u) == 0) {  // float16 NHWC: the staged, HBM-rate kernel
-        const int KP = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : 16));
-        float wT[129 * 16];
-        for (int b = 0; b < B; ++b)
-            for (int k = 0; k < KP; ++k) wT[b * KP + k] = k < K ? weights_host[(size_t)k * B + b] : 0.0f;
-        // weights are constants of the caller's pipeline: device copy + host mirror in constant slot 1 of the stream's workspace,
-        // compared byte for byte and re-uploaded (stream-ordered) only when they change (avx_const_upload)
-        avx_ws* wsp = avx_workspace(ctx, s);
-        if (!wsp) return AVX_ERR_NOMEM;
-        float* dwT = nullptr;
-        {
-            const int rcu = avx_const_upload(ctx, wsp, 1, wT, sizeof(float) * B * KP, s, (void**)&dwT);
-            if (rcu) return rcu;
-        }
-        const size_t lds = (size_t)kT * B * 2 + 16;
-        const size_t tiles = (n + kT - 1) / kT, cap = (size_t)ctx->num_cus * 8;
-        g = (int)(tiles < cap ? tiles : cap);
-        const __half* c = (const __half*)hsi;
-        // AVX_SPEC_PIPE=0 pins the plain (un-pipelined) tile loop
-        static const bool pipe_on = [] { const char* e = getenv("AVX_SPEC_PIPE"); return !(e && e[0] == '0'); }();
-        const int nv = !pipe_on ? 0 : B <= 32 ? 4 : B <= 88 ? 11 : 0;
-#define AVX_SPEC2(KPV, NVV)                                                                                                                  \
-        {                                                                                                                                    \
-            AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_spectral_nhwc_h<KPV, NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((k_spectral_nhwc_h<KPV, NVV>), dim3(g), dim3(kT), lds, s, c, n, B, dwT, K, out_planes, u.partials);           \
-        }
-#define AVX_SPEC(KPV) { if (nv == 4) AVX_SPEC2(KPV, 4) else if (nv == 11) AVX_SPEC2(KPV, 11) else AVX_SPEC2(KPV, 0) }
-        if (KP == 4) AVX_SPEC(4) else if (KP == 8) AVX_SPEC(8) else if (KP == 12) AVX_SPEC(12) else AVX_SPEC(16)
-#undef AVX_SPEC2
-#undef AVX_SPEC
+        if ((rc = launch_spectral_nhwc_h(ctx, s, (const __half*)hsi, n, B, weights_host, K, out_planes, u.partials, &g))) return rc;
     } else {
         float* dmat = nullptr;  // cached: uploaded only when the weights change
         { avx_ws* wsc = avx_workspace(ctx, s); if (!wsc) return AVX_ERR_NOMEM; const int rcu = avx_const_upload(ctx, wsc, 0, weights_host, sizeof(float) * K * B, s, (void**)&dmat); if (rcu) return rcu; }
@@ -1471,8 +1483,12 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
         } else {
             const size_t esz = d->hsi_dtype == 0 ? 4 : 2;
             const char* cube = (const char*)d->hsi + (size_t)f * n * d->bands * esz;
-            hipLaunchKernelGGL(k_spectral_integrate<3>, dim3(g), dim3(kT), sizeof(float) * 3 * d->bands, s, (const void*)cube, d->hsi_layout, d->hsi_dtype, n,
-                               d->bands, u.mat, 3, raw, u.partials);
+            if (d->hsi_layout == 0 && d->hsi_dtype == 1 && ((uintptr_t)cube & 15u) == 0 && d->bands <= 129) {  // what an MST++-style model hands over
+                if ((rc = launch_spectral_nhwc_h(ctx, s, (const __half*)cube, n, d->bands, d->weights_host, 3, raw, u.partials, nullptr))) return rc;
+            } else {
+                hipLaunchKernelGGL(k_spectral_integrate<3>, dim3(g), dim3(kT), sizeof(float) * 3 * d->bands, s, (const void*)cube, d->hsi_layout, d->hsi_dtype, n,
+                                   d->bands, u.mat, 3, raw, u.partials);
+            }
         }
         // 4) von Kries denominators
         hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(1024), 0, s, u.partials, g, 3, n, d->adaptation, d->eps, u.stats);
