@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "dichromat_common.h"
+#include "stack_up.h"
 
 using namespace avxk;
 
@@ -33,10 +34,9 @@ __global__ __launch_bounds__(kGT) void k_resize_linear_f32(const float* __restri
         const float a1 = ax.f[x], a0 = 1.f - a1, b1 = ay.f[y], b0 = 1.f - b1;
         const float* S0 = src + ((size_t)sy0 * W + sx) * C + c;
         const float* S1 = src + ((size_t)sy1 * W + sx) * C + c;
-        float r0, r1;
-        if (x < ax.dmax) { r0 = S0[0] * a0 + S0[C] * a1; r1 = S1[0] * a0 + S1[C] * a1; }
-        else { r0 = S0[0] * 1.f; r1 = S1[0] * 1.f; }
-        dst[i] = r0 * b0 + r1 * b1;
+        const bool inner = x < ax.dmax;
+        const int o = inner ? C : 0;
+        dst[i] = stack_lerp(S0[0], S0[o], S1[0], S1[o], a0, a1, b0, b1, inner);  // stack_up.h: the one statement of this arithmetic
     }
 }
 
@@ -403,6 +403,19 @@ int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int ne
     ax.a += 4 * (size_t)start;
     hipLaunchKernelGGL(k_resize_cubic_f32, dim3(grid_for(ctx, (size_t)H * W * 3)), dim3(kGT), 0, s, src, H, W, 3, dst, H, W, ax, ay);
     AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+// The INTER_LINEAR tables of an H x W -> Hd x Wd resize, for kernels that recompute resized values instead of reading a
+// materialised copy (stack_up.h); same cache, same lifetime rules as avx_resize_hwc's own lookups.
+int avx_geom_linear_tables(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int H, int W, int Hd, int Wd, avx_lin_tab* ax, avx_lin_tab* ay) {
+    TableCache tc{ctx, ws, s};
+    int rc = tc.room();
+    if (rc) return rc;
+    AxisLin x{}, y{};
+    if ((rc = tc.lin(W, Wd, &x)) || (rc = tc.lin(H, Hd, &y))) return rc;
+    *ax = avx_lin_tab{x.ofs, x.f, x.dmax};
+    *ay = avx_lin_tab{y.ofs, y.f, y.dmax};
     return AVX_OK;
 }
 

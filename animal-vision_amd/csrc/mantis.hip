@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "dichromat_common.h"
+#include "stack_up.h"
 
 using namespace avxk;
 
@@ -18,6 +19,8 @@ extern "C" int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, i
 extern "C" int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
 int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s);
 int avx_geom_cache_trim(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int limit);
+int avx_geom_linear_tables(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int H, int W, int Hd, int Wd, avx_lin_tab* ax, avx_lin_tab* ay);
+int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, double* out_dev, hipStream_t s);
 
 namespace {
 
@@ -105,6 +108,34 @@ __global__ __launch_bounds__(kMT) void k_stack_minmax(const float* __restrict__ 
         partial[(size_t)blockIdx.x * K + threadIdx.x] = make_float2(a, b);
     }
 }
+// the same over a stack that exists only at reduced size: every pixel's K resized values are recomputed (stack_up.h), nothing is written
+template <int K>
+__global__ __launch_bounds__(kMT) void k_up_minmax(const StackUp u, size_t cap_floats, float2* __restrict__ partial) {
+    __shared__ float smn[kMT / 64][KMAX], smx[kMT / 64][KMAX];
+    float mn[KMAX], mx[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { mn[k] = 3.4e38f; mx[k] = -3.4e38f; }
+    extern __shared__ float tile_lds[];
+    stack_tiles<K, false>(u, tile_lds, cap_floats, [&](int, int, float (&v)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+    });
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < u.K) {
+            float a = mn[k], b = mx[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+            if (lane == 0) { smn[wave][k] = a; smx[wave][k] = b; }
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < u.K) {
+        float a = smn[0][threadIdx.x], b = smx[0][threadIdx.x];
+        for (int w = 1; w < kMT / 64; ++w) { a = fminf(a, smn[w][threadIdx.x]); b = fmaxf(b, smx[w][threadIdx.x]); }
+        partial[(size_t)blockIdx.x * u.K + threadIdx.x] = make_float2(a, b);
+    }
+}
 __global__ void k_stack_minmax_final(const float2* partial, int nblocks, int K, float2* mm) {
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= K) return;
@@ -122,34 +153,55 @@ __global__ __launch_bounds__(kMT) void k_stack_safe_norm(float* __restrict__ S, 
     }
 }
 
-struct BarcodeArgs { const float* S; size_t n; int K; const double* p95; float lut[KMAX * 3]; float wtm, sat; float* bar /*3 planes*/; float* broad; };
-// mantis_shrimp.py:199-211,224: S_norm, argmax, soft/hard tint, saturation; broad = mean(S_norm)
-__global__ __launch_bounds__(kMT) void k_barcode(BarcodeArgs a) {
-    const float den = (float)a.p95[0] + 1e-8f;
-    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
-        float sn[KMAX];
-        float sum = 0.f, best = -1.f;
-        int arg = 0;
-        for (int k = 0; k < a.K; ++k) {
-            sn[k] = clip01f(a.S[p * a.K + k] / den);
+struct BarcodeArgs { const float* S; size_t n; int K; const double* p95; float lut[KMAX * 3]; float wtm, sat; float* bar /*3 planes*/; float* broad;
+                     StackUp up; /* S == NULL: the normalised stack is read through its resize (stack_up.h) */ };
+// mantis_shrimp.py:199-211,224: S_norm, argmax, soft/hard tint, saturation; broad = mean(S_norm).  sn: the pixel's K safe-normed
+// band values on entry.  Fully unrolled over KMAX with k < K predicates (the arrays stay in registers), the argmax band's LUT row is
+// carried along instead of being indexed afterwards.
+template <int KT>
+__device__ __forceinline__ void barcode_pixel(const BarcodeArgs& a, size_t p, float (&sn)[KT], float den) {
+    float sum = 0.f, best = -1.f;
+    float hard[3] = {a.lut[0], a.lut[1], a.lut[2]};
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+        if (KT < KMAX || k < a.K) {
+            sn[k] = clip01f(sn[k] / den);
             sum += sn[k];
-            if (sn[k] > best) { best = sn[k]; arg = k; }  // np.argmax: first maximum
+            if (sn[k] > best) { best = sn[k]; hard[0] = a.lut[3 * k]; hard[1] = a.lut[3 * k + 1]; hard[2] = a.lut[3 * k + 2]; }  // np.argmax: first maximum
         }
-        const float wden = sum + 1e-8f;
-        float soft[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < a.K; ++k) {
+    const float wden = sum + 1e-8f;
+    float soft[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+        if (KT < KMAX || k < a.K) {
             const float w = sn[k] / wden;
 #pragma unroll
             for (int c = 0; c < 3; ++c) soft[c] = fma_t(w, a.lut[3 * k + c], soft[c]);
         }
-        float bc[3];
+    float bc[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) bc[c] = (1.0f - a.wtm) * soft[c] + a.wtm * a.lut[3 * arg + c];
-        const float Yb = (0.2126f * bc[0] + 0.7152f * bc[1]) + 0.0722f * bc[2];
+    for (int c = 0; c < 3; ++c) bc[c] = (1.0f - a.wtm) * soft[c] + a.wtm * hard[c];
+    const float Yb = (0.2126f * bc[0] + 0.7152f * bc[1]) + 0.0722f * bc[2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.bar[(size_t)c * a.n + p] = clip01f(Yb + (bc[c] - Yb) * (1.0f + a.sat));
-        a.broad[p] = sum / (float)a.K;
+    for (int c = 0; c < 3; ++c) a.bar[(size_t)c * a.n + p] = clip01f(Yb + (bc[c] - Yb) * (1.0f + a.sat));
+    a.broad[p] = sum / (float)a.K;
+}
+__global__ __launch_bounds__(kMT) void k_barcode(BarcodeArgs a) {
+    const float den = (float)a.p95[0] + 1e-8f;
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
+        float sn[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < a.K) sn[k] = a.S[p * a.K + k];
+        barcode_pixel<KMAX>(a, p, sn, den);
     }
+}
+// the same with the normalised stack read through its resize, tile by tile (stack_up.h)
+template <int K>
+__global__ __launch_bounds__(kMT) void k_barcode_up(BarcodeArgs a, size_t cap_floats) {
+    extern __shared__ float tile_lds[];
+    const float den = (float)a.p95[0] + 1e-8f;
+    stack_tiles<K, true>(a.up, tile_lds, cap_floats, [&](int x, int y, float (&v)[K]) { barcode_pixel<K>(a, (size_t)y * a.up.W + x, v, den); });
 }
 
 // :214-218 render = baseline_lin with red kill and haze, HWC -> 3 planes
@@ -416,22 +468,53 @@ extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_b
     float* out_f = d->out_float ? reinterpret_cast<float*>(out_hwc) : nullptr;
     hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, baseline, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_base_hwc, base_f);
     // 3-4) RGB->HSI (optionally at reduced size) folded with the band windows -> HxWxK stack, safe_norm per band
-    if (hs != H || wsm != W) {
+    // AVX_MANTIS_UP=0 pins the materialised H x W x K stack on the reduced-size route too (A/B)
+    const char* up_env = getenv("AVX_MANTIS_UP");  // read per call: tests flip it
+    const bool virt = (hs != H || wsm != W) && !(up_env && up_env[0] == '0') && stack_k_tiled(K);
+    BarcodeArgs b{};
+    if (virt) {
+        // reduced-size route: the resized stack is never built -- min/max, the percentile's three passes and the barcode recompute
+        // each pixel's K values from the (cache-resident) small stack: five cheap passes instead of 83 MB written once and read seven times
         if ((rc = avx_resize_hwc(ctx, baseline, 0, H, W, 3, small, hs, wsm, 3, s))) return rc;
         hipLaunchKernelGGL(k_rgbf_to_stack, dim3(grid_for(ctx, nsmall)), dim3(kMT), 0, s, StackArgs{small, nsmall, dM, K, B, dgains, d->lobe_denom, dwts, sstack});
-        if ((rc = avx_resize_hwc(ctx, sstack, 0, hs, wsm, K, stack, H, W, 1, s))) return rc;
+        StackUp up{};
+        up.S = sstack; up.hs = hs; up.ws = wsm; up.H = H; up.W = W; up.K = K; up.mm = nullptr;
+        if ((rc = avx_geom_linear_tables(ctx, ws, s, hs, wsm, H, W, &up.ax, &up.ay))) return rc;
+        const size_t cap_floats = stack_tile_floats(hs, wsm, H, W, K), tile_lds = cap_floats * sizeof(float);
+        AVX_REQUIRE(ctx, tile_lds <= 96 * 1024, "mantis: the source rectangle of a 64 x 16 tile does not fit LDS (%zu bytes)", tile_lds);
+        AVX_STACK_K_SWITCH(K, AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_up_minmax<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds)))
+        AVX_STACK_K_SWITCH(K, AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_barcode_up<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds)))
+        const long up_tiles = (long)((W + kUpTW - 1) / kUpTW) * ((H + kUpTH - 1) / kUpTH), up_cap = (long)ctx->num_cus * 4;  // workgroups walk tiles: the per-workgroup epilogue is paid 1,024 times, not 4,096
+        const int gu = (int)(up_tiles < up_cap ? up_tiles : up_cap);
+        AVX_STACK_K_SWITCH(K, hipLaunchKernelGGL(k_up_minmax<KT>, dim3(gu), dim3(kMT), tile_lds, s, up, cap_floats, part))
+        hipLaunchKernelGGL(k_stack_minmax_final, dim3(1), dim3(1024), 0, s, part, gu, K, mm);
+        up.mm = mm;
+        if ((rc = avx_uv_percentile_up_device(ctx, up, 95.0, pct, s))) return rc;
+        b.S = nullptr; b.up = up;
     } else {
-        hipLaunchKernelGGL(k_rgbf_to_stack, dim3(g), dim3(kMT), 0, s, StackArgs{baseline, n, dM, K, B, dgains, d->lobe_denom, dwts, stack});
+        if (hs != H || wsm != W) {
+            if ((rc = avx_resize_hwc(ctx, baseline, 0, H, W, 3, small, hs, wsm, 3, s))) return rc;
+            hipLaunchKernelGGL(k_rgbf_to_stack, dim3(grid_for(ctx, nsmall)), dim3(kMT), 0, s, StackArgs{small, nsmall, dM, K, B, dgains, d->lobe_denom, dwts, sstack});
+            if ((rc = avx_resize_hwc(ctx, sstack, 0, hs, wsm, K, stack, H, W, 1, s))) return rc;
+        } else {
+            hipLaunchKernelGGL(k_rgbf_to_stack, dim3(g), dim3(kMT), 0, s, StackArgs{baseline, n, dM, K, B, dgains, d->lobe_denom, dwts, stack});
+        }
+        hipLaunchKernelGGL(k_stack_minmax, dim3(g), dim3(kMT), 0, s, stack, n, K, part);
+        hipLaunchKernelGGL(k_stack_minmax_final, dim3(1), dim3(1024), 0, s, part, g, K, mm);
+        hipLaunchKernelGGL(k_stack_safe_norm, dim3(grid_for(ctx, n * K)), dim3(kMT), 0, s, stack, n, K, mm);
+        // 5-6) barcode
+        if ((rc = avx_uv_percentile_device(ctx, stack, n * K, 95.0, pct, s))) return rc;
+        b.S = stack;
     }
-    hipLaunchKernelGGL(k_stack_minmax, dim3(g), dim3(kMT), 0, s, stack, n, K, part);
-    hipLaunchKernelGGL(k_stack_minmax_final, dim3(1), dim3(1024), 0, s, part, g, K, mm);
-    hipLaunchKernelGGL(k_stack_safe_norm, dim3(grid_for(ctx, n * K)), dim3(kMT), 0, s, stack, n, K, mm);
-    // 5-6) barcode
-    if ((rc = avx_uv_percentile_device(ctx, stack, n * K, 95.0, pct, s))) return rc;
-    BarcodeArgs b{};
-    b.S = stack; b.n = n; b.K = K; b.p95 = pct; b.wtm = d->winner_take_most; b.sat = d->barcode_saturation; b.bar = bar; b.broad = broad;
+    b.n = n; b.K = K; b.p95 = pct; b.wtm = d->winner_take_most; b.sat = d->barcode_saturation; b.bar = bar; b.broad = broad;
     for (int i = 0; i < K * 3; ++i) b.lut[i] = d->band_lut_host[i];
-    hipLaunchKernelGGL(k_barcode, dim3(g), dim3(kMT), 0, s, b);
+    if (virt) {
+        const size_t cap_floats = stack_tile_floats(hs, wsm, H, W, K);
+        const long up_tiles = (long)((W + kUpTW - 1) / kUpTW) * ((H + kUpTH - 1) / kUpTH), up_cap = (long)ctx->num_cus * 4;
+        AVX_STACK_K_SWITCH(K, hipLaunchKernelGGL(k_barcode_up<KT>, dim3((unsigned)(up_tiles < up_cap ? up_tiles : up_cap)), dim3(kMT), cap_floats * sizeof(float), s, b, cap_floats))
+    } else {
+        hipLaunchKernelGGL(k_barcode, dim3(g), dim3(kMT), 0, s, b);
+    }
     // 7) clear-water look
     hipLaunchKernelGGL(k_prep_render, dim3(g), dim3(kMT), 0, s, baseline, n, d->red_keep, d->haze, d->haze_keep, make_float3(d->haze_tint[0], d->haze_tint[1], d->haze_tint[2]), P0);
     float* render = P0;

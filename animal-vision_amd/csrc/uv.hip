@@ -16,6 +16,7 @@
 #include <hip/hip_fp16.h>
 
 #include "dichromat_common.h"
+#include "stack_up.h"
 
 using namespace avxk;
 
@@ -909,6 +910,53 @@ __device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int 
     __syncthreads();
 }
 
+// One radix pass over the values of a band stack that only exists at reduced size (stack_up.h): every thread recomputes the K
+// resized + normalised values of its pixels and histograms them; flush, ticket and pick as in k_sel_pass (one job).
+struct SelUpArgs { StackUp u; size_t cap_floats; int pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket; unsigned long long rank0; float gamma; int has_next; double* out; };
+template <int K>
+__global__ __launch_bounds__(kT) void k_sel_pass_up(const SelUpArgs a) {
+    __shared__ uint32_t h[2048];
+    __shared__ uint32_t wmin[kT / 64];
+    __shared__ int is_last;
+    const int nb = 1 << a.bits, t = threadIdx.x;
+    const bool last_pass = a.pass == 2, find_next = last_pass && a.has_next;
+    for (int i = t; i < 2048; i += kT) h[i] = 0;
+    const uint32_t prefix = a.pass == 0 ? 0u : a.st->prefix, mask = a.pass == 0 ? 0u : a.st->mask;
+    const uint32_t above = prefix | ~mask;
+    uint32_t best = 0xffffffffu;
+    __syncthreads();
+    extern __shared__ float tile_lds[];
+    stack_tiles<K, true>(a.u, tile_lds, a.cap_floats, [&](int, int, float (&v)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t key = f2key(v[k]);
+            if ((key & mask) == prefix) atomicAdd(&h[(key >> a.shift) & (nb - 1)], 1u);
+            else if (find_next && key > above && key < best) best = key;
+        }
+    });
+    if (find_next) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(best, o); best = w < best ? w : best; }
+        __syncthreads();
+        if ((t & 63) == 0) wmin[t >> 6] = best;
+        __syncthreads();
+        if (t == 0) {
+            for (int w = 1; w < kT / 64; ++w) best = wmin[w] < best ? wmin[w] : best;
+            if (best != 0xffffffffu) atomicMin(&a.st->next_above, best);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < nb; i += kT)
+        if (h[i]) atomicAdd(&a.hist[i], h[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    sel_pick(a.hist, a.st, a.pass, a.shift, a.bits, a.rank0, a.gamma, a.has_next, a.out);
+    if (t == 0) *a.ticket = 0;
+}
+
 // SRC: 0 uint8 frames (decode table + K x 3 matrix), 1 raw catch planes.  R: blur radius 0 | 1.  STAGE: 0 one radix-select pass
 // (NJ order statistics per frame), 1 map + encode.
 template <int SRC, int R, int STAGE, int NJ>
@@ -1169,6 +1217,35 @@ int avx_uv_percentile_device(avx_ctx* ctx, const float* x, size_t n, double q, d
     int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
     return run_percentile(ctx, u, x, n, q, out_dev, s);
+}
+
+// np.percentile(q) over the H x W x K values of a reduced-size band stack read through its resize (+ safe_norm): stack_up.h
+int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, double* out_dev, hipStream_t s) {
+    UvScratch u;
+    int rc = uv_small_scratch(ctx, s, &u);
+    if (rc) return rc;
+    const size_t n = (size_t)up.H * up.W * up.K;
+    const float vi = (float)(n - 1) * ((float)q / 100.0f);  // as run_percentiles
+    float lo = floorf(vi);
+    if (lo < 0) lo = 0;
+    if (lo > (float)(n - 1)) lo = (float)(n - 1);
+    SelUpArgs a{};
+    a.u = up; a.st = u.sel; a.hist = u.hist; a.ticket = u.ticket; a.rank0 = (unsigned long long)lo; a.gamma = vi - lo; a.has_next = (size_t)lo + 1 < n ? 1 : 0; a.out = out_dev;
+    static_assert(kT == 256, "AVX_STACK_TILES assumes 256 threads");
+    const size_t tiles = (size_t)((up.W + kUpTW - 1) / kUpTW) * ((up.H + kUpTH - 1) / kUpTH), cap = (size_t)ctx->num_cus * 4;
+    const int g = (int)(tiles < cap ? (tiles ? tiles : 1) : cap);
+    a.cap_floats = stack_tile_floats(up.hs, up.ws, up.H, up.W, up.K);
+    const size_t lds = a.cap_floats * sizeof(float);
+    AVX_REQUIRE(ctx, lds <= 96 * 1024, "percentile through a resized stack: the tile's source rectangle does not fit LDS (%zu bytes)", lds);
+    AVX_REQUIRE(ctx, stack_k_tiled(up.K) && up.mm, "percentile through a resized stack: K=%d is not instantiated / no min-max table", up.K);
+    AVX_STACK_K_SWITCH(up.K, AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sel_pass_up<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)))
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int p = 0; p < 3; ++p) {
+        a.pass = p; a.shift = shifts[p]; a.bits = bits[p];
+        AVX_STACK_K_SWITCH(up.K, hipLaunchKernelGGL(k_sel_pass_up<KT>, dim3(g), dim3(kT), lds, s, a))
+    }
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
 }
 
 int avx_uv_percentiles_device(avx_ctx* ctx, int count, const float* const* x, const size_t* n, const double* q, double* const* out_dev, hipStream_t s) {

@@ -501,6 +501,8 @@ class Workload:
 
                 rerun = lambda seed: np_backend.run_jittered(self.uv_obj, self.pool[0], seed)[1]  # noqa: E731
             st = outlier_stats(got[0], want, rerun, runs=3)
+            if st.get("unexplained_px", 0):  # a handful of pixels in 8 MP: three jitter draws miss some ties that ten find
+                st = outlier_stats(got[0], want, rerun, runs=10)
             ok = st["frac_ne"] <= 0.05 and st["frac_gt1"] <= 2e-3 and st["outlier_px"] <= 16 + 1e-3 * st["pixels"] and st.get("unexplained_px", 0) == 0
             return bool(ok), st
         dd = np.abs(got[0].astype(np.int16) - want.astype(np.int16))

@@ -76,3 +76,18 @@ def test_mantis_rejects_non_numeric_and_bad_panorama():
         MantisShrimp().visualize(np.zeros((8, 8, 3), np.int32))
     with pytest.raises(ValueError):
         MantisShrimp(panorama_scale=0.8).visualize(np.zeros((16, 16, 3), np.uint8))
+
+
+def test_mantis_reduced_stack_read_through_its_resize_equals_the_materialised_stack(monkeypatch):
+    """hsi_scale < 1: min/max, the 95th percentile and the barcode recompute each pixel's K band values from the small stack
+    (csrc/stack_up.h) instead of reading a resized H x W x K copy -- same arithmetic, so the frames must be identical."""
+    from animal_vision_amd.animals import MantisShrimp
+    from animal_vision_amd.synthetic import noise_frame, structured_frame
+
+    for frame, kw in ((structured_frame(3, 270, 484), {}), (noise_frame(4, 133, 201), dict(hsi_scale=0.5, panorama_scale=1.2)), (structured_frame(5, 1080, 1920), {})):
+        m = MantisShrimp(**kw)
+        monkeypatch.setenv("AVX_MANTIS_UP", "0")
+        base0, out0 = m.visualize(frame)
+        monkeypatch.setenv("AVX_MANTIS_UP", "1")
+        base1, out1 = m.visualize(frame)
+        assert np.array_equal(base0, base1) and np.array_equal(out0, out1), (frame.shape, kw, int(np.abs(out0.astype(int) - out1.astype(int)).max()))

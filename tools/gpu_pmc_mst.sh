@@ -27,7 +27,7 @@ for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive
     for r in rows:
         byk[r["Kernel_Name"]].append(r)
     for k, rs in byk.items():
-        if not any(t in k for t in ("k_mst_", "k_dwconv", "k_ew", "k_sel_pass", "k_plane_blur", "streak", "k_spectral", "k_bee", "dichromat", "k_mantis")):
+        if not any(t in k for t in ("k_mst_", "k_dwconv", "k_ew", "k_sel_pass", "k_plane_blur", "streak", "k_spectral", "k_bee", "dichromat", "k_mantis", "k_up_", "k_barcode", "k_stack")):
             continue
         ids = sorted({int(r["Dispatch_Id"]) for r in rs})
         keep = set(ids[len(ids) * 2 // 3:])
