@@ -36,7 +36,7 @@ for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive
         for r in rs:
             if int(r["Dispatch_Id"]) in keep:
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-# HBM traffic of ONE frame of the route: FETCH_SIZE / WRITE_SIZE (KB) summed over every dispatch between the last two k_map_encode
+# HBM traffic of ONE frame of the route: FETCH_SIZE / WRITE_SIZE (KB) summed over every dispatch between two consecutive k_map_encode
 # launches (one per frame); bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: gfx950 tallies 128-B reads as 64 B)
 tot = {}
 for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive=True):
@@ -46,7 +46,10 @@ for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     marks = [i for i, r in enumerate(rows) if "k_map_encode" in r["Kernel_Name"]]
     if len(marks) >= 2:
-        win = rows[marks[-2] + 1: marks[-1] + 1]
+        # a steady frame: the window after the warm-up frame's mark (the LAST window also holds bench.py's own 20 extra launches of the
+        # dominant kernel and the parity check's forward pass)
+        lo, hi = (marks[1], marks[2]) if len(marks) >= 3 else (marks[-2], marks[-1])
+        win = rows[lo + 1: hi + 1]
         tot[rows[0]["Counter_Name"]] = sum(float(r["Counter_Value"]) for r in win)
         per = collections.defaultdict(float)
         for r in win:
