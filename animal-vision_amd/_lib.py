@@ -238,6 +238,7 @@ _SIGS = {
                                  ctypes.POINTER(ctypes.c_void_p), _vp]),
     "avx_ew_run": (_i, [_vp, ctypes.POINTER(EwProgram), _vp]),
     "avx_mantis_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, ctypes.POINTER(MantisDesc), _vp]),
+    "avx_mantis_u8_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(MantisDesc), _vp]),
     "avx_resize_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "avx_binocular_warp_u8": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "avx_split_compose_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -173,6 +173,14 @@ class MantisShrimp(Animal):
         d, _keep = self._desc(H, W)
         ctx._check(lib.avx_mantis_u8(ctx._h, d_in.ptr, d_base.ptr, d_out.ptr, H, W, ctypes.byref(d), ctx._s(stream)))
 
+    def run_device_batch(self, d_in: DeviceBuffer, d_base: DeviceBuffer, d_out: DeviceBuffer, n_frames: int, H: int, W: int, stream=None):
+        """n_frames contiguous uint8 frames (baselines / outputs contiguous too): independent frames overlap on the library's lanes."""
+        if self.ctx is None:
+            self.ctx = get_context()
+        ctx = self.ctx
+        d, _keep = self._desc(H, W)
+        ctx._check(lib.avx_mantis_u8_batch(ctx._h, d_in.ptr, d_base.ptr, d_out.ptr, n_frames, H, W, ctypes.byref(d), ctx._s(stream)))
+
     def _visualize_float(self, image: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """Float frames (same-dtype contract): to_float01's `max > 1.001` rule and srgb_to_linear run as a plane program
         (a frame-wide reduction decides the /255), the fused stack takes the linear frame and writes float32 sRGB."""

@@ -407,15 +407,58 @@ extern "C" int avx_percentile_dev(avx_ctx* ctx, const float* data_dev, size_t n,
     return avx_uv_percentile_device(ctx, data_dev, n, q, out_dev, avx_pick_stream(ctx, stream));
 }
 
-extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d, void* stream) {
-    if (!ctx) return AVX_ERR_INVALID;
+static int mantis_check(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d) {
     AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_mantis_desc), "avx_mantis_u8: desc is NULL or struct_size mismatch");
     AVX_REQUIRE(ctx, (in_hwc || d->lin_hwc_in) && out_base_hwc && out_hwc && H > 0 && W > 0, "avx_mantis_u8: bad arguments");
     AVX_REQUIRE(ctx, d->n_bands >= 1 && d->n_bands <= KMAX && d->band_matrix_host && d->band_lut_host, "avx_mantis_u8: bad band tables");
     AVX_REQUIRE(ctx, d->n_wavelengths >= 1 && d->lobe_gains_host && d->band_weights_host && d->lobe_denom > 0.f, "avx_mantis_u8: per-wavelength tables missing");
     AVX_REQUIRE(ctx, d->rows_host && d->xx_host && d->yy_host, "avx_mantis_u8: row/column tables missing");
+    return AVX_OK;
+}
+static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d, hipStream_t s);
+
+extern "C" int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    const int rc = mantis_check(ctx, in_hwc, out_base_hwc, out_hwc, H, W, d);
+    if (rc) return rc;
     AVX_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = avx_pick_stream(ctx, stream);
+    return mantis_frame(ctx, in_hwc, out_base_hwc, out_hwc, H, W, d, avx_pick_stream(ctx, stream));
+}
+
+// N uint8 frames (contiguous, H*W*3 each): the frames of a batch do not depend on each other, so they run on up to four "lanes"
+// (streams of the context, each with its own workspace) forked from and joined back into `stream` -- a frame is ~25 dependent
+// launches of 5-50 us at 1080p, most of them too small to fill the device on their own.  AVX_MANTIS_LANES=1 pins one lane.
+extern "C" int avx_mantis_u8_batch(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int n_frames, int H, int W,
+                                   const avx_mantis_desc* d, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, n_frames > 0 && in_hwc, "avx_mantis_u8_batch: n_frames must be positive and the frames uint8");
+    int rc = mantis_check(ctx, in_hwc, out_base_hwc, out_hwc, H, W, d);
+    if (rc) return rc;
+    AVX_REQUIRE(ctx, d->lin_hwc_in == nullptr && !d->out_float, "avx_mantis_u8_batch: uint8 frames only");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s0 = avx_pick_stream(ctx, stream);
+    const char* le = getenv("AVX_MANTIS_LANES");
+    int want = le ? atoi(le) : 4;
+    want = want < 1 ? 1 : (want > n_frames ? n_frames : want);
+    const int n_lanes = want > 1 ? avx_lanes(ctx, want) : 0;
+    if (n_lanes > 1) {
+        AVX_HIP(ctx, hipEventRecord(ctx->lane_fork, s0));
+        for (int l = 0; l < n_lanes; ++l) AVX_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l], ctx->lane_fork, 0));
+    }
+    const size_t fb = (size_t)H * W * 3;
+    for (int f = 0; f < n_frames; ++f) {
+        hipStream_t s = n_lanes > 1 ? ctx->lanes[f % n_lanes] : s0;
+        if ((rc = mantis_frame(ctx, in_hwc + f * fb, out_base_hwc + f * fb, out_hwc + f * fb, H, W, d, s))) return rc;
+    }
+    if (n_lanes > 1)
+        for (int l = 0; l < n_lanes; ++l) {
+            AVX_HIP(ctx, hipEventRecord(ctx->lane_done[l], ctx->lanes[l]));
+            AVX_HIP(ctx, hipStreamWaitEvent(s0, ctx->lane_done[l], 0));
+        }
+    return AVX_OK;
+}
+
+static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_hwc, uint8_t* out_hwc, int H, int W, const avx_mantis_desc* d, hipStream_t s) {
     avx_ws* ws = avx_workspace(ctx, s);
     if (!ws) return AVX_ERR_NOMEM;
     const int K = d->n_bands;

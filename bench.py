@@ -209,16 +209,14 @@ class Workload:
                     ctx._check(lib.avx_spectral_integrate(ctx._h, d_cube.ptr, 0, 1, H, W, Bn, wts.ctypes.data, Kp,
                                                           d_planes.ptr + 4 * Kp * H * W * (j % min(B, 4)), None, stream))
         elif self.uvsp:
-            self.d_base = ctx.malloc(pool[0].nbytes)
+            self.d_base = ctx.malloc(pool[0].nbytes * (B if species == "mantis" else 1))
             if species == "mantis":
                 uv_obj = self.uv_obj = animals.MantisShrimp()
                 uv_obj.ctx = ctx
-                frame_bytes = pool[0].nbytes
                 d_in, d_base, d_out = self.d_in, self.d_base, self.d_out
 
-                def run_step():
-                    for j in range(B):
-                        uv_obj.run_device(d_in.view(j * frame_bytes, frame_bytes), d_base, d_out.view(j * frame_bytes, frame_bytes), H, W, stream)
+                def run_step():  # the step's frames in one call: independent frames overlap on the library's lanes (avx_mantis_u8_batch)
+                    uv_obj.run_device_batch(d_in, d_base, d_out, B, H, W, stream)
             else:
                 uv_obj = self.uv_obj = getattr(animals, animals.UV_CLASS[species[3:]])()
                 variant = "day" if species == "uv:rat_uv" else None

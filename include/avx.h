@@ -244,6 +244,10 @@ typedef struct avx_mantis_desc {
 
 int avx_mantis_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_baseline_hwc, uint8_t* out_hwc, int H, int W,
                   const avx_mantis_desc* desc, void* stream);
+/* The same for n_frames contiguous uint8 frames (baselines and outputs contiguous too): independent frames run on up to four
+ * internal streams forked from / joined into `stream` (renderers/video.py's frame loop hands the library a batch). */
+int avx_mantis_u8_batch(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_baseline_hwc, uint8_t* out_hwc, int n_frames, int H, int W,
+                        const avx_mantis_desc* desc, void* stream);
 
 /* ---- stages of the other UV species, each on device pointers so that a species is a sequence of asynchronous
  * calls on one stream (animal-vision_amd/planevm.py) --------------------------------------------------------- */

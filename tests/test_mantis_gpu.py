@@ -91,3 +91,33 @@ def test_mantis_reduced_stack_read_through_its_resize_equals_the_materialised_st
         monkeypatch.setenv("AVX_MANTIS_UP", "1")
         base1, out1 = m.visualize(frame)
         assert np.array_equal(base0, base1) and np.array_equal(out0, out1), (frame.shape, kw, int(np.abs(out0.astype(int) - out1.astype(int)).max()))
+
+
+def test_mantis_batch_on_lanes_equals_frame_by_frame(monkeypatch):
+    """avx_mantis_u8_batch: the frames of a batch run on up to four internal streams with their own workspaces; every frame must
+    come out exactly as from the single-frame entry point, with one lane and with four."""
+    from animal_vision_amd import get_context
+    from animal_vision_amd.animals import MantisShrimp
+    from animal_vision_amd.synthetic import noise_frame, structured_frame
+
+    H, W, B = 136, 200, 5
+    frames = np.stack([structured_frame(i, H, W) if i % 2 else noise_frame(i, H, W) for i in range(B)])
+    m = MantisShrimp()
+    want = [m.visualize(f) for f in frames]
+    ctx = get_context()
+    m.ctx = ctx
+    d_in, d_base, d_out = ctx.malloc(frames.nbytes), ctx.malloc(frames.nbytes), ctx.malloc(frames.nbytes)
+    try:
+        ctx.upload(frames, d_in)
+        for lanes in ("1", "4"):
+            monkeypatch.setenv("AVX_MANTIS_LANES", lanes)
+            ctx.memset(d_out, 0)
+            ctx.memset(d_base, 0)
+            m.run_device_batch(d_in, d_base, d_out, B, H, W)
+            base = ctx.download(d_base, frames.shape, np.uint8)
+            out = ctx.download(d_out, frames.shape, np.uint8)
+            for i in range(B):
+                assert np.array_equal(base[i], want[i][0]) and np.array_equal(out[i], want[i][1]), (lanes, i)
+    finally:
+        for b in (d_in, d_base, d_out):
+            b.free()
