@@ -483,13 +483,20 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // and performs NumPy's float32 lerp.  Pass 0 takes its state from the arguments: no init launch, no memset.
 constexpr int kSelMax = 4;  // order statistics resolved together by one set of passes
 struct SelJob { const float* x; size_t n; unsigned long long rank0; float gamma; int has_next; double* out; };
-struct SelPass { int n_jobs, pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket; SelJob job[kSelMax]; };
+struct SelPass { int n_jobs, pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket; SelJob job[kSelMax];
+                 size_t x_frame_stride; int out_frame_stride; };  // blockIdx.y = frame: job arrays x_frame_stride floats apart, results out_frame_stride doubles apart, kSelMax states / histograms and one ticket per frame
 
 // NJ percentiles per launch: the data pass walks the NJ arrays one after the other into NJ LDS histograms, and the
 // last workgroup picks for each in turn -- the per-launch fixed costs (LDS clear / flush, ticket, tail latency)
 // are paid once, which is most of the time of a pass at 1080p.
 template <int NJ>
-__global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a) {
+__global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
+    SelPass a = a_in;
+    {   // frame of this workgroup (gridDim.y == 1: the plain single-array form)
+        const int f = blockIdx.y;
+        a.st += (size_t)f * kSelMax; a.hist += (size_t)f * kSelMax * 2048; a.ticket += f;
+        for (int j = 0; j < kSelMax; ++j) { a.job[j].x += (size_t)f * a.x_frame_stride; a.job[j].out += (size_t)f * a.out_frame_stride; }
+    }
     __shared__ uint32_t h[NJ][2048];
     __shared__ uint32_t wmin[kT / 64];
     __shared__ unsigned long long csum[kT];
@@ -803,6 +810,7 @@ struct BeeArgs {
     SelState* st; uint32_t* hist; uint32_t* ticket; double* pct;          // per frame: kSelMax states, kSelMax x 2048 bins, 1 ticket, 8 doubles
     unsigned long long rank0; float gamma; int has_next;
     float eps; float M[9]; const float* enc_thr; const uint8_t* coarse; uint32_t lo_key;
+    float* sel_planes;   // STAGE 0, pass 0: the values being selected are also written out, [frame][job][H*W] (passes 1-2 then read planes)
 };
 
 __device__ __forceinline__ void map_rgb(int mode, float U, float B, float G, const double* pct, float eps, const float* M, float (&rgb)[3]) {
@@ -1083,13 +1091,18 @@ __global__ __launch_bounds__(kT) void k_bee_tile(const BeeArgs a) {
                 for (int k = 0; k < 3; ++k) ubg[k] = R ? fma_t(w[k][yy + 2] + w[k][yy], a.t2, w[k][yy + 1] * a.t1) : w[k][yy];
                 const float U = ubg[0], B = ubg[1], G = ubg[2];
                 if (STAGE == 0) {
+                    float sv[3] = {U, B, G};
                     if (a.mode == 2) {
                         const float O1 = G - B, O2 = B - U;
-                        visit(0, __fsqrt_rn(O1 * O1 + O2 * O2));
-                        if (NJ > 1) visit(NJ > 1 ? 1 : 0, ((U + B) + G) / 3.0f);
-                    } else {
-                        visit(0, U);
-                        if (NJ > 2) { visit(NJ > 2 ? 1 : 0, B); visit(NJ > 2 ? 2 : 0, G); }
+                        sv[0] = __fsqrt_rn(O1 * O1 + O2 * O2);
+                        sv[1] = ((U + B) + G) / 3.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) visit(j, sv[j]);
+                    if (a.sel_planes) {
+                        const size_t px = (size_t)(y0 + y) * a.W + x0 + x;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) a.sel_planes[((size_t)f * NJ + j) * n + px] = sv[j];
                     }
                 } else {
                     float rgb[3];
@@ -1332,14 +1345,20 @@ static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_
     int rc = d->source == 0 ? avx_const_upload(ctx, ws, 0, d->rgb_matrix, sizeof(float) * 9, s, (void**)&mat)
                             : avx_const_upload(ctx, ws, 0, d->weights_host, sizeof(float) * 3 * d->bands, s, (void**)&mat);
     if (rc) return rc;
-    float* raw = nullptr;
-    if (d->source == 1) {
-        const int fb = n_frames < kBeeMaxFrames ? n_frames : kBeeMaxFrames;
-        if ((rc = avx_ensure_scratch(ctx, ws, sizeof(float) * n * 3 * fb + 256))) return rc;
-        raw = (float*)ws->d_scratch;
-    }
     const int R = d->blur_ksize / 2, mode = d->mapping;
     const int nj = mode == 2 ? 2 : (mode == 0 ? 3 : (mode == 3 ? 1 : 0));
+    float *raw = nullptr, *selp = nullptr;
+    {
+        // AVX_BEE_SELPLANES=0: all three radix passes recompute (no plane scratch)
+        static const bool planes_on = [] { const char* e = getenv("AVX_BEE_SELPLANES"); return !(e && e[0] == '0'); }();
+        const int fb = n_frames < kBeeMaxFrames ? n_frames : kBeeMaxFrames;
+        const size_t raw_f = d->source == 1 ? n * 3 * fb : 0, sel_f = (planes_on && nj > 0) ? n * nj * fb : 0;
+        if (raw_f + sel_f) {
+            if ((rc = avx_ensure_scratch(ctx, ws, sizeof(float) * (raw_f + sel_f) + 256))) return rc;
+            if (raw_f) raw = (float*)ws->d_scratch;
+            if (sel_f) selp = (float*)ws->d_scratch + raw_f;
+        }
+    }
     const double q = mode == 3 ? 98.0 : 95.0;
     const float vi = (float)(n - 1) * ((float)q / 100.0f);  // NumPy evaluates the virtual index in float32 (run_percentiles)
     float lo = floorf(vi);
@@ -1385,10 +1404,26 @@ static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_
             if (d->source == 0) { if (R) AVX_BEE(0, 1, STG, NJV); else AVX_BEE(0, 0, STG, NJV); }    \
             else { if (R) AVX_BEE(1, 1, STG, NJV); else AVX_BEE(1, 0, STG, NJV); }                   \
         }
-        // 2) the order statistics the mapping needs: three radix passes over the recomputed values
-        for (int ps = 0; ps < 3 && nj > 0; ++ps) {
+        // 2) the order statistics the mapping needs: three radix passes.  The first recomputes the values from the frame (and writes them
+        //    out as planes, 4 B per value); passes 2 and 3 only look at elements inside the selected prefix, so they read those planes with
+        //    the plain selection kernel (all F frames per launch) instead of recomputing catches, rescale and blur twice more.
+        a.sel_planes = selp;
+        for (int ps = 0; ps < (selp ? 1 : 3) && nj > 0; ++ps) {
             a.pass = ps; a.shift = shifts[ps]; a.bits = bits[ps];
             if (nj == 1) AVX_BEE_SR(0, 1) else if (nj == 2) AVX_BEE_SR(0, 2) else AVX_BEE_SR(0, 3)
+        }
+        if (selp && nj > 0) {
+            SelPass sp{};
+            sp.n_jobs = nj; sp.st = sel; sp.hist = hist; sp.ticket = ticket; sp.x_frame_stride = (size_t)nj * n; sp.out_frame_stride = 8;
+            for (int j = 0; j < nj; ++j) sp.job[j] = SelJob{selp + (size_t)j * n, n, (unsigned long long)lo, vi - lo, (size_t)lo + 1 < n ? 1 : 0, pct + j};
+            const size_t want = (n + (size_t)kT * 16 - 1) / ((size_t)kT * 16), capb = (size_t)ctx->num_cus;
+            const int gs = (int)(want < capb ? (want ? want : 1) : capb);
+            for (int ps = 1; ps < 3; ++ps) {
+                sp.pass = ps; sp.shift = shifts[ps]; sp.bits = bits[ps];
+                if (nj == 1) hipLaunchKernelGGL(k_sel_pass<1>, dim3(gs, F), dim3(kT), 0, s, sp);
+                else if (nj == 2) hipLaunchKernelGGL(k_sel_pass<2>, dim3(gs, F), dim3(kT), 0, s, sp);
+                else hipLaunchKernelGGL(k_sel_pass<4>, dim3(gs, F), dim3(kT), 0, s, sp);
+            }
         }
         // 3) map + encode
         a.pass = 0; a.shift = 0; a.bits = 11;
@@ -1518,11 +1553,12 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
     const size_t n = (size_t)H * W;
     const int g = grid_for(ctx, n);
     {   // the recompute form (k_bee_tile): every mapping but falsecolor_uv_mixed (a second order statistic over its own output), blur k <= 3
-        // Measured (MI355X, opponent mapping, device-resident batches): 26.1 vs 20.2 GP/s at 1080p (8 frames per step), 29.4 vs 32.2 at 4K
-        // (4 frames): the tile pipeline is bound by its arithmetic (three IEEE divisions, a square root and the 3 x 3 passes per pixel and
-        // pass), not by bytes, so it wins where the plane route is launch-bound and loses where that route streams.  AVX_BEE_FUSED=1 / 0 pins it.
+        // Measured (MI355X, opponent mapping, device-resident batches): 26.4 vs 20.2 GP/s at 1080p (8 frames per step), 35.6 vs 30.6-33.3 at 4K
+        // (4 frames) once the second and third radix passes read the planes the first one writes (AVX_BEE_SELPLANES; 28.7 with all three
+        // recomputing): the tile pipeline is bound by its arithmetic (three IEEE divisions, a square root and the 3 x 3 passes per pixel and
+        // pass), not by bytes.  AVX_BEE_FUSED=0 pins the plane route below.
         const char* pin = getenv("AVX_BEE_FUSED");
-        const bool want = pin && *pin ? atoi(pin) != 0 : n <= (size_t)2500000;
+        const bool want = pin && *pin ? atoi(pin) != 0 : true;
         if (want && d->mapping != 4 && !debug_planes && (d->blur_ksize == 0 || d->blur_ksize == 1 || d->blur_ksize == 3))
             return honeybee_recompute(ctx, in_hwc, out_hwc, n_frames, H, W, d, s0);
     }
