@@ -1,7 +1,7 @@
-"""Mantis at 3840x2160: how many jitter runs of the oracle it takes to reproduce the device's >1-code pixels (tests/_sensitivity.py)."""
+"""Test tool (uses the oracle as the checker). Mantis at 3840x2160: how many jitter runs of the oracle it takes to reproduce the device's >1-code pixels (tests/_sensitivity.py)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/tools/ -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from animal_vision_amd.animals import MantisShrimp
 from animal_vision_amd.synthetic import structured_frame
