@@ -237,6 +237,7 @@ _SIGS = {
     "avx_percentiles_dev": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_void_p), _vp]),
     "avx_ew_run": (_i, [_vp, ctypes.POINTER(EwProgram), _vp]),
+    "avx_ew_spec_stats": (_i, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),
     "avx_mantis_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, ctypes.POINTER(MantisDesc), _vp]),
     "avx_mantis_u8_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(MantisDesc), _vp]),
     "avx_resize_hwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),

@@ -16,33 +16,19 @@
 // Arithmetic contract: every instruction is one IEEE float32 operation, in the order NumPy evaluates the
 // reference's expression (-ffp-contract=off: nothing fuses); transcendental functions are the device's (1-2 ulp
 // from NumPy's): within 1e-4 relative of the reference, the UV path's bar.  uint8 encode = the exact threshold table.
+#include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "dichromat_common.h"
+#include "ew_common.h"
 
 using namespace avxk;
 
+using namespace avxew;
+
 namespace {
-
-constexpr int kET = 256;
-
-struct EwArgs {
-    avx_ew_insn insn[AVX_EW_MAX_INSN];
-    avx_ew_plane planes[AVX_EW_MAX_PLANES];
-    uint8_t acc_reg[AVX_EW_MAX_ACC], acc_kind[AVX_EW_MAX_ACC];
-    int n_insn, n_acc;
-    int W;
-    size_t n;
-    const double* scalars;
-    float* partial;  // [block][n_acc]
-    const float* lut; const float* thr; const uint8_t* coarse; uint32_t lo_key;
-    int uses_encode, uses_xy;
-    uint32_t* ticket; double* scalars_out; uint8_t acc_out_kind[AVX_EW_MAX_ACC]; int acc_slot[AVX_EW_MAX_ACC];
-};
-
-__device__ __forceinline__ float acc_init(int kind) { return kind == AVX_EW_ACC_MIN ? INFINITY : (kind == AVX_EW_ACC_MAX ? -INFINITY : 0.f); }
-__device__ __forceinline__ float acc_merge(int kind, float a, float b) { return kind == AVX_EW_ACC_MIN ? fminf(a, b) : (kind == AVX_EW_ACC_MAX ? fmaxf(a, b) : a + b); }
 
 // The per-pixel register files live in VGPRs: four float[NREG] arrays (one per pixel of the thread), indexed by the
 // wave-uniform register numbers of the instruction through s_set_gpr_idx (no LDS, no scratch).  NREG = 16 leaves
@@ -242,6 +228,14 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
 
 }  // namespace
 
+static std::atomic<unsigned long long> g_spec_hits{0}, g_spec_misses{0};
+
+extern "C" int avx_ew_spec_stats(unsigned long long* hits, unsigned long long* misses) {
+    if (hits) *hits = g_spec_hits.load();
+    if (misses) *misses = g_spec_misses.load();
+    return avxew::kEwSpecCount;
+}
+
 extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, p && p->struct_size == sizeof(avx_ew_program), "avx_ew_run: program is NULL or struct_size mismatch");
@@ -297,6 +291,23 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
         max_reg = max_reg > reg ? max_reg : reg;
         a.acc_out_kind[k] = (uint8_t)kind; a.acc_slot[k] = slot;
     }
+    if (const char* dump = getenv("AVX_EW_DUMP")) {  // tools/gen_ew_kernels.py: the structure of every program that runs (one line each)
+        if (FILE* f = fopen(dump, "a")) {
+            fprintf(f, "%d %d %d :", p->n_insn, p->n_planes, p->n_acc);
+            for (int i = 0; i < p->n_insn; ++i) {
+                const avx_ew_insn in = a.insn[i];
+                const int opc = in.op & AVX_EW_OPCODE_MASK;
+                const unsigned simm = (opc == AVX_EW_LOAD || opc == AVX_EW_STORE) ? in.imm : (opc == AVX_EW_SELECT ? (in.imm & 0xff) : 0u);
+                fprintf(f, " %u,%u,%u,%u,%u", in.op, in.dst, in.a, in.b, simm);
+            }
+            fprintf(f, " :");
+            for (int i = 0; i < p->n_planes; ++i) fprintf(f, " %d", a.planes[i].kind);
+            fprintf(f, " :");
+            for (int k = 0; k < p->n_acc; ++k) fprintf(f, " %d,%d", a.acc_reg[k], a.acc_kind[k]);
+            fprintf(f, "\n");
+            fclose(f);
+        }
+    }
     // programs with reductions: fewer, fatter workgroups (the last one folds gridDim partials per accumulator)
     const int px = (max_reg < 16 && a.n >= (size_t)1 << 20 && !getenv("AVX_EW_PX4")) ? 8 : 4;  // big frames, small programs: 8 pixels per thread
     const size_t want = (a.n + (size_t)kET * px - 1) / ((size_t)kET * px), cap = (size_t)ctx->num_cus * (p->n_acc ? 4 : 8);
@@ -309,6 +320,36 @@ extern "C" int avx_ew_run(avx_ctx* ctx, const avx_ew_program* p, void* stream) {
     }
     a.scalars = p->scalars_dev; a.partial = (float*)ws->d_ew + 64; a.ticket = (uint32_t*)ws->d_ew; a.scalars_out = p->scalars_dev;
     a.lut = ctx->d_decode_lut; a.thr = ctx->d_enc_thr_f32; a.coarse = ctx->d_coarse_f32; a.lo_key = ctx->coarse_lo_key[0];
+    // A program whose structure was recorded when ew_gen.hip was generated runs as its own straight-line kernel (same arithmetic,
+    // registers and loads scheduled by the compiler instead of an instruction at a time); anything else is interpreted.
+    // AVX_EW_NO_SPEC=1 pins the interpreter.
+    if (!getenv("AVX_EW_NO_SPEC")) {
+        uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+        auto mix = [&](unsigned byte) { h1 = (h1 ^ byte) * 0x100000001b3ull; h2 = (h2 ^ (byte + 0x9e)) * 0x100000001b3ull; h2 ^= h2 >> 29; };
+        for (int i = 0; i < p->n_insn; ++i) {
+            const avx_ew_insn in = a.insn[i];
+            const int opc = in.op & AVX_EW_OPCODE_MASK;
+            const unsigned simm = (opc == AVX_EW_LOAD || opc == AVX_EW_STORE) ? in.imm : (opc == AVX_EW_SELECT ? (in.imm & 0xff) : 0u);
+            mix(in.op); mix(in.dst); mix(in.a); mix(in.b); mix(simm & 0xff);
+        }
+        mix(0xff);
+        for (int i = 0; i < p->n_planes; ++i) mix((unsigned)a.planes[i].kind);
+        mix(0xfe);
+        for (int k = 0; k < p->n_acc; ++k) { mix(a.acc_reg[k]); mix(a.acc_kind[k]); }
+        int lo = 0, hi = kEwSpecCount - 1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) / 2;
+            const EwSpecEntry& e = kEwSpec[mid];
+            if (e.h1 == h1 && e.h2 == h2) {
+                ++g_spec_hits;
+                hipLaunchKernelGGL(px == 8 ? e.k8 : e.k4, dim3(grid), dim3(kET), 0, s, a);
+                AVX_HIP(ctx, hipGetLastError());
+                return AVX_OK;
+            }
+            if (e.h1 < h1 || (e.h1 == h1 && e.h2 < h2)) lo = mid + 1; else hi = mid - 1;
+        }
+        ++g_spec_misses;
+    }
     if (max_reg < 16 && px == 8) hipLaunchKernelGGL((k_ew<16, 8>), dim3(grid), dim3(kET), 0, s, a);
     else if (max_reg < 16) hipLaunchKernelGGL((k_ew<16, 4>), dim3(grid), dim3(kET), 0, s, a);
     else hipLaunchKernelGGL((k_ew<32, 4>), dim3(grid), dim3(kET), 0, s, a);

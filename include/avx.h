@@ -318,6 +318,9 @@ typedef struct avx_ew_program {
     double* scalars_dev; int32_t n_scalars;              /* the device-side scalar table                             */
 } avx_ew_program;
 int avx_ew_run(avx_ctx* ctx, const avx_ew_program* program, void* stream);
+/* Programs whose structure was recorded when csrc/ew_gen.hip was generated (tools/gen_ew_kernels.py) run as their own straight-line
+ * kernels; others are interpreted.  Returns the number of generated kernels; *hits / *misses count avx_ew_run calls of either kind. */
+int avx_ew_spec_stats(unsigned long long* hits, unsigned long long* misses);
 
 /* ---- MST++ helpers (ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py) ----------------------------
  * Hand-written kernels for the memory-bound parts of the forward pass; PyTorch-ROCm keeps the dense GEMMs/convs.
