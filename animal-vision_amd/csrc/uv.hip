@@ -517,10 +517,20 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
         const uint32_t prefix = a.pass == 0 ? 0u : st->prefix, mask = a.pass == 0 ? 0u : st->mask;
         const uint32_t above = prefix | ~mask;  // largest key with this prefix
         uint32_t best = 0xffffffffu;
+        // Run-length combining: neighbouring samples of a frame usually share a bin (always, nearly, in the first pass, where a bin is a
+        // quarter of a binade), and 64 lanes adding 1 to the same LDS word serialise -- a thread keeps (bin, count) of its current run and
+        // issues one atomic per run instead of one per sample.
+        uint32_t run_bin = 0xffffffffu, run_cnt = 0;
         auto visit = [&](float f) {
             const uint32_t k = f2key(f);
-            if ((k & mask) == prefix) atomicAdd(&h[j][(k >> a.shift) & (nb - 1)], 1u);
-            else if (find_next && k > above && k < best) best = k;  // successor candidates outside the 22-bit prefix
+            if ((k & mask) == prefix) {
+                const uint32_t b = (k >> a.shift) & (nb - 1);
+                if (b == run_bin) { ++run_cnt; }
+                else {
+                    if (run_cnt) atomicAdd(&h[j][run_bin], run_cnt);
+                    run_bin = b; run_cnt = 1;
+                }
+            } else if (find_next && k > above && k < best) best = k;  // successor candidates outside the 22-bit prefix
         };
         // 16-byte loads over the aligned body; the (<= 3 + 3) head / tail elements go to the first threads of block 0
         const size_t mis = ((16 - ((uintptr_t)jb.x & 15)) & 15) / 4;
@@ -546,6 +556,7 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
             if ((size_t)t < head) visit(jb.x[t]);
             if (tail0 + t < jb.n && t < 4) visit(jb.x[tail0 + t]);
         }
+        if (run_cnt) atomicAdd(&h[j][run_bin], run_cnt);
         if (find_next) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(best, o); best = v < best ? v : best; }
@@ -1208,7 +1219,8 @@ static int run_percentiles(avx_ctx* ctx, const UvScratch& u, const PctReq* req, 
         }
         // few, fat workgroups: every workgroup flushes its non-empty LDS bins with global atomics
         const size_t want = (nmax + (size_t)kT * 16 - 1) / ((size_t)kT * 16);
-        const size_t cap = (size_t)ctx->num_cus;  // measured: 1 workgroup per CU (same-address global atomics scale with the grid)
+        static const int wg_per_cu = [] { const char* e = getenv("AVX_SEL_WG"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+        const size_t cap = (size_t)ctx->num_cus * wg_per_cu;  // measured again in round 2 (hummingbird 1080p: 3.24 / 3.02 / 2.49 / 2.07 GP/s at 1 / 2 / 4 / 8 per CU): every workgroup pays the histogram clear, flush and ticket
         const int g = (int)(want < cap ? (want ? want : 1) : cap);
         const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
         for (int p = 0; p < 3; ++p) {
