@@ -489,6 +489,9 @@ struct SelPass { int n_jobs, pass, shift, bits; SelState* st; uint32_t* hist; ui
 // NJ percentiles per launch: the data pass walks the NJ arrays one after the other into NJ LDS histograms, and the
 // last workgroup picks for each in turn -- the per-launch fixed costs (LDS clear / flush, ticket, tail latency)
 // are paid once, which is most of the time of a pass at 1080p.
+__device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int bits, unsigned long long rank0, float gamma, int has_next, double* out,
+                         uint32_t prefix0, uint32_t mask0);
+
 template <int NJ>
 __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
     SelPass a = a_in;
@@ -499,11 +502,7 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
     }
     __shared__ uint32_t h[NJ][2048];
     __shared__ uint32_t wmin[kT / 64];
-    __shared__ unsigned long long csum[kT];
-    __shared__ int first_after[kT / 64];
-    __shared__ int sel_chunk, sel_bin, is_last;
-    __shared__ unsigned long long sel_rank;
-    __shared__ uint32_t sel_cnt;
+    __shared__ int is_last;
     const int nb = 1 << a.bits, t = threadIdx.x;
     const bool last_pass = a.pass == 2;
     for (int i = t; i < NJ * 2048; i += kT) (&h[0][0])[i] = 0;
@@ -541,16 +540,15 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
         // the grid kept ~1 MB in flight, an eighth of what an HBM round trip needs, and a pass ran at 0.7 TB/s
         const size_t stride = (size_t)gridDim.x * kT;
         size_t i = (size_t)blockIdx.x * kT + t;
-        for (; i + 3 * stride < nvec; i += 4 * stride) {
-            const float4 v0 = xv[i], v1 = xv[i + stride], v2 = xv[i + 2 * stride], v3 = xv[i + 3 * stride];
-            visit(v0.x); visit(v0.y); visit(v0.z); visit(v0.w);
-            visit(v1.x); visit(v1.y); visit(v1.z); visit(v1.w);
-            visit(v2.x); visit(v2.y); visit(v2.z); visit(v2.w);
-            visit(v3.x); visit(v3.y); visit(v3.z); visit(v3.w);
-        }
-        for (; i < nvec; i += stride) {
-            const float4 v = xv[i];
-            visit(v.x); visit(v.y); visit(v.z); visit(v.w);
+        // Eight 16-byte loads in flight per thread, the ragged end included (clamped index, masked visit): with a one-load-per-trip
+        // remainder loop a 1080p plane (8 vectors per thread at one workgroup per CU) paid a memory round trip for each of its last four.
+        for (; i < nvec; i += 8 * stride) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const size_t idx = i + q * stride; v[q] = xv[idx < nvec ? idx : nvec - 1]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i + q * stride < nvec) { visit(v[q].x); visit(v[q].y); visit(v[q].z); visit(v[q].w); }
         }
         if (blockIdx.x == 0) {
             if ((size_t)t < head) visit(jb.x[t]);
@@ -583,76 +581,9 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
     if (t == 0) is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!is_last) return;
-    const int per = nb / kT;  // nb in {1024, 2048}: 4 or 8 consecutive bins per thread
     for (int j = 0; j < a.n_jobs; ++j) {
         const SelJob jb = a.job[j];
-        SelState* st = a.st + j;
-        uint32_t* hist = a.hist + j * 2048;
-        const uint32_t prefix = a.pass == 0 ? 0u : st->prefix, mask = a.pass == 0 ? 0u : st->mask;
-        uint32_t loc[8];
-        unsigned long long sum = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)  // independent uncached loads: all in flight together
-            loc[i] = i < per ? __hip_atomic_load(&hist[t * per + (i < per ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sum += loc[i];
-        // inclusive scan of the 256 chunk sums (Hillis-Steele in LDS), then the one thread whose chunk straddles the rank
-        __syncthreads();
-        csum[t] = sum;
-        __syncthreads();
-        for (int o = 1; o < kT; o <<= 1) {
-            const unsigned long long v = t >= o ? csum[t - o] : 0ull;
-            __syncthreads();
-            csum[t] += v;
-            __syncthreads();
-        }
-        const unsigned long long r = a.pass == 0 ? jb.rank0 : st->rank;
-        const unsigned long long incl = csum[t], excl = incl - sum;
-        if (t == 0) sel_chunk = kT - 1;  // rank beyond the data (cannot happen for rank < n): last chunk
-        __syncthreads();
-        if (excl <= r && r < incl) sel_chunk = t;
-        __syncthreads();
-        if (t == sel_chunk) {
-            unsigned long long cum = excl;
-            int i = 0;
-            for (; i < per; ++i) {
-                if (cum + loc[i] > r) break;
-                cum += loc[i];
-            }
-            if (i == per) i = per - 1;
-            const int b = t * per + i;
-            st->prefix = prefix | ((uint32_t)b << a.shift);
-            st->mask = mask | ((uint32_t)(nb - 1) << a.shift);
-            st->rank = r - cum;
-            if (a.pass == 0) st->next_above = 0xffffffffu;
-            if (last_pass) { st->key_lo = prefix | (uint32_t)b; st->cnt_in_bin = loc[i]; sel_bin = b; sel_rank = r - cum; sel_cnt = loc[i]; }
-        }
-        if (last_pass) {  // successor of x[k] among the distinct keys, then np.percentile's float32 lerp
-            __syncthreads();
-            int f = 0x7fffffff;
-            for (int i = per - 1; i >= 0; --i)
-                if (loc[i] && t * per + i > sel_bin) f = t * per + i;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(f, o); f = v < f ? v : f; }
-            if ((t & 63) == 0) first_after[t >> 6] = f;
-            __syncthreads();
-            if (t == 0) {
-                int m = first_after[0];
-                for (int w = 1; w < kT / 64; ++w) m = first_after[w] < m ? first_after[w] : m;
-                const uint32_t next_above = __hip_atomic_load(&st->next_above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t next_key = m != 0x7fffffff ? (prefix | (uint32_t)m) : next_above;
-                const uint32_t key_lo = prefix | (uint32_t)sel_bin;
-                const float lo = key2f(key_lo);
-                float hi = lo;
-                if (jb.has_next && sel_rank + 1 >= sel_cnt) hi = next_key == 0xffffffffu ? lo : key2f(next_key);  // else x[k+1] duplicates x[k]
-                const float diff = hi - lo;
-                float res = lo + diff * jb.gamma;
-                if (jb.gamma >= 0.5f) res = hi - diff * (1.0f - jb.gamma);
-                *jb.out = (double)res;  // a float32 value (np.percentile returns np.float32 here)
-            }
-        }
-        for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
-        __syncthreads();
+        sel_pick(a.hist + j * 2048, a.st + j, a.pass, a.shift, a.bits, jb.rank0, jb.gamma, jb.has_next, jb.out, 0u, 0u);
     }
     if (t == 0) *a.ticket = 0;
 }
@@ -873,19 +804,24 @@ __device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int 
     for (int i = 0; i < 8; ++i) loc[i] = i < per ? __hip_atomic_load(&hist[t * per + (i < per ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sum += loc[i];
-    __syncthreads();
-    csum[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < kT; o <<= 1) {
-        const unsigned long long v = t >= o ? csum[t - o] : 0ull;
+    // inclusive scan of the 256 chunk sums: within a wave by shuffles, across the four waves through LDS (two barriers; the
+    // Hillis-Steele form in LDS took sixteen, and the pick is pure latency on the critical path of every pass)
+    unsigned long long incl = sum;
+    {
+        const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        __syncthreads();  // csum is free (a previous job's readers are done)
+        if (lane == 63) csum[wave] = incl;
+        if (t == 0) sel_chunk = kT - 1;
         __syncthreads();
-        csum[t] += v;
-        __syncthreads();
+        for (int w = 0; w < wave; ++w) incl += csum[w];
     }
     const unsigned long long r = pass == 0 ? rank0 : st->rank;
-    const unsigned long long incl = csum[t], excl = incl - sum;
-    if (t == 0) sel_chunk = kT - 1;
-    __syncthreads();
+    const unsigned long long excl = incl - sum;
     if (excl <= r && r < incl) sel_chunk = t;
     __syncthreads();
     if (t == sel_chunk) {
