@@ -79,6 +79,23 @@ __global__ __launch_bounds__(kGT) void k_resize_cubic_f32(const float* __restric
     }
 }
 
+// panorama_warp (uv_helpers.py:84-99) widens only x: the vertical pass of cv2.resize(INTER_CUBIC) at scale 1 has the coefficients
+// (0, 1, 0, 0) exactly, so for FINITE sources r0*0 + r1*1 + r2*0 + r3*0 == r1 and three of the four source rows need not be read
+// (12 loads per pixel instead of 48).  One thread per output pixel, the three channels together.
+__global__ __launch_bounds__(kGT) void k_panorama_cubic_x(const float* __restrict__ src, int H, int W, float* __restrict__ dst, AxisCub ax) {
+    const size_t total = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
+        const int x = (int)(i % W), y = (int)(i / W);
+        const int* ix = ax.idx + 4 * x;
+        const float* a = ax.a + 4 * x;
+        const float* S = src + (size_t)y * W * 3;
+        const int i0 = ix[0] * 3, i1 = ix[1] * 3, i2 = ix[2] * 3, i3 = ix[3] * 3;
+        const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[i * 3 + c] = S[i0 + c] * a0 + S[i1 + c] * a1 + S[i2 + c] * a2 + S[i3 + c] * a3;
+    }
+}
+
 // cv::saturate_cast<uchar>(float): cvRound (round half to even), clamped
 __device__ __forceinline__ void put_area(float* d, float v) { *d = v; }
 __device__ __forceinline__ void put_area(uint8_t* d, float v) { const float r = rintf(v); *d = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r)); }
@@ -391,7 +408,8 @@ int avx_geom_cache_trim(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int limit) {
 
 // uv_helpers.panorama_warp (:84-99): INTER_CUBIC widen to newW, then the centre crop [start, start+W): only the
 // cropped columns are computed (the x table is sliced); the height is unchanged (cubic taps 0,1,0,0: identity).
-int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s) {
+// finite_src: the source is known to hold finite values (decoded uint8 frames): the identity vertical pass is skipped
+int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s, bool finite_src) {
     avx_ws* ws = avx_workspace(ctx, s);
     if (!ws) return AVX_ERR_NOMEM;
     TableCache tc{ctx, ws, s};
@@ -401,8 +419,21 @@ int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int ne
     if ((rc = tc.cub(W, newW, &ax)) || (rc = tc.cub(H, H, &ay))) return rc;
     ax.idx += 4 * (size_t)start;
     ax.a += 4 * (size_t)start;
-    hipLaunchKernelGGL(k_resize_cubic_f32, dim3(grid_for(ctx, (size_t)H * W * 3)), dim3(kGT), 0, s, src, H, W, 3, dst, H, W, ax, ay);
+    if (finite_src && !getenv("AVX_PANO_FULL")) hipLaunchKernelGGL(k_panorama_cubic_x, dim3(grid_for(ctx, (size_t)H * W)), dim3(kGT), 0, s, src, H, W, dst, ax);
+    else hipLaunchKernelGGL(k_resize_cubic_f32, dim3(grid_for(ctx, (size_t)H * W * 3)), dim3(kGT), 0, s, src, H, W, 3, dst, H, W, ax, ay);
     AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+// The INTER_CUBIC x tables of panorama_warp (W -> newW, cropped from column `start`), for mantis.hip's fused front end.
+int avx_geom_cubic_x_tables(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int W, int newW, int start, const int** idx, const float** a) {
+    TableCache tc{ctx, ws, s};
+    int rc = tc.room();
+    if (rc) return rc;
+    AxisCub ax{};
+    if ((rc = tc.cub(W, newW, &ax))) return rc;
+    *idx = ax.idx + 4 * (size_t)start;
+    *a = ax.a + 4 * (size_t)start;
     return AVX_OK;
 }
 

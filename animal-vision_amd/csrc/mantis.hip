@@ -17,9 +17,10 @@ int avx_uv_percentiles_device(avx_ctx* ctx, int count, const float* const* x, co
 int avx_uv_plane_blur_device(avx_ctx* ctx, const float* in, float* out, int K, int H, int W, int ksize, const double* taps_host, hipStream_t s);
 extern "C" int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C, void* dst, int Hd, int Wd, int interp, void* stream);
 extern "C" int avx_sobel3_plane(avx_ctx* ctx, const float* plane, int H, int W, float* gx, float* gy, void* stream);
-int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s);
+int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int newW, int start, float* dst, hipStream_t s, bool finite_src);
 int avx_geom_cache_trim(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int limit);
 int avx_geom_linear_tables(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int H, int W, int Hd, int Wd, avx_lin_tab* ax, avx_lin_tab* ay);
+int avx_geom_cubic_x_tables(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int W, int newW, int start, const int** idx, const float** a);
 int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, double* out_dev, hipStream_t s);
 
 namespace {
@@ -52,6 +53,42 @@ __global__ __launch_bounds__(kMT) void k_encode_hwc(const float* __restrict__ in
     for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n3; i += (size_t)gridDim.x * kMT) {
         if (out_f) out_f[i] = l2s_f(clip01f(in[i]));
         else out[i] = (uint8_t)quantize_coarse<float, kCoarseNFix>(in[i], thr, coarse, lo_key);
+    }
+}
+
+// The UV front end of a uint8 frame in one pass: decode table -> panorama warp (x-only cubic, k_panorama_cubic_x's expression; idx == NULL:
+// no warp) -> the linear frame (float32 HWC) AND its baseline encode.  Replaces three launches and a 25 MB intermediate round trip
+// per 1080p frame; same tables, same arithmetic, byte-identical outputs.
+__global__ __launch_bounds__(kMT) void k_uv_front_u8(const uint8_t* __restrict__ in, int H, int W, const int* __restrict__ idx, const float* __restrict__ ca,
+                                                     const float* __restrict__ lut_g, const float* __restrict__ thr_g, const uint8_t* __restrict__ coarse_g,
+                                                     uint32_t lo_key, float* __restrict__ lin_out, uint8_t* __restrict__ base_out) {
+    __shared__ float lut[256];
+    __shared__ float thr[256];
+    __shared__ uint8_t coarse[kCoarseTableBytes];
+    for (int i = threadIdx.x; i < 256; i += kMT) { lut[i] = lut_g[i]; thr[i] = thr_g[i]; }
+    for (int i = threadIdx.x; i < kCoarseTableBytes; i += kMT) coarse[i] = coarse_g[i];
+    __syncthreads();
+    const size_t total = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < total; i += (size_t)gridDim.x * kMT) {
+        float v[3];
+        if (idx) {
+            const int x = (int)(i % W), y = (int)(i / W);
+            const int* ix = idx + 4 * x;
+            const float* a = ca + 4 * x;
+            const uint8_t* S = in + (size_t)y * W * 3;
+            const int i0 = ix[0] * 3, i1 = ix[1] * 3, i2 = ix[2] * 3, i3 = ix[3] * 3;
+            const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = lut[S[i0 + c]] * a0 + lut[S[i1 + c]] * a1 + lut[S[i2 + c]] * a2 + lut[S[i3 + c]] * a3;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = lut[in[i * 3 + c]];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lin_out[i * 3 + c] = v[c];
+            if (base_out) base_out[i * 3 + c] = (uint8_t)quantize_coarse<float, kCoarseNFix>(v[c], thr, coarse, lo_key);
+        }
     }
 }
 
@@ -289,9 +326,22 @@ int grid_for(avx_ctx* ctx, size_t items) {
 static int uv_front(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, int newW, float* tmp, float* lin_out, uint8_t* base_out, hipStream_t s) {
     const size_t n = (size_t)H * W;
     int rc;
+    if (!getenv("AVX_UV_FRONT_SPLIT")) {  // one pass (k_uv_front_u8); AVX_UV_FRONT_SPLIT=1: decode, warp and encode as separate launches
+        const int* idx = nullptr;
+        const float* ca = nullptr;
+        if (newW > W) {
+            avx_ws* ws = avx_workspace(ctx, s);
+            if (!ws) return AVX_ERR_NOMEM;
+            if ((rc = avx_geom_cubic_x_tables(ctx, ws, s, W, newW, (newW - W) / 2, &idx, &ca))) return rc;
+        }
+        hipLaunchKernelGGL(k_uv_front_u8, dim3(grid_for(ctx, n)), dim3(kMT), 0, s, in_hwc, H, W, idx, ca, ctx->d_decode_lut, ctx->d_enc_thr_f32, ctx->d_coarse_f32,
+                           ctx->coarse_lo_key[0], lin_out, base_out);
+        AVX_HIP(ctx, hipGetLastError());
+        return AVX_OK;
+    }
     if (newW > W) {
         hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, tmp);
-        if ((rc = avx_geom_panorama_cubic(ctx, tmp, H, W, newW, (newW - W) / 2, lin_out, s))) return rc;
+        if ((rc = avx_geom_panorama_cubic(ctx, tmp, H, W, newW, (newW - W) / 2, lin_out, s, true))) return rc;  // tmp: decoded uint8, finite
     } else {
         hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, lin_out);
     }
@@ -365,7 +415,7 @@ extern "C" int avx_panorama_warp_f32(avx_ctx* ctx, const float* src_hwc, int H, 
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, src_hwc && dst_hwc && src_hwc != dst_hwc && H > 0 && W > 0 && new_w > W, "avx_panorama_warp_f32: bad arguments");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
-    return avx_geom_panorama_cubic(ctx, src_hwc, H, W, new_w, (new_w - W) / 2, dst_hwc, avx_pick_stream(ctx, stream));
+    return avx_geom_panorama_cubic(ctx, src_hwc, H, W, new_w, (new_w - W) / 2, dst_hwc, avx_pick_stream(ctx, stream), false);  // caller's float data
 }
 
 extern "C" int avx_band_stack(avx_ctx* ctx, const float* lin_hwc, int H, int W, const avx_band_stack_desc* d, float* stack_hwk_out, void* stream) {
@@ -496,20 +546,26 @@ static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_h
     const int g = grid_for(ctx, n);
     // 1) to_float01 + srgb_to_linear (:148-149); float frames arrive already linearised (lin_hwc_in, built by the caller's
     //    plane program: to_float01's max rule needs a frame-wide reduction)
-    const float* lin_src = d->lin_hwc_in;
-    if (!lin_src) {
-        hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, lin0);
-        lin_src = lin0;
-    }
-    // 2) panorama warp (:152): INTER_CUBIC widen + centre crop
-    const float* baseline = lin_src;
-    if (newW != W) {
-        if ((rc = avx_geom_panorama_cubic(ctx, lin_src, H, W, newW, (newW - W) / 2, blin, s))) return rc;
-        baseline = blin;
-    }
-    float* base_f = d->out_float ? reinterpret_cast<float*>(out_base_hwc) : nullptr;
+    const float* baseline;
     float* out_f = d->out_float ? reinterpret_cast<float*>(out_hwc) : nullptr;
-    hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, baseline, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_base_hwc, base_f);
+    if (!d->lin_hwc_in && !d->out_float) {  // uint8 frame: decode -> warp -> linear frame + baseline encode in one pass (uv_front)
+        if ((rc = uv_front(ctx, in_hwc, H, W, newW, lin0, blin, out_base_hwc, s))) return rc;
+        baseline = blin;
+    } else {
+        const float* lin_src = d->lin_hwc_in;
+        if (!lin_src) {
+            hipLaunchKernelGGL(k_decode_lin, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, in_hwc, ctx->d_decode_lut, 3 * n, lin0);
+            lin_src = lin0;
+        }
+        // 2) panorama warp (:152): INTER_CUBIC widen + centre crop
+        baseline = lin_src;
+        if (newW != W) {
+            if ((rc = avx_geom_panorama_cubic(ctx, lin_src, H, W, newW, (newW - W) / 2, blin, s, d->lin_hwc_in == nullptr))) return rc;
+            baseline = blin;
+        }
+        float* base_f = d->out_float ? reinterpret_cast<float*>(out_base_hwc) : nullptr;
+        hipLaunchKernelGGL(k_encode_hwc, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, baseline, 3 * n, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_base_hwc, base_f);
+    }
     // 3-4) RGB->HSI (optionally at reduced size) folded with the band windows -> HxWxK stack, safe_norm per band
     // AVX_MANTIS_UP=0 pins the materialised H x W x K stack on the reduced-size route too (A/B)
     const char* up_env = getenv("AVX_MANTIS_UP");  // read per call: tests flip it
