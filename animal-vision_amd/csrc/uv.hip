@@ -505,11 +505,32 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
     __shared__ int is_last;
     const int nb = 1 << a.bits, t = threadIdx.x;
     const bool last_pass = a.pass == 2;
+    // The first eight 16-byte vectors of a thread's share of job j (all of it for a 1080p plane at one workgroup per CU): fetched a
+    // job AHEAD -- job 0's while the histograms are cleared, job j + 1's before job j is visited -- so the jobs' memory round trips
+    // overlap instead of adding up (a pass over four planes was four dependent round trips).
+    const size_t stride = (size_t)gridDim.x * kT, i0 = (size_t)blockIdx.x * kT + t;
+    auto job_vec = [&](int j, const float4*& xv, size_t& nvec, size_t& head, size_t& tail0) {
+        const SelJob jb = a.job[j];
+        const size_t mis = ((16 - ((uintptr_t)jb.x & 15)) & 15) / 4;
+        head = mis < jb.n ? mis : jb.n;
+        nvec = (jb.n - head) / 4; tail0 = head + nvec * 4;
+        xv = reinterpret_cast<const float4*>(jb.x + head);
+    };
+    auto fetch8 = [&](int j, float4 (&v)[8]) {
+        const float4* xv; size_t nvec, head, tail0;
+        job_vec(j, xv, nvec, head, tail0);
+        if (nvec == 0) return;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const size_t idx = i0 + q * stride; v[q] = xv[idx < nvec ? idx : nvec - 1]; }
+    };
+    float4 cur[8], nxt[8];
+    fetch8(0, cur);
     for (int i = t; i < NJ * 2048; i += kT) (&h[0][0])[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (j >= a.n_jobs) break;
+        if (j + 1 < NJ && j + 1 < a.n_jobs) fetch8(j + 1 < NJ ? j + 1 : j, nxt);
         const SelJob jb = a.job[j];
         SelState* st = a.st + j;
         const bool find_next = last_pass && jb.has_next;
@@ -532,17 +553,14 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
             } else if (find_next && k > above && k < best) best = k;  // successor candidates outside the 22-bit prefix
         };
         // 16-byte loads over the aligned body; the (<= 3 + 3) head / tail elements go to the first threads of block 0
-        const size_t mis = ((16 - ((uintptr_t)jb.x & 15)) & 15) / 4;
-        const size_t head = mis < jb.n ? mis : jb.n;
-        const size_t nvec = (jb.n - head) / 4, tail0 = head + nvec * 4;
-        const float4* xv = reinterpret_cast<const float4*>(jb.x + head);
-        // four independent 16-byte loads in flight per thread before the first (dependent) LDS atomic: with one load per trip
-        // the grid kept ~1 MB in flight, an eighth of what an HBM round trip needs, and a pass ran at 0.7 TB/s
-        const size_t stride = (size_t)gridDim.x * kT;
-        size_t i = (size_t)blockIdx.x * kT + t;
-        // Eight 16-byte loads in flight per thread, the ragged end included (clamped index, masked visit): with a one-load-per-trip
-        // remainder loop a 1080p plane (8 vectors per thread at one workgroup per CU) paid a memory round trip for each of its last four.
-        for (; i < nvec; i += 8 * stride) {
+        const float4* xv; size_t nvec, head, tail0;
+        job_vec(j, xv, nvec, head, tail0);
+        // first batch: already here (cur); further batches (frames beyond 8 vectors per thread): eight loads in flight each, the ragged
+        // end included (clamped index, masked visit)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i0 + q * stride < nvec) { visit(cur[q].x); visit(cur[q].y); visit(cur[q].z); visit(cur[q].w); }
+        for (size_t i = i0 + 8 * stride; i < nvec; i += 8 * stride) {
             float4 v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const size_t idx = i + q * stride; v[q] = xv[idx < nvec ? idx : nvec - 1]; }
@@ -550,6 +568,8 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
             for (int q = 0; q < 8; ++q)
                 if (i + q * stride < nvec) { visit(v[q].x); visit(v[q].y); visit(v[q].z); visit(v[q].w); }
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
         if (blockIdx.x == 0) {
             if ((size_t)t < head) visit(jb.x[t]);
             if (tail0 + t < jb.n && t < 4) visit(jb.x[tail0 + t]);
