@@ -29,7 +29,8 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // The same on a pair with packed float32 arithmetic: a wave64 vector instruction holds its SIMD for 4 cycles whether it is
 // v_mul_f32 or v_pk_mul_f32 (measured: SQ_ACTIVE_INST_VALU ~ SQ_INSTS_VALU in quad-cycles), so the packed forms halve the cost
 // of everything but the two transcendentals per element.
-__device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
+// The sigmoid form on a pair (round 2's first version; kept for A/B: -DAVX_GELU_SIGMOID).
+__device__ __forceinline__ float2_t gelu_sig2(float2_t x) {
     constexpr float C0 = -0x1.26a96cp+1f, C1 = -0x1.af022ep-4f, C2 = 0x1.79c67ep-12f, C3 = 0x1.7218f2p-14f, C4 = -0x1.b16328p-19f;
     auto c2 = [](float v) { return float2_t{v, v}; };
     const float2_t u = x * x;
@@ -40,6 +41,36 @@ __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
     const float2_t t = x * p;
     const float2_t d = float2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + c2(1.0f);
     return x * float2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
+// GELU without transcendentals: x * Phi(x), Phi(x) - 1/2 = xc * R(xc^2) with xc = clamp(x, -4, 4) and R a degree-7 minimax polynomial pinned
+// so that Phi(+-4) = 1 / 0 exactly (the clamp continues the function flat: the error stays bounded however large |x| is).
+// |Phi error| <= 3.2e-5 (at |x| = 4, where the true tail is 3.2e-5), |gelu error| <= 1.3e-4 absolute at x = -4 and <= 3.2e-5 relative for x > 0;
+// end to end it moves the float32 network's output by 2.5e-6 on average (max 1.7e-5) -- 2 % of what float16 storage alone does.  Two v_med3_f32 +
+// ten packed float32 operations per PAIR: on gfx950 a packed FMA costs ~1.95 ns per wave and SIMD, v_exp_f32 / v_rcp_f32 3.6 ns each
+// (tools/experiments/valu_rate4.hip), so this is 23 ns per pair against the sigmoid form's 30.
+__device__ __forceinline__ float2_t gelu_poly2(float2_t x) {
+    constexpr float R0 = 0x1.9860cap-2f, R1 = -0x1.0e9c60p-4f, R2 = 0x1.3a08cap-7f, R3 = -0x1.0bd734p-10f, R4 = 0x1.4005e4p-14f, R5 = -0x1.f322cap-19f,
+                    R6 = 0x1.c24602p-24f, R7 = -0x1.61225cp-30f;
+    auto c2 = [](float v) { return float2_t{v, v}; };
+    const float2_t xc = float2_t{__builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f)};
+    const float2_t t = xc * xc;
+    float2_t r = __builtin_elementwise_fma(t, c2(R7), c2(R6));
+    r = __builtin_elementwise_fma(r, t, c2(R5));
+    r = __builtin_elementwise_fma(r, t, c2(R4));
+    r = __builtin_elementwise_fma(r, t, c2(R3));
+    r = __builtin_elementwise_fma(r, t, c2(R2));
+    r = __builtin_elementwise_fma(r, t, c2(R1));
+    r = __builtin_elementwise_fma(r, t, c2(R0));
+    return x * __builtin_elementwise_fma(xc, r, c2(0.5f));
+}
+
+__device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
+#ifdef AVX_GELU_SIGMOID
+    return gelu_sig2(x);
+#else
+    return gelu_poly2(x);
+#endif
 }
 
 // acc += a.f16[half] * b.f16[half] in float32 (v_fma_mix_f32: both float16 operands are converted inside the FMA; the
