@@ -53,7 +53,7 @@ WORKLOADS = {
     "honeybee_mst_4k": ("honeybee_mst", 2160, 3840, 1),
     # BASELINE config 5: standalone spectral integration of an fp16 NHWC cube, (N bands-out, B bands-in) = (12,31), (10,81)
     "spectral_4k_12x31": ("spectral:12x31", 2160, 3840, 8),
-    "spectral_4k_10x81": ("spectral:10x81", 2160, 3840, 4),
+    "spectral_4k_10x81": ("spectral:10x81", 2160, 3840, 8),
     "spectral_1080p_12x31": ("spectral:12x31", 1080, 1920, 8),
     # the other UV species: "uv:<module>" = plane-program species, "mantis" = the fused mantis stack
     "mantis_1080p": ("mantis", 1080, 1920, 4),
