@@ -32,6 +32,9 @@ struct avx_ws {
     tab geom_tabs[64] = {};          // immutable resampling tables cached by (kind, component, source size, target size)
     int n_geom_tabs = 0;
     void* bee_small = nullptr;       // honeybee tail, recompute form (uv.hip): per-frame partials, statistics, histograms, select states, percentiles
+    float* d_scan = nullptr;         // mantis.hip: the blurred scanline plane of the current (H, W, rows, taps) -- frame-independent, kept across frames
+    size_t scan_cap = 0;
+    uint64_t scan_key = 0;
     void* d_ew = nullptr;            // per-block partial reductions of elementwise programs (ew.hip)
     size_t ew_cap = 0;
 };

@@ -251,11 +251,26 @@ __global__ __launch_bounds__(kMT) void k_prep_render(const float* __restrict__ l
     }
 }
 
-struct PolArgs { const float* gx; const float* gy; size_t n; float cos2g, sin2g, mix, lin_s, lin_gamma, circ_s; float* gain; };
+struct PolArgs { const float* gx; const float* gy; size_t n; float cos2g, sin2g, mix, lin_s, lin_gamma, circ_s; float* gain;
+                 const float* broad; int H, W; /* broad != NULL: the Sobel pair is computed here (geom.hip::k_sobel3's expressions), gx / gy unused */ };
 // :226-242
 __global__ __launch_bounds__(kMT) void k_polgain(PolArgs a) {
     for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
-        const float theta = atan2f(a.gy[p], a.gx[p]);
+        float gxv, gyv;
+        if (a.broad) {  // cv2.Sobel(ksize=3, BORDER_REFLECT_101), dx and dy, as k_sobel3
+            const int x = (int)(p % a.W), y = (int)(p / a.W);
+            const int xm = reflect101(x - 1, a.W), xp = reflect101(x + 1, a.W);
+            float dd[3], ss[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float* R = a.broad + (size_t)reflect101(y - 1 + k, a.H) * a.W;
+                dd[k] = R[xp] - R[xm];
+                ss[k] = R[xm] + R[x] * 2 + R[xp];
+            }
+            gxv = dd[0] + dd[1] * 2 + dd[2];
+            gyv = ss[2] - ss[0];
+        } else { gxv = a.gx[p]; gyv = a.gy[p]; }
+        const float theta = atan2f(gyv, gxv);
         const float c2 = cosf(2.0f * theta), s2 = sinf(2.0f * theta);
         const float cm = a.cos2g + a.mix * c2, sm = a.sin2g + a.mix * s2;  // cos2g/sin2g arrive as float32((1-mix)*global)
         const float al = powf(clip01f(0.5f * (cm + 1.0f)), a.lin_gamma);
@@ -265,8 +280,10 @@ __global__ __launch_bounds__(kMT) void k_polgain(PolArgs a) {
 }
 
 // :244-250: unsharp guided by pol_gain, then the barcode blend
+// rows != NULL: the scanline gain of :264-265 (k_scan_gain) applied to the blended value in the same pass
 __global__ __launch_bounds__(kMT) void k_unsharp_blend(const float* __restrict__ P, const float* __restrict__ Bl, const float* __restrict__ gain, const float* __restrict__ bar,
-                                                       size_t n, float amount, int do_unsharp, float opacity, float* __restrict__ out) {
+                                                       size_t n, float amount, int do_unsharp, float opacity, float* __restrict__ out,
+                                                       const float* __restrict__ rows = nullptr, float scan_gain = 0.f) {
     for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < 3 * n; i += (size_t)gridDim.x * kMT) {
         float r = P[i];
         if (do_unsharp) {
@@ -274,7 +291,9 @@ __global__ __launch_bounds__(kMT) void k_unsharp_blend(const float* __restrict__
             high = high < -1.f ? -1.f : (high > 1.f ? 1.f : high);
             r = clip01f(r + (amount * gain[i % n]) * high);
         }
-        out[i] = clip01f((1.0f - opacity) * r + opacity * bar[i]);
+        float v = clip01f((1.0f - opacity) * r + opacity * bar[i]);
+        if (rows) v = clip01f(v * (1.0f + scan_gain * (rows[i % n] - 0.5f)));
+        out[i] = v;
     }
 }
 
@@ -536,7 +555,7 @@ static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_h
     // constant tables of the species: cached per workspace, uploaded only when their bytes change (was six pageable copies in
     // front of every frame)
     float *dM, *drows, *dxx, *dyy, *dgains, *dwts;
-    (void)tab;
+    (void)tab; (void)rowsb; (void)rowsb;
     if ((rc = avx_const_upload(ctx, ws, 2, d->lobe_gains_host, sizeof(float) * B * 3, s, (void**)&dgains))) return rc;
     if ((rc = avx_const_upload(ctx, ws, 3, d->band_weights_host, sizeof(float) * B * K, s, (void**)&dwts))) return rc;
     if ((rc = avx_const_upload(ctx, ws, 4, d->band_matrix_host, sizeof(float) * K * 3, s, (void**)&dM))) return rc;
@@ -618,22 +637,39 @@ static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_h
     hipLaunchKernelGGL(k_prep_render, dim3(g), dim3(kMT), 0, s, baseline, n, d->red_keep, d->haze, d->haze_keep, make_float3(d->haze_tint[0], d->haze_tint[1], d->haze_tint[2]), P0);
     float* render = P0;
     if (d->pre_soft_ksize > 0) { if ((rc = avx_uv_plane_blur_device(ctx, P0, P1, 3, H, W, d->pre_soft_ksize, d->pre_soft_taps_host, s))) return rc; render = P1; }
-    // 8) polarisation gain
-    if ((rc = avx_sobel3_plane(ctx, broad, H, W, gx, gy, s))) return rc;
-    PolArgs pa{gx, gy, n, d->cos2_global, d->sin2_global, d->orientation_mix, d->pol_linear_strength, d->pol_linear_gamma, d->pol_circular_strength, gain};
+    // 8) polarisation gain (the Sobel pair of `broad` is formed inside k_polgain)
+    PolArgs pa{gx, gy, n, d->cos2_global, d->sin2_global, d->orientation_mix, d->pol_linear_strength, d->pol_linear_gamma, d->pol_circular_strength, gain, broad, H, W};
     hipLaunchKernelGGL(k_polgain, dim3(g), dim3(kMT), 0, s, pa);
     float* other = render == P0 ? P1 : P0;
     const int do_unsharp = d->unsharp_ksize > 0 && d->unsharp_amount > 0.f;
     if (do_unsharp) { if ((rc = avx_uv_plane_blur_device(ctx, render, other, 3, H, W, d->unsharp_ksize, d->unsharp_taps_host, s))) return rc; }
-    // 9) barcode blend
-    hipLaunchKernelGGL(k_unsharp_blend, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, render, other, gain, bar, n, d->unsharp_amount, do_unsharp, d->barcode_opacity, P2);
-    // 10) scanlines
+    // 10) scanlines: rows[y] broadcast along x and blurred -- a function of (H, W, rows, taps) only, not of the frame: built once per
+    //     workspace and kept (two launches fewer per frame); the gain itself rides in the blend kernel below
+    const float* rr = nullptr;
     if (d->scan_row_gain != 0.f) {
-        hipLaunchKernelGGL(k_rows_plane, dim3(g), dim3(kMT), 0, s, drows, H, W, rowsp);
-        const float* rr = rowsp;
-        if (d->scan_ksize > 0) { if ((rc = avx_uv_plane_blur_device(ctx, rowsp, rowsb, 1, H, W, d->scan_ksize, d->scan_taps_host, s))) return rc; rr = rowsb; }
-        hipLaunchKernelGGL(k_scan_gain, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, P2, rr, n, d->scan_row_gain);
+        uint64_t key = 0xcbf29ce484222325ull;
+        auto mixb = [&](const void* ptr, size_t bytes) { const unsigned char* q = (const unsigned char*)ptr; for (size_t i = 0; i < bytes; ++i) key = (key ^ q[i]) * 0x100000001b3ull; };
+        const int dims[3] = {H, W, d->scan_ksize};
+        mixb(dims, sizeof(dims));
+        mixb(d->rows_host, sizeof(float) * H);
+        if (d->scan_ksize > 0) mixb(d->scan_taps_host, sizeof(double) * d->scan_ksize);
+        key |= 1;  // never 0 (the "nothing cached" value)
+        if (ws->scan_key != key || ws->scan_cap < n) {
+            if (ws->scan_cap < n) {
+                if (ws->d_scan) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_scan)); }
+                ws->d_scan = nullptr; ws->scan_cap = 0;
+                AVX_HIP(ctx, hipMalloc((void**)&ws->d_scan, sizeof(float) * n));
+                ws->scan_cap = n;
+            }
+            hipLaunchKernelGGL(k_rows_plane, dim3(g), dim3(kMT), 0, s, drows, H, W, d->scan_ksize > 0 ? rowsp : ws->d_scan);
+            if (d->scan_ksize > 0) { if ((rc = avx_uv_plane_blur_device(ctx, rowsp, ws->d_scan, 1, H, W, d->scan_ksize, d->scan_taps_host, s))) return rc; }
+            ws->scan_key = key;
+        }
+        rr = ws->d_scan;
     }
+    // 9) barcode blend (+ the scanline gain)
+    hipLaunchKernelGGL(k_unsharp_blend, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, render, other, gain, bar, n, d->unsharp_amount, do_unsharp, d->barcode_opacity, P2, rr,
+                       d->scan_row_gain);
     // 11-12) periphery + encode
     const int do_periph = d->periph_ksize > 0;
     if (do_periph) { if ((rc = avx_uv_plane_blur_device(ctx, P2, P0, 3, H, W, d->periph_ksize, d->periph_taps_host, s))) return rc; }
