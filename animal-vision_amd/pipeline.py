@@ -66,6 +66,31 @@ def reduce_stats(local: StreamStats, dist=None) -> StreamStats:
 
 
 # ---------------------------------------------------------------- device pipeline -------------------
+# Host copies of a frame (pageable <-> pinned, 25 MB at 4K) run on a few threads: one core moves ~10 GB/s and faults the fresh
+# output array's pages in one by one, which made the host side of a dichromat stream (2 ms per 4K frame) the limiter, not the GPU.
+_COPY_THREADS = 4
+_copy_pool = None
+
+
+def _pcopy(dst: np.ndarray, src: np.ndarray) -> None:
+    """dst[...] = src, split by rows over a small thread pool for large frames (NumPy releases the GIL while copying)."""
+    global _copy_pool
+    if src.nbytes < (4 << 20) or src.shape[0] < _COPY_THREADS:
+        dst[...] = src
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _copy_pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="avx-copy")
+    rows = src.shape[0]
+    step = (rows + _COPY_THREADS - 1) // _COPY_THREADS
+
+    def part(r0):
+        dst[r0:r0 + step] = src[r0:r0 + step]
+
+    list(_copy_pool.map(part, range(0, rows, step)))
+
+
 @dataclass
 class _Slot:
     stream: int
@@ -114,7 +139,9 @@ class FramePipeline:
     def _retire(self, s: _Slot, emit: Callable[[int, np.ndarray], None]):
         if s.busy:
             self.ctx.sync(s.stream)
-            emit(s.index, s.h_out.array.copy())
+            out = np.empty_like(s.h_out.array)
+            _pcopy(out, s.h_out.array)
+            emit(s.index, out)
             s.busy = False
 
     def run(self, frames: Iterator[Tuple[int, np.ndarray]], emit: Callable[[int, np.ndarray], None]) -> StreamStats:
@@ -128,7 +155,7 @@ class FramePipeline:
             self._retire(s, emit)
             if frame.shape != (self.H, self.W, 3) or frame.dtype != np.uint8:
                 raise ValueError(f"frame {index}: expected uint8 {(self.H, self.W, 3)}, got {frame.dtype} {frame.shape}")
-            s.h_in.array[...] = frame
+            _pcopy(s.h_in.array, frame)
             ctx._check(lib.avx_memcpy_h2d(ctx._h, s.d_in.ptr, s.h_in.ptr, nbytes, s.stream))
             self.op.run_device(s.d_in, s.d_out, 1, self.H, self.W, stream=s.stream)
             if self.split_compare:

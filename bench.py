@@ -519,7 +519,7 @@ class Workload:
         st = pipe.run(((i, pool[i % len(pool)]) for i in range(n)), lambda i, o: None)
         pipe.close()
         return {"value": round(st.megapixels_per_second, 1), "unit": "MP/s", "frames": n,
-                "note": "pageable numpy frame -> pinned -> H2D -> kernels -> D2H -> numpy copy, 3 frames in flight, 1 host thread"}
+                "note": "pageable numpy frame -> pinned -> H2D -> kernels -> D2H -> numpy copy, 3 frames in flight, 1 host thread + 4 copy threads"}
 
     def close(self):
         for nm in ("d_in", "d_out", "d_cube", "d_planes", "d_base"):
