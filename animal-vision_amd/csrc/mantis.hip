@@ -106,17 +106,24 @@ __global__ __launch_bounds__(kMT) void k_rgbf_to_stack(StackArgs a) {
         if (c0 >= 0.f && c1 >= 0.f && c2 >= 0.f) {
             for (int k = 0; k < a.K; ++k) a.out[p * a.K + k] = fma_t(c2, M[3 * k + 2], fma_t(c1, M[3 * k + 1], c0 * M[3 * k]));
         } else {
-            for (int k = 0; k < a.K; ++k) {
-                float acc = 0.f;
-                for (int b = 0; b < a.B; ++b) {
-                    const float w = a.wts[(size_t)k * a.B + b];
-                    if (w != 0.f) {
-                        const float spec = ((a.gains[3 * b + 2] * c2 + a.gains[3 * b + 1] * c1) + a.gains[3 * b] * c0) / a.denom;
-                        acc = fma_t(spec > 0.f ? spec : 0.f, w, acc);
+            // band by band: the wavelength's value (one division) is shared by the K windows -- computed once per wavelength, not once per
+            // (window, wavelength); each window's sum still runs over b in order, and a zero weight leaves it unchanged either way
+            float acc[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+            for (int b = 0; b < a.B; ++b) {
+                const float spec = ((a.gains[3 * b + 2] * c2 + a.gains[3 * b + 1] * c1) + a.gains[3 * b] * c0) / a.denom;
+                const float sp = spec > 0.f ? spec : 0.f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < a.K) {
+                        const float w = a.wts[(size_t)k * a.B + b];
+                        if (w != 0.f) acc[k] = fma_t(sp, w, acc[k]);
                     }
-                }
-                a.out[p * a.K + k] = acc;
             }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < a.K) a.out[p * a.K + k] = acc[k];
         }
     }
 }
