@@ -307,12 +307,6 @@ __global__ __launch_bounds__(kMT) void k_unsharp_blend(const float* __restrict__
 __global__ __launch_bounds__(kMT) void k_rows_plane(const float* __restrict__ rows, int H, int W, float* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < (size_t)H * W; i += (size_t)gridDim.x * kMT) out[i] = rows[i / W] * 1.0f;
 }
-// :264-265
-__global__ __launch_bounds__(kMT) void k_scan_gain(float* __restrict__ P, const float* __restrict__ rows, size_t n, float gain) {
-    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < 3 * n; i += (size_t)gridDim.x * kMT)
-        P[i] = clip01f(P[i] * (1.0f + gain * (rows[i % n] - 0.5f)));
-}
-
 struct FinishArgs { const float* P; const float* periph; int H, W; const float* xx; const float* yy; float softness, radius; int do_periph;
                     const float* thr; const uint8_t* coarse; uint32_t lo_key; uint8_t* out; float* out_f; };
 // :268-278: radial sigmoid blend with the blurred copy, then encode
