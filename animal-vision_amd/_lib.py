@@ -218,6 +218,7 @@ _SIGS = {
     "avx_stream_create": (_i, [_vp, ctypes.POINTER(_vp)]),
     "avx_stream_destroy": (_i, [_vp, _vp]),
     "avx_sync": (_i, [_vp, _vp]),
+    "avx_stream_wait": (_i, [_vp, _vp, _vp]),
     "avx_device_sync": (_i, [_vp]),
     "avx_timer_start": (_i, [_vp, _vp]),
     "avx_timer_stop": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),

@@ -222,6 +222,7 @@ void avx_destroy(avx_ctx* ctx) {
     for (int i = 0; i < ctx->n_ws; ++i) avx_ws_release(&ctx->ws[i]);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    for (auto& e : ctx->wait_ev) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < ctx->n_lanes; ++i) {
         (void)hipStreamDestroy(ctx->lanes[i]);
         (void)hipEventDestroy(ctx->lane_done[i]);
@@ -312,6 +313,19 @@ int avx_sync(avx_ctx* ctx, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     AVX_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return AVX_OK;
+}
+
+// `waiter` does not run past this point until everything enqueued on `signaler` so far has finished (no host wait): the
+// fork / join of frames that run on several streams of one context (bench.py's UV-species steps, pipeline slots).
+int avx_stream_wait(avx_ctx* ctx, void* waiter, void* signaler) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t& ev = ctx->wait_ev[ctx->wait_next];
+    ctx->wait_next = (ctx->wait_next + 1) % avx_ctx::kWaitEvents;
+    if (!ev) AVX_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    AVX_HIP(ctx, hipEventRecord(ev, avx_pick_stream(ctx, signaler)));
+    AVX_HIP(ctx, hipStreamWaitEvent(avx_pick_stream(ctx, waiter), ev, 0));
     return AVX_OK;
 }
 

@@ -72,6 +72,9 @@ struct avx_ctx {
     hipStream_t lanes[kMaxLanes] = {};
     hipEvent_t lane_done[kMaxLanes] = {};
     hipEvent_t lane_fork = nullptr;
+    static constexpr int kWaitEvents = 16;   // avx_stream_wait: a ring of timing-less events
+    hipEvent_t wait_ev[kWaitEvents] = {};
+    int wait_next = 0;
     int n_lanes = 0;
 };
 

@@ -144,6 +144,10 @@ class Context:
     def sync(self, stream=None):
         self._check(lib.avx_sync(self._h, self._s(stream)))
 
+    def stream_wait(self, waiter, signaler):
+        """`waiter` waits (on the device) for everything enqueued on `signaler` so far."""
+        self._check(lib.avx_stream_wait(self._h, self._s(waiter), self._s(signaler)))
+
     def device_sync(self):
         self._check(lib.avx_device_sync(self._h))
 

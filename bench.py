@@ -220,12 +220,26 @@ class Workload:
             else:
                 uv_obj = self.uv_obj = getattr(animals, animals.UV_CLASS[species[3:]])()
                 variant = "day" if species == "uv:rat_uv" else None
-                plan = self.plan = uv_obj._plan(pool[0], variant)  # records the device call sequence for this frame size
-                ctx.upload(pool[0], plan.d_in)
+                # One recorded plan per lane (animals/_uv_species.py::SpeciesStreamOp, what pipeline.FramePipeline replays per slot): the step's
+                # frames run on up to four streams forked from / joined into the timed one, as the video loop overlaps them (AVX_BENCH_UV_LANES=1: one).
+                from animal_vision_amd.animals._uv_species import SpeciesStreamOp
+
+                L = max(1, min(B, int(os.environ.get("AVX_BENCH_UV_LANES", "4"))))
+                sop = self.sop = SpeciesStreamOp(uv_obj, H, W, depth=L, variant=variant, ctx=ctx)
+                plan = self.plan = sop.plans[0]
+                for be in sop.plans:
+                    ctx.upload(pool[0], be.d_in)
+                lanes = self.lanes = [ctx.stream_create() for _ in range(L)] if L > 1 else [stream]
 
                 def run_step():
+                    if L > 1:
+                        for ls in lanes:
+                            ctx.stream_wait(ls, stream)
                     for j in range(B):
-                        plan.run_device(stream)
+                        sop.plans[j % L].run_device(lanes[j % L])
+                    if L > 1:
+                        for ls in lanes:
+                            ctx.stream_wait(stream, ls)
         elif self.bee:
             op = self.op = animals.HoneyBee()._operator()
             op.ctx = ctx
@@ -526,6 +540,13 @@ class Workload:
             b = getattr(self, nm, None)
             if b is not None:
                 b.free()
+        if getattr(self, "sop", None) is not None:
+            for ls in self.lanes:
+                if ls != self.stream:
+                    self.ctx.sync(ls)
+                    self.ctx.stream_destroy(ls)
+            self.sop.close()
+            self.sop = None
         if self.own_stream:
             self.ctx.stream_destroy(self.stream)
         self.mst = self.t_in = self.t_out = None

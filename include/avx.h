@@ -57,6 +57,7 @@ int avx_memset(avx_ctx* ctx, void* dst, int value, size_t bytes, void* stream);
 int avx_stream_create(avx_ctx* ctx, void** out_stream);
 int avx_stream_destroy(avx_ctx* ctx, void* stream);
 int avx_sync(avx_ctx* ctx, void* stream);         /* hipStreamSynchronize(stream) */
+int avx_stream_wait(avx_ctx* ctx, void* waiter, void* signaler); /* device-side: waiter waits for signaler's work so far */
 int avx_device_sync(avx_ctx* ctx);                /* hipDeviceSynchronize() */
 
 /* HIP-event stopwatch ON `stream` (bench.py roofline leg: per-launch duration of the hot kernel). */
