@@ -50,7 +50,7 @@ WORKLOADS = {
     "honeybee_1080p": ("honeybee", 1080, 1920, 8),
     "honeybee_4k": ("honeybee", 2160, 3840, 4),
     "honeybee_mst_1080p": ("honeybee_mst", 1080, 1920, 2),
-    "honeybee_mst_4k": ("honeybee_mst", 2160, 3840, 1),
+    "honeybee_mst_4k": ("honeybee_mst", 2160, 3840, 2),
     # BASELINE config 5: standalone spectral integration of an fp16 NHWC cube, (N bands-out, B bands-in) = (12,31), (10,81)
     "spectral_4k_12x31": ("spectral:12x31", 2160, 3840, 8),
     "spectral_4k_10x81": ("spectral:10x81", 2160, 3840, 8),
@@ -258,7 +258,24 @@ class Workload:
                 self.own_stream = False
                 op32 = self.op32 = op.padded_clone(32)  # the cube arrives channels-last, 31 bands in a 32-wide group
 
+                ML = max(1, min(B, int(os.environ.get("AVX_BENCH_MST_LANES", "2"))))
+                mst_streams = self.mst_streams = [torch.cuda.Stream() for _ in range(ML)] if ML > 1 else []
+
                 def run_step():
+                    if ML > 1:  # the step's frames on ML torch streams forked from / joined into the timed one
+                        main = torch.cuda.current_stream()
+                        for ts in mst_streams:
+                            ts.wait_stream(main)
+                        for j in range(B):
+                            ts = mst_streams[j % ML]
+                            with torch.cuda.stream(ts):
+                                cube = mst.predict_device_nhwc(t_in[j])
+                                op32.run_device(None, DeviceBuffer(ctx, t_out[j].data_ptr(), t_out[j].numel(), owned=False), 1, H, W,
+                                                hsi_ptr=cube.data_ptr(), hsi_layout=0, hsi_dtype=1, stream=ts.cuda_stream)
+                                cube.record_stream(ts)
+                        for ts in mst_streams:
+                            main.wait_stream(ts)
+                        return
                     for j in range(B):
                         cube = mst.predict_device_nhwc(t_in[j])
                         op32.run_device(None, DeviceBuffer(ctx, t_out[j].data_ptr(), t_out[j].numel(), owned=False), 1, H, W,
@@ -352,7 +369,8 @@ class Workload:
         elif not self.bee:
             what = f"{s} dichromat core"
         elif self.mst is not None:
-            what = "honeybee UV path, MST++ HSI (seeded weights, fp16) + spectral remap"
+            what = "honeybee UV path, MST++ HSI (seeded weights, fp16) + spectral remap" + (
+                f", the step's frames on {len(self.mst_streams)} streams" if getattr(self, "mst_streams", None) else "")
         else:
             what = "honeybee UV path as coded (analytic lobes), opponent map"
         return what + f", {W}x{H} uint8 frames, {B} frames/step per GPU, device-resident"
@@ -402,6 +420,9 @@ class Workload:
             if pmc and pmc.get("frames_per_launch") == B:
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
                 roof["traffic_note"] = pmc["note"]
+            elif pmc and self.mst is not None:  # measured per frame (one frame per step); a step is B independent frames
+                roof["traffic"] = int(pmc["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
+                roof["traffic_note"] = pmc["note"] + f"; x{B} frames per step"
         except (OSError, ValueError):
             pass
         return {"value": round(value, 1), "unit": "MP/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
