@@ -5,13 +5,15 @@ A "step" is one pass of the hot path over one batch of synthetic frames that are
 
 Default run (no --workload) = the HEADLINE of BASELINE.json's metric ("dog LMS + honeybee MST++ UV, 1080p & 4K"):
   * the JSON line's value / roofline / config are the honeybee UV path with the MST++ HSI stage at 4K (`honeybee_mst_4k`,
-    dtype f16 = the reference's autocast, predict_torch.py:109), timed over exactly --steps steps after --warmup;
+    dtype f16 = the reference's autocast, predict_torch.py:109), timed over exactly --steps steps after --warmup; a step is two
+    independent frames on two streams forked from / joined into the timed one (AVX_BENCH_MST_LANES=1: one after the other);
   * `workloads` carries the driver-run numbers of the metric's other legs and of BASELINE config 2 -- dog_1080p, dog_4k,
     honeybee_mst_1080p, cat_1080p -- each timed the same way over >= 1 s, each with its own roofline and parity_checked;
   * `c4_stream` is BASELINE config 4: a fixed 256-frame 4K synthetic stream through the frame loop (pipeline.run_video:
     pinned staging, H2D || kernels || D2H, frames round-robin over the ranks, each rank touching only its own frames),
     dog and honeybee-MST++, PCIe-inclusive frames/s for the whole job (strong scaling: compare across --gpus).
---workload NAME times that one workload instead (all species, spectral config 5, ...).
+--workload NAME times that one workload instead (all species, spectral config 5, ...); the UV species run a step's frames on up to
+four streams, one recorded plan each (AVX_BENCH_UV_LANES), mantis through avx_mantis_u8_batch's lanes.
 
 --gpus N: one process per GPU.  Launched by torchrun (WORLD_SIZE set) this process IS a rank; launched bare with N > 1 it
 becomes a launcher: it touches no GPU (no torch / HIP import), starts N rank processes of this file with RANK / LOCAL_RANK /
