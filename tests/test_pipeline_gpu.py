@@ -236,3 +236,42 @@ def test_two_process_stream_on_one_gpu(tmp_path, oracle):
     assert got.shape[0] == 13
     for i, f in enumerate(frames):
         assert np.array_equal(got[i], oracle.dichromat_visualize(oracle.DICHROMATS["dog"], f)[1]), i
+
+
+def test_stream_wait_forks_and_joins_lanes(oracle):
+    """avx_stream_wait: frames enqueued on lane streams forked from a main stream, joined back into it, downloaded on the main
+    stream without any host wait in between -- every frame must be complete (bench.py's UV / MST++ steps, FramePipeline slots)."""
+    from animal_vision_amd import get_context
+    from animal_vision_amd.animals import Dog
+    from animal_vision_amd.dichromat import DichromatOp
+    from animal_vision_amd.synthetic import noise_frame
+
+    ctx = get_context()
+    H, W, n = 540, 960, 6
+    frames = [noise_frame(100 + i, H, W) for i in range(n)]
+    want = [oracle.dichromat_visualize(oracle.DICHROMATS["dog"], f)[1] for f in frames]
+    op = DichromatOp(Dog.SPEC, ctx)
+    main = ctx.stream_create()
+    lanes = [ctx.stream_create() for _ in range(3)]
+    d_in = [ctx.malloc(frames[0].nbytes) for _ in range(n)]
+    d_out = [ctx.malloc(frames[0].nbytes) for _ in range(n)]
+    try:
+        for rep in range(3):
+            for i in range(n):
+                ctx.upload(frames[i], d_in[i], stream=main)  # on the main stream: the lanes must wait for it
+                ctx.memset(d_out[i], 0, stream=main)
+            for ls in lanes:
+                ctx.stream_wait(ls, main)
+            for i in range(n):
+                op.run_device(d_in[i], d_out[i], 1, H, W, lanes[i % len(lanes)])
+            for ls in lanes:
+                ctx.stream_wait(main, ls)
+            got = [ctx.download(d_out[i], frames[i].shape, np.uint8, stream=main, sync=False) for i in range(n)]
+            ctx.sync(main)
+            for i in range(n):
+                assert np.array_equal(got[i], want[i]), (rep, i)
+    finally:
+        for b in d_in + d_out:
+            b.free()
+        for s in lanes + [main]:
+            ctx.stream_destroy(s)
