@@ -44,7 +44,8 @@ for f in glob.glob("gpurun_out/pmc_mst/p*/**/*counter_collection.csv", recursive
     if not rows:
         continue
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    marks = [i for i, r in enumerate(rows) if "k_map_encode" in r["Kernel_Name"]]
+    # the last kernel of a frame: k_map_encode (plane schedule of the honeybee tail) or k_bee_tile<.., .., 1, ..> (its map + encode stage)
+    marks = [i for i, r in enumerate(rows) if "k_map_encode" in r["Kernel_Name"] or re.search(r"k_bee_tile<\d, \d, 1, ", r["Kernel_Name"])]
     if len(marks) >= 2:
         # a steady frame: the window after the warm-up frame's mark (the LAST window also holds bench.py's own 20 extra launches of the
         # dominant kernel and the parity check's forward pass)
