@@ -260,6 +260,7 @@ _SIGS = {
     "avx_mst_conv3x3_lds": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_attn_pack16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "avx_mst_attn_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "avx_mst_attn_tail_x": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_ffn_fused": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_dw_gemm_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_dwconv3x3_nhwc_add": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -264,14 +264,18 @@ template <int C, int MINW>
 __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __restrict__ v /*[B][H][W][C]*/, const __half* __restrict__ x /*[B][H][W][C]*/,
                                                              const uint4* __restrict__ mpack /*[C/32][C/16][64]*/, const __half* __restrict__ taps1 /*[9][C]*/,
                                                              const __half* __restrict__ taps2 /*[9][C]*/, const float* __restrict__ bias /*[C]*/,
-                                                             __half* __restrict__ out, int B, int H, int W) {
+                                                             __half* __restrict__ out, int B, int H, int W, const uint4* __restrict__ wvpack /*[C/32][C/16][64] or NULL*/) {
     constexpr int NO = C / 8, NS = C / 16, NT = C / 32, PP = C * 2 + 16;
     constexpr int VRP = (VS * PP + 255) / 256 * 256, MRP = (MS * PP + 255) / 256 * 256;
     constexpr int NFILL = (VS * VS * NO + kFT - 1) / kFT;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* vt = smem;                                  // [VS][VRP]: [VS px][PP]  v on the halo region
-    unsigned char* mt = vt + (size_t)VS * VRP;                 // [MS][MRP]: [MS px][PP]  gelu(dw1(v))
-    __half* t2l = reinterpret_cast<__half*>(mt + (size_t)MS * MRP);  // [9][C] second conv's taps
+    unsigned char* mt = vt + (size_t)VS * VRP;                 // [MS][MRP]: [MS px][PP]  gelu(dw1(v)); with wvpack: first x on the halo region, [VS][VRP]
+    // wvpack != NULL: v is not read but formed here, v = float16(x W_v^T) on the halo region (to_v has no bias, so the zero rows outside
+    // the image stay zero: the convs' padding).  The staged tile is then x; it lands in the SECOND region (sized for it), the product goes
+    // to vt, and once every wave is past that the region is mt's.  The Gram pass then writes no v at all: 128 B/px less per block.
+    const bool fromx = wvpack != nullptr;
+    __half* t2l = reinterpret_cast<__half*>(mt + (size_t)VS * VRP);  // [9][C] second conv's taps (behind the larger of the two uses of the region)
     __half* t1l = t2l + 9 * C;                                 // [9][C] first conv's taps
     float* bl = reinterpret_cast<float*>(t1l + 9 * C);         // [C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
@@ -301,15 +305,16 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
             const int yy = t.y0 + f_dy[k], xx = t.x0 + f_dx[k];
             const bool ok = f_lds[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
             const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            uint4 r = *reinterpret_cast<const uint4*>(v + ((t.b * H + yc) * (size_t)W + xc) * C + f_off[k]);
+            uint4 r = *reinterpret_cast<const uint4*>((fromx ? x : v) + ((t.b * H + yc) * (size_t)W + xc) * C + f_off[k]);
             r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
             pre[k] = r;
         }
     };
     auto fill = [&]() {
+        unsigned char* dst = fromx ? mt : vt;
 #pragma unroll
         for (int k = 0; k < NFILL; ++k)
-            if (f_lds[k] >= 0) *reinterpret_cast<uint4*>(vt + f_lds[k]) = pre[k];
+            if (f_lds[k] >= 0) *reinterpret_cast<uint4*>(dst + f_lds[k]) = pre[k];
     };
     // phase B items of this lane (pixels of the 18 x 18 map: part * per + lane + 64 i): LDS offsets and image offsets, once
     constexpr int NB = (((MS * MS + (8 / NO) - 1) / (8 / NO)) + 63) / 64;
@@ -329,7 +334,31 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
     fetch(t);
     for (;;) {
         fill();
-        __syncthreads();  // vt complete (and the tables, first time round)
+        __syncthreads();  // vt (or the x tile) complete (and the tables, first time round)
+        if (fromx) {
+            // ---- phase A: v = float16(x W_v^T) on the 20 x 20 halo region: 32-pixel groups x 32-channel tiles over the waves ----
+            constexpr int NG = (VS * VS + 31) / 32;
+            for (int task = wave; task < NG * NT; task += kFT / 64) {
+                const int g = task / NT, nt = task % NT;
+                const int q = 32 * g + p, qc = q < VS * VS ? q : VS * VS - 1;
+                const int lo = (qc / VS) * VRP + (qc % VS) * PP;
+                float16_t d;
+#pragma unroll
+                for (int vv = 0; vv < 16; ++vv) d[vv] = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2)
+                    d = mfma16(__builtin_bit_cast(half8_t, wvpack[(size_t)(nt * NS + s2) * 64 + lane]),
+                               __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(mt + lo + 32 * s2 + 16 * h)), d);
+                if (q < VS * VS) {
+                    half8_t o0, o1;
+#pragma unroll
+                    for (int vv = 0; vv < 8; ++vv) { o0[vv] = (_Float16)d[vv]; o1[vv] = (_Float16)d[8 + vv]; }
+                    reinterpret_cast<uint4*>(vt + lo + 64 * nt + 32 * h)[0] = __builtin_bit_cast(uint4, o0);
+                    reinterpret_cast<uint4*>(vt + lo + 64 * nt + 32 * h)[1] = __builtin_bit_cast(uint4, o1);
+                }
+            }
+            __syncthreads();  // vt complete; the x tile is dead: its region becomes mt
+        }
         // ---- phase B: mid = gelu(dw1(v)) on the 18 x 18 region, zero outside the image ----
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -424,15 +453,16 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
 
 template <int C, int MINW>
 int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpack, const void* taps1, const void* taps2, const float* bias, void* out, int B,
-                     int H, int W, hipStream_t s) {
+                     int H, int W, hipStream_t s, const void* wvpack) {
     constexpr int PP = C * 2 + 16, VRP = (VS * PP + 255) / 256 * 256, MRP = (MS * PP + 255) / 256 * 256;
-    const size_t lds = (size_t)VS * VRP + (size_t)MS * MRP + (size_t)2 * 9 * C * 2 + sizeof(float) * C;
+    const size_t lds = (size_t)2 * VS * VRP + (size_t)2 * 9 * C * 2 + sizeof(float) * C;  // second region sized for the x tile (>= mt)
+    (void)MRP;
     const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
     const long cap = (long)ctx->num_cus * (MINW / 2);
     auto k = k_mst_attn_tail<C, MINW>;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), lds, s, (const __half*)v, (const __half*)x, (const uint4*)mpack,
-                       (const __half*)taps1, (const __half*)taps2, bias, (__half*)out, B, H, W);
+                       (const __half*)taps1, (const __half*)taps2, bias, (__half*)out, B, H, W, (const uint4*)wvpack);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
@@ -601,8 +631,24 @@ extern "C" int avx_mst_attn_tail(avx_ctx* ctx, const void* v, const void* x, con
     AVX_REQUIRE(ctx, v != out, "avx_mst_attn_tail: tiles read their neighbours' rows of v: the output cannot be v (it may be x)");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
-    if (C == 32) return launch_attn_tail<32, 4>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s);
-    return launch_attn_tail<64, 2>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s);
+    if (C == 32) return launch_attn_tail<32, 4>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s, nullptr);
+    return launch_attn_tail<64, 2>(ctx, v, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s, nullptr);
+}
+
+// The same with v formed inside the kernel: v = float16(x W_v^T) (MS_MSA.to_v :96, no bias) on each tile's halo region, wvpack16 = W_v in
+// pack_fragments16(transposed) order.  The Gram pass (avx_mst_qkv_gram with v_out = NULL) then only reads x, and v never exists in HBM.
+extern "C" int avx_mst_attn_tail_x(avx_ctx* ctx, const void* x, const void* wvpack16, const void* mpack16, const void* taps1_9xc, const void* taps2_9xc,
+                                   const float* bias, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wvpack16 && mpack16 && taps1_9xc && taps2_9xc && out && B > 0 && H > 0 && W > 0, "avx_mst_attn_tail_x: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_attn_tail_x: C=%d (32 or 64)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wvpack16 | (uintptr_t)mpack16 | (uintptr_t)out | (uintptr_t)taps1_9xc | (uintptr_t)taps2_9xc)) & 15u) == 0,
+                "avx_mst_attn_tail_x: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, x != out, "avx_mst_attn_tail_x: tiles read their neighbours' rows of x: the output cannot be x");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    if (C == 32) return launch_attn_tail<32, 4>(ctx, x, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s, wvpack16);
+    return launch_attn_tail<64, 2>(ctx, x, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s, wvpack16);
 }
 
 extern "C" int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int B, int H, int W, int C, void* stream) {

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(kT) void k_mst_qkv(const __half* __restrict__ x, co
             for (int s4 = 0; s4 < 4; ++s4) G[hd] = mfma(ak[s4], aq[s4], G[hd]);  // G[i][j] += sum_px k[px][i] q[px][j]
         }
         const size_t row = tile * 32 + p;
+        if (v_out)  // NULL: the attention tail forms v from x itself (avx_mst_attn_tail with wv): this pass only reads
 #pragma unroll
         for (int hd = 0; hd < HD; ++hd) {
             float16_t dv;
@@ -814,7 +815,7 @@ extern "C" {
 
 int avx_mst_qkv_gram(avx_ctx* ctx, const void* x, const void* wpack, size_t n_pix, int C, void* v_out, float* gram, float* nq, float* nk, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
-    AVX_REQUIRE(ctx, x && wpack && v_out && gram && nq && nk && n_pix > 0, "avx_mst_qkv_gram: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, x && wpack && gram && nq && nk && n_pix > 0, "avx_mst_qkv_gram: NULL pointer or empty tensor");  // v_out may be NULL
     AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_qkv_gram: C=%d (32, 64 or 128: 31-channel groups stored 32 wide)", C);
     AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)v_out)) & 15u) == 0, "avx_mst_qkv_gram: pointers must be 16-byte aligned");
     AVX_HIP(ctx, hipSetDevice(ctx->device));

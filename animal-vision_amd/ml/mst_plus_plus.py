@@ -122,6 +122,7 @@ class _AvxOps:
         self._conv_in = os.environ.get("AVX_MST_NO_CONV_IN", "") == ""  # A/B: uint8 frame -> conv_in output in one kernel
         self._upfuse = os.environ.get("AVX_MST_NO_UPFUSE", "") == ""  # A/B: transposed conv + fusion conv in one pass
         self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
+        self._tailx = os.environ.get("AVX_MST_NO_TAILX", "") == ""  # A/B: the tail forms v = x W_v^T itself, the Gram pass writes no v
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
         self._ctx = {}
@@ -164,20 +165,21 @@ class _AvxOps:
         """The matrix-core kernels take float16 rows of 32, 64 or 128 channels."""
         return self.enabled and x.is_cuda and x.dtype == torch.float16 and x.shape[-1] in (32, 64, 128) and self._mfma
 
-    def qkv_gram(self, x2: torch.Tensor, wpack: torch.Tensor, heads: int):
-        """x2 (b, n, c) float16 -> v (b, n, c), gram (b, heads, 32, 32), nq (b, c), nk (b, c) (csrc/mst_mfma.hip)."""
+    def qkv_gram(self, x2: torch.Tensor, wpack: torch.Tensor, heads: int, want_v: bool = True):
+        """x2 (b, n, c) float16 -> v (b, n, c) (None when not wanted: the pass then only reads), gram (b, heads, 32, 32), nq (b, c), nk (b, c)
+        (csrc/mst_mfma.hip)."""
         from .._lib import lib
 
         b, n, c = x2.shape
         x2 = x2.contiguous()
         ctx = self.ctx(x2.device)
-        v = torch.empty_like(x2)
+        v = torch.empty_like(x2) if want_v else None
         g = torch.empty((b, heads, 32, 32), dtype=torch.float32, device=x2.device)
         nq = torch.empty((b, c), dtype=torch.float32, device=x2.device)
         nk = torch.empty((b, c), dtype=torch.float32, device=x2.device)
         st = torch.cuda.current_stream(x2.device).cuda_stream
         for i in range(b):
-            ctx._check(lib.avx_mst_qkv_gram(ctx._h, x2[i].data_ptr(), wpack.data_ptr(), n, c, v[i].data_ptr(), g[i].data_ptr(), nq[i].data_ptr(),
+            ctx._check(lib.avx_mst_qkv_gram(ctx._h, x2[i].data_ptr(), wpack.data_ptr(), n, c, v[i].data_ptr() if want_v else None, g[i].data_ptr(), nq[i].data_ptr(),
                                             nk[i].data_ptr(), st))
         return v, g, nq, nk
 
@@ -297,6 +299,20 @@ class _AvxOps:
         ctx = self.ctx(v.device)
         ctx._check(lib.avx_mst_attn_tail(ctx._h, v.data_ptr(), x.data_ptr(), mpack16.data_ptr(), taps1.data_ptr(), taps2.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                          1, h, w, c, torch.cuda.current_stream(v.device).cuda_stream))
+        return out
+
+    def attn_tail_x(self, x: torch.Tensor, wvpack16: torch.Tensor, mpack16: torch.Tensor, taps1: torch.Tensor, taps2: torch.Tensor, bias: torch.Tensor,
+                    out: torch.Tensor = None) -> torch.Tensor:
+        """pos_emb(v) + v @ M + bias + x with v = float16(x @ W_v) formed inside the kernel, on one (h, w, c) float16 frame
+        (csrc/mst_fused.hip::k_mst_attn_tail, wvpack path): v never exists in HBM."""
+        from .._lib import lib
+
+        h, w, c = x.shape
+        assert x.is_contiguous()
+        out = torch.empty_like(x) if out is None else out
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_attn_tail_x(ctx._h, x.data_ptr(), wvpack16.data_ptr(), mpack16.data_ptr(), taps1.data_ptr(), taps2.data_ptr(), bias.data_ptr(),
+                                           out.data_ptr(), 1, h, w, c, torch.cuda.current_stream(x.device).cuda_stream))
         return out
 
     def rowgemm_add(self, a: torch.Tensor, wpack: torch.Tensor, add: torch.Tensor = None, a2: torch.Tensor = None, wpack2: torch.Tensor = None) -> torch.Tensor:
@@ -511,20 +527,26 @@ class MSTPlusPlus(torch.nn.Module):
         d = c // heads  # 32: 31 real channels + the zero padding
         if _AVX.fused_ok(x):  # one pass over x: q, k live only in MFMA accumulators, v is the only tensor written
             wpk = self._prep(p + ".qkv.frag", lambda: torch.cat([pack_fragments(wqkv[:, : 2 * c], False), pack_fragments(wqkv[:, 2 * c :], True)], 0).contiguous())
-            v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads)
+            tailx = _AVX._tail and _AVX._tailx and c in (32, 64)  # the tail forms v itself: this pass writes nothing but the Gram partials
+            v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads, want_v=not tailx)
             if self.capture_attn is not None:
                 self._capture(gram, nq, nk, p, heads)
             # softmax(gram / (nk nq^T) * rescale) and M = blockdiag(attn_h^T) @ W_proj^T in one small launch, M already in fragment order
             resc = self._prep(p + ".rescale32", lambda: self._p(p + ".rescale").float().reshape(heads).contiguous())
             wpt = self._prep(p + ".proj.t32", lambda: self._w(p + ".proj.weight", (0, 1)).t().float().contiguous())
             bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
-            vi = v.reshape(b, h, w, c)
+            vi = v.reshape(b, h, w, c) if v is not None else None
             if _AVX._tail and c in (32, 64):  # v @ M + bias + pos_emb(v) + x in ONE pass over v and x (the block's `msa(x) + x`, :183)
                 k1, k2 = p + ".pos_emb.0.weight", p + ".pos_emb.2.weight"
                 t1 = self._prep(k1 + ".t9h", lambda: self._w(k1, (0,)).reshape(c, 9).t().contiguous())  # [9][c] float16, tap-major
                 t2 = self._prep(k2 + ".t9h", lambda: self._w(k2, (0,)).reshape(c, 9).t().contiguous())
                 xc = x.contiguous()
                 out = torch.empty_like(xc)
+                if tailx:
+                    wv16 = self._prep(p + ".wv.frag16", lambda: pack_fragments16(wqkv[:, 2 * c :].contiguous()))
+                    for i in range(b):
+                        _AVX.attn_tail_x(xc[i], wv16, _AVX.attn_pack16(gram[i], nq[i], nk[i], resc, wpt), t1, t2, bias32, out[i])
+                    return out
                 for i in range(b):
                     _AVX.attn_tail(vi[i], xc[i], _AVX.attn_pack16(gram[i], nq[i], nk[i], resc, wpt), t1, t2, bias32, out[i])
                 return out
@@ -712,6 +734,10 @@ def hbm_bytes_per_px(stage: int = 3) -> float:
 
     def msab(c: int) -> float:
         t = 2.0 * c  # one activation tensor
+        if _AVX._tail and _AVX._tailx and c in (32, 64):
+            b = t                      # qkv + Gram: read x only (q, k never leave the matrix cores; v is formed in the tail)
+            b += 2 * t                 # attention tail in one pass: read x, write x1 (v = x W_v^T on the tile's halo, in LDS)
+            return b + ((2 * t) if (_AVX._ffn and c in _AVX.FFN_FUSED_C) else (t + 4 * t + ((4 * t + 2 * t) if _AVX._ffn2 else (4 * t + 4 * t + 4 * t + 2 * t))))
         b = 2 * t                      # qkv + Gram: read x, write v (q, k never leave the matrix cores)
         if _AVX._tail and c in (32, 64):
             b += 3 * t                 # attention tail in one pass: read v, read x, write x1

@@ -371,6 +371,10 @@ int avx_mst_attn_pack16(avx_ctx* ctx, const float* gram, const float* nq, const 
                         void* stream);
 int avx_mst_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpack16, const void* taps1_9xc, const void* taps2_9xc, const float* bias,
                       void* out, int B, int H, int W, int C, void* stream);
+/* The same with v = float16(x W_v^T) formed inside the kernel (wvpack16: W_v in pack_fragments16(transposed) order): v never exists in
+ * HBM and avx_mst_qkv_gram may be called with v_out = NULL.  out != x. */
+int avx_mst_attn_tail_x(avx_ctx* ctx, const void* x, const void* wvpack16, const void* mpack16, const void* taps1_9xc, const void* taps2_9xc,
+                        const float* bias, void* out, int B, int H, int W, int C, void* stream);
 
 /* The whole second half of an MSAB block in one kernel (MST_Plus_Plus.py:57-65 PreNorm, :141-158 FeedForward, :184 residual):
  * out = x + W2 gelu(dw3x3(gelu(W1 layernorm(x)))) on a (B, H, W, C) float16 tensor, C = 32 or 64 (31-channel groups stored
