@@ -589,6 +589,60 @@ __global__ __launch_bounds__(256) void k_mst_conv_in_u8(const uint8_t* __restric
     }
 }
 
+// The same on the matrix cores: K = 27 (+ 5 zero slots) x N = 32 is two v_mfma_f32_32x32x16_f16 per 32 pixels.  The inputs are float16
+// already (autocast's conv input) and the weights are the model's float16 values, so the products are exact and only the float32 summation
+// order differs from the scalar form above.  A lane (pixel p, half h) gathers the 16 k-slots its B fragments carry (k = 16 s + 8 h + j ->
+// tap k / 3, channel k % 3), the A fragments are built once per thread from the 27 x 32 table (output-channel rows permuted so that the
+// lane ends up with 16 contiguous channels: pack_fragments16's order).  The kernel is then bound by its 64 B/px of output.
+__global__ __launch_bounds__(256) void k_mst_conv_in_u8_mfma(const uint8_t* __restrict__ frame /*[H][W][3]*/, const float* __restrict__ w /*[27][32]*/,
+                                                             __half* __restrict__ out /*[Hp][Wp][32]*/, int H, int W, int pt, int pl, int Hp, int Wp) {
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int col = 16 * ((p % 8) / 4) + 4 * (p / 8) + p % 4;  // output channel of this lane's A row
+    half8_t af[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * h + j;
+            af[s][j] = k < 27 ? (_Float16)w[k * 32 + col] : (_Float16)0.f;
+        }
+    const size_t total = (size_t)Hp * Wp, ngroups = (total + 31) / 32;
+    for (size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += (size_t)gridDim.x * 4) {
+        const size_t i = g * 32 + p, ic = i < total ? i : total - 1;
+        const int y = (int)(ic / Wp), x = (int)(ic - (size_t)y * Wp);
+        half8_t bf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * h + j, t = k / 3, c = k - 3 * t;
+                float v = 0.f;
+                if (k < 27) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    const bool ok = yy >= 0 && yy < Hp && xx >= 0 && xx < Wp;  // the conv's zero padding applies to the PADDED frame
+                    int sy = (ok ? yy : 0) - pt, sx = (ok ? xx : 0) - pl;       // reflect (no edge repeat) back into the frame
+                    sy = sy < 0 ? -sy : (sy >= H ? 2 * (H - 1) - sy : sy);
+                    sx = sx < 0 ? -sx : (sx >= W ? 2 * (W - 1) - sx : sx);
+                    const float q = (float)frame[((size_t)sy * W + sx) * 3 + c] / 255.0f;
+                    v = ok ? q : 0.f;
+                }
+                bf[s][j] = (_Float16)v;
+            }
+        float16_t d;
+#pragma unroll
+        for (int vv = 0; vv < 16; ++vv) d[vv] = 0.f;
+        d = mfma16(af[0], bf[0], d);
+        d = mfma16(af[1], bf[1], d);
+        if (i < total) {
+            half8_t o0, o1;
+#pragma unroll
+            for (int vv = 0; vv < 8; ++vv) { o0[vv] = (_Float16)d[vv]; o1[vv] = (_Float16)d[8 + vv]; }
+            reinterpret_cast<uint4*>(out + i * 32 + 16 * h)[0] = __builtin_bit_cast(uint4, o0);
+            reinterpret_cast<uint4*>(out + i * 32 + 16 * h)[1] = __builtin_bit_cast(uint4, o1);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
@@ -679,7 +733,13 @@ extern "C" int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H,
     const int Hp = H + pad_top + pad_bottom, Wp = W + pad_left + pad_right;
     const size_t total = (size_t)Hp * Wp;
     const size_t want = (total + 255) / 256, cap = (size_t)ctx->num_cus * 16;
-    hipLaunchKernelGGL(k_mst_conv_in_u8, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, frame_hwc, w_27x32_dev, (__half*)out, H, W, pad_top, pad_left, Hp, Wp);
+    if (getenv("AVX_MST_CONV_IN_VALU"))  // A/B: the scalar-FMA form
+        hipLaunchKernelGGL(k_mst_conv_in_u8, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, frame_hwc, w_27x32_dev, (__half*)out, H, W, pad_top, pad_left, Hp, Wp);
+    else {
+        const size_t wantm = (total + 127) / 128;  // 4 waves x 32 pixels per workgroup and trip
+        hipLaunchKernelGGL(k_mst_conv_in_u8_mfma, dim3((unsigned)(wantm < cap ? wantm : cap)), dim3(256), 0, s, frame_hwc, w_27x32_dev, (__half*)out, H, W, pad_top,
+                           pad_left, Hp, Wp);
+    }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
