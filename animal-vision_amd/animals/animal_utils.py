@@ -163,6 +163,52 @@ def apply_chroma_compression(image: np.ndarray, strength: float = 0.4):
     return out.astype(np.result_type(image.dtype, np.float32) if not np.issubdtype(image.dtype, np.floating) else image.dtype, copy=False)
 
 
+def apply_tapetum_bloom(image: np.ndarray, strength: float = 0.12, sigma: float = 3.0) -> np.ndarray:
+    """animals/animal_utils.py:183-204 (the reference defines it and names it only in a commented block of cat.py:50-59): a luminance mask
+    above the midtones and the frame itself are blurred (cv2.GaussianBlur, ksize from sigma: the shared Gaussian contract), the frame is
+    screen-blended with its blur where the mask says so.  One plane program, two device blurs, one plane program."""
+    from ..planevm import run_planes
+
+    planes = _planes_of(image)
+    k = cv_auto_ksize(float(sigma))
+    taps = gaussian_taps(k, float(sigma))
+    st = float(strength)
+
+    def build(be, v):
+        x = [be.clip01(c) for c in v]
+        L = (0.2126 * x[0] + 0.7152 * x[1]) + 0.0722 * x[2]
+        mask = be.clip01((L - 0.4) / 0.6)
+        blurred = be.blur_taps([mask] + x, k, taps)
+        mask, blur = blurred[0], blurred[1:]
+        out = []
+        for c, b in zip(x, blur):
+            screen = 1.0 - (1.0 - c) * (1.0 - b)
+            out.append(be.clip01(c + (st * mask) * (screen - c)))
+        return out
+
+    return np.stack(run_planes(planes, build), axis=-1).astype(image.dtype, copy=False)
+
+
+def apply_rod_vision(image: np.ndarray, chroma_scale: float = 0.08, luminance_boost: float = 1.4, gamma: float = 0.8) -> np.ndarray:
+    """animals/animal_utils.py:261-305 (defined, never called in the reference): scotopic luminance 0.1 R + 0.8 G + 0.1 B blurred with
+    sigma 1.2, the frame pulled towards it (chroma_scale of the colour kept), luminance boost, clip, gamma."""
+    from ..planevm import run_planes
+
+    planes = _planes_of(image)
+    k = cv_auto_ksize(1.2)
+    taps = gaussian_taps(k, 1.2)
+    keep = float(np.float32(1 - chroma_scale))
+    cs, boost, g = float(chroma_scale), float(luminance_boost), float(gamma)
+
+    def build(be, v):
+        x = [be.clip01(c) for c in v]
+        L = (0.1 * x[0] + 0.8 * x[1]) + 0.1 * x[2]
+        gray = be.blur_taps([L], k, taps)[0]
+        return [be.power(be.clip01((gray * keep + c * cs) * boost), g) for c in x]
+
+    return np.stack(run_planes(planes, build), axis=-1).astype(image.dtype, copy=False)
+
+
 def apply_s_cone_vertical_gain(image_lin, s_top=1.0, s_bottom=0.6, *, power: float = 1.0, extra_boost: float = 0.0, band=None, clamp: bool = True):
     """animals/animal_utils.py:206-259: per-row gain on the blue channel (ramp, power shaping, boost, optional Gaussian
     bump), clipped to [0, 1] when `clamp`.  Like the reference it works on `image_lin.astype(float32, copy=False)`: a

@@ -244,6 +244,31 @@ def apply_chroma_compression(image: np.ndarray, strength: float = 0.4):
     return gray + (image - gray) * (1 - strength)
 
 
+def apply_tapetum_bloom(image: np.ndarray, strength: float = 0.12, sigma: float = 3.0) -> np.ndarray:
+    """animals/animal_utils.py:183-204 (defined, referenced only from a commented block of cat.py): luminance-gated screen blend with a
+    blurred copy.  cv2.GaussianBlur -> the shared Gaussian contract (cv_gaussian_blur, ksize from sigma)."""
+    x = np.clip(image.astype(np.float32, copy=False), 0.0, 1.0)
+    L = 0.2126 * x[..., 0] + 0.7152 * x[..., 1] + 0.0722 * x[..., 2]
+    mask = np.clip((L - 0.4) / 0.6, 0.0, 1.0)
+    mask = cv_gaussian_blur(mask, (0, 0), sigma, sigma)[..., None]
+    blur = cv_gaussian_blur(x, (0, 0), sigma, sigma)
+    screen = 1.0 - (1.0 - x) * (1.0 - blur)
+    y = x + strength * mask * (screen - x)
+    return np.clip(y, 0.0, 1.0).astype(image.dtype, copy=False)
+
+
+def apply_rod_vision(image: np.ndarray, chroma_scale: float = 0.08, luminance_boost: float = 1.4, gamma: float = 0.8) -> np.ndarray:
+    """animals/animal_utils.py:261-305 (defined, not called): scotopic luminance (blurred, sigma 1.2), heavy desaturation, boost, gamma."""
+    x = np.clip(image.astype(np.float32), 0.0, 1.0)
+    L = 0.1 * x[..., 0] + 0.8 * x[..., 1] + 0.1 * x[..., 2]
+    L = cv_gaussian_blur(L, (0, 0), 1.2, 1.2)
+    gray = L[..., None]
+    x = gray * (1 - chroma_scale) + x * chroma_scale
+    x = np.clip(x * luminance_boost, 0.0, 1.0)
+    x = np.power(x, gamma)
+    return x.astype(image.dtype, copy=False)
+
+
 def apply_s_cone_vertical_gain(image_lin, s_top=1.0, s_bottom=0.6, *, power=1.0, extra_boost=0.0, band=None, clamp=True):
     """animals/animal_utils.py:206-259 (mutates an f32 input in place, like the reference)."""
     out = image_lin.astype(np.float32, copy=False)

@@ -136,3 +136,23 @@ def test_uv_mappers_by_name_vs_oracle(oracle):
         um.map_uv_purple_yellow(np.zeros((2, 3, 4), np.float32))
     with pytest.raises(ValueError):
         um.map_falsecolor(U, B[:-1], G)
+
+
+def test_tapetum_bloom_and_rod_vision_vs_oracle(oracle):
+    """animal_utils.py:183-204, :261-305 -- defined by the reference, used by none of its species (cat.py:50-59 names them in a commented
+    block): no reference outputs exist, so the pin is the oracle's restatement (blur = the shared Gaussian contract, bit-exact; the
+    elementwise parts float32, `power` within the device's powf)."""
+    from animal_vision_amd.animals import animal_utils as au
+
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:97, 0:131]
+    img = (0.5 + 0.45 * np.sin(xx / 7.0)[..., None] * np.cos(yy[..., None] / 5.0 + np.arange(3)) + 0.05 * rng.standard_normal((97, 131, 3))).astype(np.float32)
+    for frame in (img, (img * 1.3 - 0.1).astype(np.float32), img.astype(np.float64)):  # the second leaves [0, 1]: both helpers clip first
+        for kw in ({}, dict(strength=0.3, sigma=1.5)):
+            got, want = au.apply_tapetum_bloom(frame, **kw), oracle.apply_tapetum_bloom(frame, **kw)
+            assert got.dtype == frame.dtype and got.shape == frame.shape
+            np.testing.assert_allclose(got, want, rtol=0, atol=3e-7)
+        for kw in ({}, dict(chroma_scale=0.15, luminance_boost=1.1, gamma=0.6)):
+            got, want = au.apply_rod_vision(frame, **kw), oracle.apply_rod_vision(frame, **kw)
+            assert got.dtype == frame.dtype and got.shape == frame.shape
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7)
