@@ -497,6 +497,15 @@ def gaussian_blur(img: np.ndarray, sigma: float) -> np.ndarray:
     return cv_gaussian_blur(img, (k, k), sigma, sigma)
 
 
+def apply_scatter_and_blue_bias(img_lin: np.ndarray, *, sigma: float, blue_bias: float) -> np.ndarray:
+    """uv_helpers.py:100-106."""
+    out = img_lin.copy()
+    if sigma > 0.15:
+        out = gaussian_blur(out, sigma)
+    out[..., 2] = np.clip(out[..., 2] + float(blue_bias), 0.0, 1.0)
+    return out
+
+
 def snow_glare_tone_compress(img_lin: np.ndarray, *, strength: float, knee: float = 0.8) -> np.ndarray:
     """uv_helpers.py:111-121."""
     if strength <= 0.0:

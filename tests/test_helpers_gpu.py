@@ -156,3 +156,44 @@ def test_tapetum_bloom_and_rod_vision_vs_oracle(oracle):
             got, want = au.apply_rod_vision(frame, **kw), oracle.apply_rod_vision(frame, **kw)
             assert got.dtype == frame.dtype and got.shape == frame.shape
             np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7)
+
+
+def test_uv_helpers_by_name_vs_oracle(oracle):
+    """animal_vision_amd.uv_helpers: every function name of the reference's uv_helpers.py, NumPy in / NumPy out on the device, against
+    the oracle's restatements (blurs and resizes bit-exact, elementwise float32 within the device's powf / cosf)."""
+    from animal_vision_amd import uv_helpers as uh
+
+    for name in ("to_float01", "from_float01", "srgb_to_linear", "linear_to_srgb", "safe_norm", "resize_preserve_range", "gaussian_blur", "panorama_warp",
+                 "apply_scatter_and_blue_bias", "snow_glare_tone_compress", "bandpass_weights", "integrate_band", "integrate_uv", "classic_rgb_to_hsi_scaled",
+                 "D65_like", "von_kries_white_patch", "von_kries_gray_world", "EPS_DEFAULT"):
+        assert hasattr(uh, name), name
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    f01 = rng.random((37, 53, 3), dtype=np.float32)
+    f255 = (f01 * 255).astype(np.float32)
+    for x in (u8, f01, f255, f01.astype(np.float64)):
+        got, want = uh.to_float01(x), oracle.to_float01(x)
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, want, rtol=0, atol=6e-8)
+    assert np.array_equal(uh.from_float01(f01, np.uint8), oracle.from_float01(f01, np.uint8))
+    assert uh.from_float01(f01, np.float64).dtype == np.float64
+    wide = np.concatenate([f01.ravel(), np.array([0.0, 0.04045, 0.0404501, 0.0031308, 0.0031309, 1.0, -0.2, 1.7], np.float32)])
+    np.testing.assert_allclose(uh.srgb_to_linear(wide), oracle.uv_srgb_to_linear(wide), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(uh.linear_to_srgb(wide), oracle.uv_linear_to_srgb(wide), rtol=2e-6, atol=1e-7)
+    for kw in (dict(sigma=0.1, blue_bias=0.05), dict(sigma=1.2, blue_bias=-0.02)):
+        np.testing.assert_allclose(uh.apply_scatter_and_blue_bias(f01, **kw), oracle.apply_scatter_and_blue_bias(f01, **kw), rtol=0, atol=6e-8)
+    hot = (f01 * 1.2).astype(np.float32)
+    np.testing.assert_allclose(uh.snow_glare_tone_compress(hot, strength=0.6), oracle.snow_glare_tone_compress(hot, strength=0.6), rtol=2e-7, atol=6e-8)
+    assert uh.snow_glare_tone_compress(hot, strength=0.0) is hot
+    lam = np.linspace(300.0, 700.0, 81, dtype=np.float32)
+    hsi = rng.random((20, 30, 81), dtype=np.float32)
+    np.testing.assert_allclose(uh.integrate_uv(hsi, lam, 320.0, 400.0), oracle.integrate_uv(hsi, lam, 320.0, 400.0), rtol=0, atol=2e-6)
+    U, B, G = (rng.random((25, 31), dtype=np.float32) * s for s in (0.3, 1.4, 1e-12))
+    for mine, ref in ((uh.von_kries_white_patch, oracle.von_kries_white_patch), (uh.von_kries_gray_world, oracle.von_kries_gray_world)):
+        for a, b in zip(mine(U, B, G), ref(U, B, G)):
+            np.testing.assert_allclose(a, b, rtol=2e-6, atol=0)
+    lam31 = np.linspace(400.0, 700.0, 31, dtype=np.float32)
+    got = uh.classic_rgb_to_hsi_scaled(f01[:36, :52], wavelengths=lam31, scale=0.25)
+    want = oracle.classic_rgb_to_hsi_scaled(f01[:36, :52], wavelengths=lam31, scale=0.25)
+    assert got.shape == (36, 52, 31)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7)
