@@ -197,3 +197,25 @@ def test_uv_helpers_by_name_vs_oracle(oracle):
     want = oracle.classic_rgb_to_hsi_scaled(f01[:36, :52], wavelengths=lam31, scale=0.25)
     assert got.shape == (36, 52, 31)
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7)
+
+
+def test_cat_widevision_utils_by_name_vs_oracle(oracle):
+    """animals/cat_widevision_utils.py by name: center_zoom (uint8 and float32 INTER_LINEAR), zoom_scale_from_cat_ratio, and the
+    binocular wide-FOV warp of a float [0, 1] frame (two remaps + cos^2 blend) against the oracle's restatement."""
+    from animal_vision_amd.animals import cat_widevision_utils as cw
+
+    rng = np.random.default_rng(5)
+    u8 = rng.integers(0, 256, (90, 130, 3), dtype=np.uint8)
+    f01 = rng.random((90, 130, 3), dtype=np.float32)
+    kw = dict(camera_hfov_deg=100.0, cat_per_eye_half_fov_deg=105.0, cat_to_human_ratio=1.25)
+    s = cw.zoom_scale_from_cat_ratio(**kw)
+    assert s == oracle.zoom_scale_from_cat_ratio(**kw) and s > 1.0
+    assert np.array_equal(cw.center_zoom(u8, s), oracle.center_zoom(u8, s))
+    assert cw.center_zoom(u8, 1.0) is u8
+    np.testing.assert_allclose(cw.center_zoom(f01, s), oracle.center_zoom(f01, s), rtol=0, atol=1e-7)
+    wk = dict(fov_in_deg=100.0, per_eye_half_fov_deg=105.0, overlap_deg=40.0)
+    got, want = cw.animal_fov_binocular_warp(f01, **wk), oracle.animal_fov_binocular_warp(f01, **wk)
+    assert got.dtype == np.float32 and got.shape == f01.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        cw.animal_fov_binocular_warp(f01, out_size=(64, 48), **wk)
