@@ -275,3 +275,25 @@ def test_stream_wait_forks_and_joins_lanes(oracle):
             b.free()
         for s in lanes + [main]:
             ctx.stream_destroy(s)
+
+
+def test_image_renderer_surface(tmp_path):
+    """renderers/image.py's surface: render() remembers and saves, send_image() is its alias, render_split_compare() composes the same
+    labelled half-and-half frame as VideoRenderer.make_split_frame, open() / close() exist; the GUI preview raises."""
+    from animal_vision_amd.renderers import ImageRenderer, VideoRenderer
+    from animal_vision_amd.synthetic import noise_frame, structured_frame
+
+    a, b = noise_frame(1, 120, 200), structured_frame(2, 120, 200)
+    out = os.path.join(str(tmp_path), "split.png")
+    r = ImageRenderer(save_to=out)
+    r.open()
+    r.render_split_compare(a, b, left_label="Human", right_label="Cat")
+    want = VideoRenderer(read_path=None, write_path=None).make_split_frame(a, b, left_label="Human", right_label="Cat")
+    assert np.array_equal(r.visualized_image, want)
+    assert np.array_equal(ImageRenderer(out).get_image(), want)
+    assert not np.array_equal(want[:40, :100], a[:40, :100])  # the left label is drawn
+    r.send_image(a)
+    assert r.visualized_image is a
+    r.close()
+    with pytest.raises(NotImplementedError):
+        ImageRenderer(show_window=True).render(a)
