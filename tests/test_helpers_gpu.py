@@ -219,3 +219,26 @@ def test_cat_widevision_utils_by_name_vs_oracle(oracle):
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
     with pytest.raises(NotImplementedError):
         cw.animal_fov_binocular_warp(f01, out_size=(64, 48), **wk)
+
+
+def test_animal_utils2_human_zoom_and_cat_view_vs_oracle(oracle):
+    """animals/animal_utils2.py:123-165 by name, composed here from the oracle's restatements of its parts."""
+    from animal_vision_amd.animals import animal_utils2 as au2
+
+    rng = np.random.default_rng(9)
+    kw = dict(camera_hfov_deg=100.0, cat_per_eye_half_fov_deg=105.0, binocular_overlap_deg=40.0)
+    for image in (rng.integers(0, 256, (84, 126, 3), dtype=np.uint8), rng.random((84, 126, 3), dtype=np.float32)):
+        zoomed, cat = au2.human_zoom_and_cat_view(image, **kw)
+        assert zoomed.dtype == image.dtype and cat.dtype == image.dtype and zoomed.shape == cat.shape == image.shape
+        scale = oracle.zoom_scale_from_cat_ratio(camera_hfov_deg=100.0, cat_per_eye_half_fov_deg=105.0, cat_to_human_ratio=1.30)
+        want_zoom = oracle.center_zoom(image, scale)
+        img01 = image.astype(np.float32) / 255.0 if image.dtype == np.uint8 else image
+        want_cat01 = oracle.animal_fov_binocular_warp(np.clip(img01, 0, 1).astype(np.float32), fov_in_deg=100.0, per_eye_half_fov_deg=105.0, overlap_deg=40.0)
+        if image.dtype == np.uint8:
+            assert np.array_equal(zoomed, want_zoom)
+            want_cat = (np.clip(want_cat01, 0, 1) * 255.0 + 0.5).astype(np.uint8)
+            d = np.abs(cat.astype(np.int16) - want_cat.astype(np.int16))
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        else:
+            np.testing.assert_allclose(zoomed, np.clip(want_zoom, 0, 1), rtol=0, atol=1e-7)
+            np.testing.assert_allclose(cat, np.clip(want_cat01, 0, 1), rtol=0, atol=2e-6)
