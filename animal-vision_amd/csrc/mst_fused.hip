@@ -542,6 +542,83 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
 }
 
 
+// ---- encoder downsampling: Conv2d(32 -> 64, kernel 4, stride 2, padding 1, no bias) (MST.encoder_layers[0][1], :206-208) ------------
+// Implicit GEMM, K = 16 taps x 32 channels, N = 64.  A workgroup owns 8 x 16 output pixels; their 18 x 34 input pixels (zeros outside the
+// image) are staged once in LDS (next tile's rows in flight during the MFMAs).  Wave w takes the two output rows 2 (w & 3), + 1 (32
+// pixels) and the 32-channel output tile w >> 2, and keeps ITS 32 weight fragments (16 taps x 2 K-steps) in 128 VGPRs for the whole
+// launch -- one workgroup per CU, two waves per SIMD, so there is room -- which leaves one 16-byte LDS read (the pixel operand) per MFMA.
+// Replaces a MIOpen implicit-GEMM launch (334 us per 4K call) and the zero fill its split-K form needs.
+constexpr int DT_OH = 8, DT_OW = 16, DT_IH = 2 * DT_OH + 2, DT_IW = 2 * DT_OW + 2;
+__global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_32(const __half* __restrict__ x /*[B][H][W][32]*/, const uint4* __restrict__ wpack /*[16][2][2][64]*/,
+                                                           __half* __restrict__ out /*[B][H/2][W/2][64]*/, int B, int H, int W) {
+    constexpr int C = 32, CO = 64, PP = C * 2 + 16, RP = (DT_IW * PP + 255) / 256 * 256, NFILL = (DT_IH * DT_IW * 4 + kFT - 1) / kFT;
+    __shared__ __align__(16) unsigned char xt[DT_IH * RP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    const int g = wave & 3, nt = wave >> 2;
+    half8_t wf[32];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) wf[2 * t + s2] = __builtin_bit_cast(half8_t, wpack[((size_t)(t * 2 + nt) * 2 + s2) * 64 + lane]);
+    const int Ho = H / 2, Wo = W / 2;
+    const int tx = (Wo + DT_OW - 1) / DT_OW, ty = (Ho + DT_OH - 1) / DT_OH;
+    const long total = (long)B * ty * tx;
+    struct T2 { int ox0, oy0; long b; };
+    auto tile_of = [&](long t) { return T2{(int)(t % tx) * DT_OW, (int)((t / tx) % ty) * DT_OH, t / ((long)tx * ty)}; };
+    uint4 pre[NFILL];
+    auto fetch = [&](const T2& t) {
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            const int it = tid + k * kFT, q = it >> 2, part = it & 3;
+            const int yy = 2 * t.oy0 - 1 + q / DT_IW, xx = 2 * t.ox0 - 1 + q % DT_IW;
+            const bool ok = it < DT_IH * DT_IW * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            uint4 r = *reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + 8 * part);
+            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
+            pre[k] = r;
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile >= total) return;
+    T2 t = tile_of(tile);
+    fetch(t);
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            const int it = tid + k * kFT, q = it >> 2, part = it & 3;
+            if (it < DT_IH * DT_IW * 4) *reinterpret_cast<uint4*>(xt + (size_t)(q / DT_IW) * RP + (size_t)(q % DT_IW) * PP + 16 * part) = pre[k];
+        }
+        __syncthreads();
+        const long next = tile + gridDim.x;
+        if (next < total) fetch(tile_of(next));
+        {
+            const int r = 2 * g + (p >> 4), c = p & 15;  // output pixel of this lane inside the tile
+            float16_t d;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[v] = 0.f;
+            const unsigned char* src = xt + (size_t)(2 * r) * RP + (size_t)(2 * c) * PP + 16 * h;  // tap (0, 0): input (2 r - 1 + 0, 2 c - 1 + 0) = tile row 2 r, col 2 c
+#pragma unroll
+            for (int tap = 0; tap < 16; ++tap)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    d = mfma16(wf[2 * tap + s2], __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(src + (size_t)(tap / 4) * RP + (size_t)(tap % 4) * PP + 32 * s2)), d);
+            const int yo = t.oy0 + r, xo = t.ox0 + c;
+            if (yo < Ho && xo < Wo) {
+                half8_t o0, o1;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)d[v]; o1[v] = (_Float16)d[8 + v]; }
+                __half* dst = out + ((t.b * Ho + yo) * (size_t)Wo + xo) * CO + 32 * nt + 16 * h;
+                reinterpret_cast<uint4*>(dst)[0] = __builtin_bit_cast(uint4, o0);
+                reinterpret_cast<uint4*>(dst)[1] = __builtin_bit_cast(uint4, o1);
+            }
+        }
+        if (next >= total) break;
+        tile = next;
+        t = tile_of(tile);
+        __syncthreads();  // everyone is done reading xt
+    }
+}
+
 // ---- uint8 frame -> conv_in output (MST_Plus_Plus.conv_in :275, 3 -> 31 channels, 3x3, zero padding 1) in one kernel --------------------
 // Replaces: uint8 -> float32 / 255 -> NCHW -> reflect pad to the predictor's stride (predict_torch.py:171-183) -> float16 -> channels-last
 // copy -> a MIOpen convolution (five elementwise launches and a library conv: ~1 ms per 4K frame).  A thread owns one output pixel: its 27
@@ -740,6 +817,21 @@ extern "C" int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H,
         hipLaunchKernelGGL(k_mst_conv_in_u8_mfma, dim3((unsigned)(wantm < cap ? wantm : cap)), dim3(256), 0, s, frame_hwc, w_27x32_dev, (__half*)out, H, W, pad_top,
                            pad_left, Hp, Wp);
     }
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+extern "C" int avx_mst_down4x4(avx_ctx* ctx, const void* x, const void* wpack16, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack16 && out && B > 0 && H > 0 && W > 0, "avx_mst_down4x4: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32, "avx_mst_down4x4: C=%d (32: the full-resolution encoder step, 31 -> 62 channels stored 32 -> 64)", C);
+    AVX_REQUIRE(ctx, H % 2 == 0 && W % 2 == 0, "avx_mst_down4x4: H and W must be even (the model pads frames to multiples of 8)");
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack16 | (uintptr_t)out)) & 15u) == 0, "avx_mst_down4x4: pointers must be 16-byte aligned");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    const long total = (long)B * ((H / 2 + DT_OH - 1) / DT_OH) * ((W / 2 + DT_OW - 1) / DT_OW);
+    const long cap = (long)ctx->num_cus;
+    hipLaunchKernelGGL(k_mst_down4x4_32, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (__half*)out, B, H, W);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -107,6 +107,12 @@ def pack_fragments16(w_kn: torch.Tensor) -> torch.Tensor:
     return torch.take(w_kn.contiguous(), idx)
 
 
+def pack_down4x4(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, 4, 4) float16 stride-2 conv weight -> [16 taps][Cout/32][Cin/16][64][8] fragments (tap = 4 ky + kx), the A operands
+    of csrc/mst_fused.hip::k_mst_down4x4_32."""
+    return torch.stack([pack_fragments16(w[:, :, t // 4, t % 4].t().contiguous()) for t in range(16)]).contiguous()
+
+
 class _AvxOps:
     """Binds the hand-written gfx950 kernels of csrc/mst.hip for CUDA tensors (data_ptr hand-off on torch's
     current stream).  AVX_MST_TORCH_ONLY=1 keeps every op in torch (A/B and debugging)."""
@@ -123,6 +129,7 @@ class _AvxOps:
         self._upfuse = os.environ.get("AVX_MST_NO_UPFUSE", "") == ""  # A/B: transposed conv + fusion conv in one pass
         self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
         self._tailx = os.environ.get("AVX_MST_NO_TAILX", "") == ""  # A/B: the tail forms v = x W_v^T itself, the Gram pass writes no v
+        self._down = os.environ.get("AVX_MST_NO_DOWN4X4", "") == ""  # A/B: hand-written 32 -> 64 stride-2 conv instead of MIOpen's implicit GEMM
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
         self._ctx = {}
@@ -250,6 +257,18 @@ class _AvxOps:
         ctx = self.ctx(frame.device)
         ctx._check(lib.avx_mst_conv_in_u8(ctx._h, frame.data_ptr(), H, W, t, b, l, r, w_27x32.data_ptr(), out.data_ptr(),
                                           torch.cuda.current_stream(frame.device).cuda_stream))
+        return out
+
+    def down4x4(self, x: torch.Tensor, wpack16: torch.Tensor) -> torch.Tensor:
+        """Conv2d(32 -> 64, 4, stride 2, padding 1) on (b, h, w, 32) float16 through an LDS halo tile with the wave's weights
+        held in registers (csrc/mst_fused.hip::k_mst_down4x4_32)."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        assert x.is_contiguous() and c == 32 and h % 2 == 0 and w % 2 == 0
+        out = torch.empty((b, h // 2, w // 2, 2 * c), dtype=torch.float16, device=x.device)
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_down4x4(ctx._h, x.data_ptr(), wpack16.data_ptr(), out.data_ptr(), b, h, w, c, torch.cuda.current_stream(x.device).cuda_stream))
         return out
 
     def conv3x3_lds(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:
@@ -646,7 +665,11 @@ class MSTPlusPlus(torch.nn.Module):
         for i in range(2):
             fea = self._msab(fea, f"{p}.encoder_layers.{i}.0", heads)
             skips.append(fea)
-            fea = self._conv_nhwc(fea, self._w(f"{p}.encoder_layers.{i}.1.weight", (0, 1)), stride=2, padding=1)
+            dkey = f"{p}.encoder_layers.{i}.1.weight"
+            if _AVX.fused_ok(fea) and _AVX._down and fea.shape[-1] == 32 and fea.is_contiguous():  # full resolution: the hand-written implicit GEMM
+                fea = _AVX.down4x4(fea, self._prep(dkey + ".frag16", lambda: pack_down4x4(self._w(dkey, (0, 1)))))
+            else:
+                fea = self._conv_nhwc(fea, self._w(dkey, (0, 1)), stride=2, padding=1)
             heads *= 2
         fea = self._msab(fea, p + ".bottleneck", heads)
         for i in range(2):

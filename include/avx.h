@@ -361,6 +361,9 @@ int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H, int W, int
 /* avx_mst_conv3x3_add through an LDS halo tile (16 x 16 pixels, every input pixel fetched once): wpack16 = the nine taps' C x C
  * weights as v_mfma_f32_32x32x16_f16 A fragments ([9][2][64][8] float16, ml/mst_plus_plus.py::pack_fragments16 per tap). */
 int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int B, int H, int W, int C, void* stream);
+/* MST.encoder_layers[i][1] at full resolution (MST_Plus_Plus.py:206-208): Conv2d(C -> 2C, 4, stride 2, padding 1, bias=False) on (B, H, W, C)
+ * float16 -> (B, H/2, W/2, 2C), C = 32; wpack16 = [16 taps][2C/32][C/16] fragments (pack_fragments16 of W[:, :, ky, kx]^T). */
+int avx_mst_down4x4(avx_ctx* ctx, const void* x, const void* wpack16, void* out, int B, int H, int W, int C, void* stream);
 
 /* The tail of the first half of an MSAB block in one pass (MS_MSA :104-106, :132-137; MSAB :183):
  * out = v @ M + bias + dw3x3(gelu(dw3x3(v))) + x on (B, H, W, C) float16 tensors, C = 32 or 64, with M the per-frame C x C matrix
