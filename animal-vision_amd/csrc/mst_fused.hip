@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
 constexpr int DT_OH = 8, DT_OW = 16, DT_IH = 2 * DT_OH + 2, DT_IW = 2 * DT_OW + 2;
 __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_32(const __half* __restrict__ x /*[B][H][W][32]*/, const uint4* __restrict__ wpack /*[16][2][2][64]*/,
                                                            __half* __restrict__ out /*[B][H/2][W/2][64]*/, int B, int H, int W) {
-    constexpr int C = 32, CO = 64, PP = C * 2 + 16, RP = (DT_IW * PP + 255) / 256 * 256, NFILL = (DT_IH * DT_IW * 4 + kFT - 1) / kFT;
+    constexpr int C = 32, CO = 64, PP = C * 2 + 16, RP = DT_IW * PP + 16 /* odd in 16-byte slots: a ds_read_b128 lane group spans two output rows */, NFILL = (DT_IH * DT_IW * 4 + kFT - 1) / kFT;
     __shared__ __align__(16) unsigned char xt[DT_IH * RP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
     const int g = wave & 3, nt = wave >> 2;
@@ -564,18 +564,18 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_32(const __half* __restr
     const int tx = (Wo + DT_OW - 1) / DT_OW, ty = (Ho + DT_OH - 1) / DT_OH;
     const long total = (long)B * ty * tx;
     struct T2 { int ox0, oy0; long b; };
-    auto tile_of = [&](long t) { return T2{(int)(t % tx) * DT_OW, (int)((t / tx) % ty) * DT_OH, t / ((long)tx * ty)}; };
+    auto tile_of = [&](long t) { const unsigned u = (unsigned)t, row = u / (unsigned)tx; return T2{(int)(u - row * tx) * DT_OW, (int)(row % (unsigned)ty) * DT_OH, (long)(row / (unsigned)ty)}; };
     uint4 pre[NFILL];
+    unsigned okmask = 0;  // bit k: pre[k] is a pixel of the image (the others are the padding zeros / past the tile)
     auto fetch = [&](const T2& t) {
+        okmask = 0;
 #pragma unroll
         for (int k = 0; k < NFILL; ++k) {
             const int it = tid + k * kFT, q = it >> 2, part = it & 3;
             const int yy = 2 * t.oy0 - 1 + q / DT_IW, xx = 2 * t.ox0 - 1 + q % DT_IW;
-            const bool ok = it < DT_IH * DT_IW * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            okmask |= (it < DT_IH * DT_IW * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1u << k : 0u;
             const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            uint4 r = *reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + 8 * part);
-            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
-            pre[k] = r;
+            pre[k] = *reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + 8 * part);  // clamped: always a valid address
         }
     };
     long tile = blockIdx.x;
@@ -586,22 +586,40 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_32(const __half* __restr
 #pragma unroll
         for (int k = 0; k < NFILL; ++k) {
             const int it = tid + k * kFT, q = it >> 2, part = it & 3;
-            if (it < DT_IH * DT_IW * 4) *reinterpret_cast<uint4*>(xt + (size_t)(q / DT_IW) * RP + (size_t)(q % DT_IW) * PP + 16 * part) = pre[k];
+            const bool ok = okmask >> k & 1;
+            uint4 r = pre[k];
+            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
+            if (it < DT_IH * DT_IW * 4) *reinterpret_cast<uint4*>(xt + (size_t)(q / DT_IW) * RP + (size_t)(q % DT_IW) * PP + 16 * part) = r;
         }
         __syncthreads();
         const long next = tile + gridDim.x;
         if (next < total) fetch(tile_of(next));
         {
             const int r = 2 * g + (p >> 4), c = p & 15;  // output pixel of this lane inside the tile
-            float16_t d;
+            float16_t d, d1;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) d[v] = 0.f;
-            const unsigned char* src = xt + (size_t)(2 * r) * RP + (size_t)(2 * c) * PP + 16 * h;  // tap (0, 0): input (2 r - 1 + 0, 2 c - 1 + 0) = tile row 2 r, col 2 c
+            for (int v = 0; v < 16; ++v) d[v] = 0.f, d1[v] = 0.f;
+            const unsigned char* src = xt + (size_t)(2 * r) * RP + (size_t)(2 * c) * PP + 16 * h;  // tap (ky, kx) reads input (2 r - 1 + ky, 2 c - 1 + kx) = tile row 2 r + ky, col 2 c + kx
+            auto frag = [&](int i) { return *reinterpret_cast<const uint4*>(src + (size_t)(i / 8) * RP + (size_t)(i / 2 % 4) * PP + 32 * (i & 1)); };  // i = 2 tap + K-step
+            constexpr int AHEAD = 6;  // pixel operands in flight ahead of the MFMA that takes them; two accumulators halve the dependent chain
+            uint4 bq[AHEAD];
 #pragma unroll
-            for (int tap = 0; tap < 16; ++tap)
+            for (int i = 0; i < AHEAD; ++i) bq[i] = frag(i);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    d = mfma16(wf[2 * tap + s2], __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(src + (size_t)(tap / 4) * RP + (size_t)(tap % 4) * PP + 32 * s2)), d);
+            for (int i = 0; i < 32; ++i) {
+                if (i & 1) d1 = mfma16(wf[i], __builtin_bit_cast(half8_t, bq[i % AHEAD]), d1);
+                else d = mfma16(wf[i], __builtin_bit_cast(half8_t, bq[i % AHEAD]), d);
+                if (i + AHEAD < 32) bq[i % AHEAD] = frag(i + AHEAD);
+            }
+            // the order above IS the schedule: left alone the scheduler sinks every read next to its MFMA (lowest register pressure) and the LDS latency shows 16 times
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i + AHEAD < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[v] += d1[v];
             const int yo = t.oy0 + r, xo = t.ox0 + c;
             if (yo < Ho && xo < Wo) {
                 half8_t o0, o1;
