@@ -162,6 +162,8 @@ int avx_init(int device, avx_ctx** out_ctx) {
     INIT_HIP(hipEventCreate(&ctx->t0));
     INIT_HIP(hipEventCreate(&ctx->t1));
     INIT_HIP(hipMalloc((void**)&ctx->d_decode_lut, 256 * sizeof(float)));
+    INIT_HIP(hipMalloc(&ctx->d_zero, 256));
+    INIT_HIP(hipMemset(ctx->d_zero, 0, 256));
     INIT_HIP(hipMalloc((void**)&ctx->d_enc_thr_f32, 256 * sizeof(float)));
     INIT_HIP(hipMalloc((void**)&ctx->d_enc_thr_f64, 256 * sizeof(double)));
     INIT_HIP(hipMemcpy(ctx->d_decode_lut, kDecodeLutBits, 256 * 4, hipMemcpyHostToDevice));
@@ -215,6 +217,7 @@ void avx_destroy(avx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->d_decode_lut) (void)hipFree(ctx->d_decode_lut);
+    if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->d_enc_thr_f32) (void)hipFree(ctx->d_enc_thr_f32);
     if (ctx->d_enc_thr_f64) (void)hipFree(ctx->d_enc_thr_f64);
     if (ctx->d_coarse_f32) (void)hipFree(ctx->d_coarse_f32);

@@ -45,6 +45,7 @@ struct avx_ctx {
     char err[512] = {0};
     // constant tables (reference outputs, csrc/srgb_tables.h), resident for the ctx lifetime
     float* d_decode_lut = nullptr;   // 256
+    void* d_zero = nullptr;          // 256 zero bytes: where the LDS-direct loads of padding pixels point (mst_fused.hip)
     float* d_enc_thr_f32 = nullptr;  // 255 (+1 pad)
     double* d_enc_thr_f64 = nullptr; // 255 (+1 pad)
     // bucketed quantiser (csrc/dichromat.hip quantize_coarse): per top-bits bucket, #thresholds <= bucket start

@@ -542,66 +542,126 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
 }
 
 
-// ---- encoder downsampling: Conv2d(32 -> 64, kernel 4, stride 2, padding 1, no bias) (MST.encoder_layers[0][1], :206-208) ------------
-// Implicit GEMM, K = 16 taps x 32 channels, N = 64.  A workgroup owns 8 x 16 output pixels; their 18 x 34 input pixels (zeros outside the
-// image) are staged once in LDS (next tile's rows in flight during the MFMAs).  Wave w takes the two output rows 2 (w & 3), + 1 (32
-// pixels) and the 32-channel output tile w >> 2, and keeps ITS 32 weight fragments (16 taps x 2 K-steps) in 128 VGPRs for the whole
-// launch -- one workgroup per CU, two waves per SIMD, so there is room -- which leaves one 16-byte LDS read (the pixel operand) per MFMA.
-// Replaces a MIOpen implicit-GEMM launch (334 us per 4K call) and the zero fill its split-K form needs.
-constexpr int DT_OH = 8, DT_OW = 16, DT_IH = 2 * DT_OH + 2, DT_IW = 2 * DT_OW + 2;
-__global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_32(const __half* __restrict__ x /*[B][H][W][32]*/, const uint4* __restrict__ wpack /*[16][2][2][64]*/,
-                                                           __half* __restrict__ out /*[B][H/2][W/2][64]*/, int B, int H, int W) {
-    constexpr int C = 32, CO = 64, PP = C * 2 + 16, RP = DT_IW * PP + 16 /* odd in 16-byte slots: a ds_read_b128 lane group spans two output rows */, NFILL = (DT_IH * DT_IW * 4 + kFT - 1) / kFT;
-    __shared__ __align__(16) unsigned char xt[DT_IH * RP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
-    const int g = wave & 3, nt = wave >> 2;
+// ---- encoder downsampling: Conv2d(C -> 2C, kernel 4, stride 2, padding 1, no bias), C = 32 and 64 as stored (MST.encoder_layers[i][1], :206-208) ----
+// Implicit GEMM, K = 16 taps x C channels.  A workgroup owns OH x 16 output pixels; their (2 OH + 2) x 34 input pixels (zeros outside the
+// image) are staged once in LDS; a wave keeps ITS 32 weight fragments (32 output channels x 512 of K) in 128 VGPRs for the whole launch
+// -- one workgroup per CU, two waves per SIMD, so there is room -- which leaves one 16-byte LDS read (the pixel operand) per MFMA, issued
+// six ahead of the MFMA that takes it.  The halo tile comes in by LDS-direct loads (global_load_lds_dwordx4: lane l's 16 bytes land at
+// M0 + 16 l, no VGPR, no ds_write): no prefetch registers, no LDS-write cycles (a ds_write_b128 is 13), and the loads of the next tiles
+// (C = 32: three buffers, two tiles ahead) are in flight under the MFMAs of this one -- with one workgroup per CU that depth is what hides
+// the HBM latency.  Replaces MIOpen's implicit GEMM (4K: 471 -> 209 us at C = 32, 319 -> 156 us at C = 64, alone on the GPU) and the
+// zero fill its split-K form needs.
+//   layout   slot (16 bytes) of part j of tile pixel (row, col) = row * RPS + col * NP + (j ^ swz(col)); RPS = 34 NP + 2 (C = 32) / + 4
+//            (C = 64) slots and swz(col) = (col >> 2) & 3 / (col >> 1) & 7 make every 16-lane group of the operand's ds_read_b128 --
+//            eight pixels two columns apart on each of two tile rows -- cover the 16 slots of the 256-byte bank row exactly once.
+//   fill     slot L of the buffer is loaded by lane L % 64 of load L / 64; padding pixels and tiles past the end read 16 zero
+//            bytes (ctx->d_zero; pad slots, which nobody reads, whatever is cheapest), so every wave issues the same number of loads per tile and s_waitcnt vmcnt(n) can count them.  The loads are
+//            inline asm (the compiler waits for vmcnt(0) in front of every LDS read that follows a load it knows writes the LDS).
+//   C = 64   the wave's 128-VGPR weight budget holds 32 output channels x half of K: waves 4-7 take kernel rows 2-3 and hand their partial
+//            sums to waves 0-3 through the LDS (one barrier per 32-pixel group).
+template <int C>
+struct DownGeo {
+    static constexpr int OH = C == 32 ? 8 : 4, OW = 16, IH = 2 * OH + 2, IW = 2 * OW + 2;
+    static constexpr int NP = C / 8;                                // 16-byte parts of a pixel
+    static constexpr int RPS = IW * NP + (C == 32 ? 2 : 4);        // row pitch, slots
+    static constexpr int NI = ((IH * RPS + 63) / 64 + 7) / 8 * 8;  // loads per tile, the same count in each of the 8 waves
+    static constexpr int PER_WAVE = NI / 8, BUF = NI * 1024, NBUF = C == 32 ? 3 : 2, GROUPS = OH / 2;
+    static constexpr int PART = C == 32 ? 0 : 2 * 4 * 4096;        // [group parity][output tile][lane-major float16_t]
+    __device__ static int swz(int col) { return C == 32 ? (col >> 2) & 3 : (col >> 1) & 7; }
+};
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // "m0 is reserved": nothing of the compiler's lives in M0 across these kernels (no indirect register indexing, no LDS-load builtin)
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_base /*the same in every lane*/) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(g) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma16(const void* base /*the same in every lane*/, unsigned ofs, unsigned lds_base) {  // base + ofs: no 64-bit lane arithmetic
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(ofs), "s"(base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int C>
+__global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_dma(const __half* __restrict__ x /*[B][H][W][C]*/, const uint4* __restrict__ wpack /*[16][2C/32][C/16][64]*/,
+                                                            __half* __restrict__ out /*[B][H/2][W/2][2C]*/, const void* __restrict__ zero, int B, int H, int W) {
+    using G = DownGeo<C>;
+    constexpr int CO = 2 * C, NT = CO / 32, KS = C / 16;
+    __shared__ __align__(1024) unsigned char lds[G::NBUF * G::BUF + G::PART];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6) /*scalar: what depends on it stays off the VALU*/, p = lane & 31, h = lane >> 5;
+    const int g0 = C == 32 ? wave & 3 : 0, nt = C == 32 ? wave >> 2 : wave & 3, kh = C == 32 ? 0 : wave >> 2;
     half8_t wf[32];
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) wf[2 * t + s2] = __builtin_bit_cast(half8_t, wpack[((size_t)(t * 2 + nt) * 2 + s2) * 64 + lane]);
+    for (int i = 0; i < 32; ++i) {
+        const int tap = C == 32 ? i >> 1 : 8 * kh + (i >> 2), s2 = C == 32 ? i & 1 : i & 3;
+        wf[i] = __builtin_bit_cast(half8_t, wpack[((size_t)(tap * NT + nt) * KS + s2) * 64 + lane]);
+    }
     const int Ho = H / 2, Wo = W / 2;
-    const int tx = (Wo + DT_OW - 1) / DT_OW, ty = (Ho + DT_OH - 1) / DT_OH;
-    const long total = (long)B * ty * tx;
-    struct T2 { int ox0, oy0; long b; };
-    auto tile_of = [&](long t) { const unsigned u = (unsigned)t, row = u / (unsigned)tx; return T2{(int)(u - row * tx) * DT_OW, (int)(row % (unsigned)ty) * DT_OH, (long)(row / (unsigned)ty)}; };
-    uint4 pre[NFILL];
-    unsigned okmask = 0;  // bit k: pre[k] is a pixel of the image (the others are the padding zeros / past the tile)
-    auto fetch = [&](const T2& t) {
-        okmask = 0;
+    const int tx = (Wo + G::OW - 1) / G::OW, ty = (Ho + G::OH - 1) / G::OH;
+    const unsigned total = (unsigned)B * ty * tx;
+    struct T2 { int ox0, oy0, b; };
+    auto tile_of = [&](unsigned u) { const unsigned row = u / (unsigned)tx; return T2{(int)(u - row * tx) * G::OW, (int)(row % (unsigned)ty) * G::OH, (int)(row / (unsigned)ty)}; };
+    // this lane's slots of a tile: tile-relative pixel and byte offset, fixed for the launch
+    int rel[G::PER_WAVE], rc[G::PER_WAVE];
 #pragma unroll
-        for (int k = 0; k < NFILL; ++k) {
-            const int it = tid + k * kFT, q = it >> 2, part = it & 3;
-            const int yy = 2 * t.oy0 - 1 + q / DT_IW, xx = 2 * t.ox0 - 1 + q % DT_IW;
-            okmask |= (it < DT_IH * DT_IW * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1u << k : 0u;
-            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            pre[k] = *reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + 8 * part);  // clamped: always a valid address
+    for (int k = 0; k < G::PER_WAVE; ++k) {
+        const int L = (wave + 8 * k) * 64 + lane, row = L / G::RPS, rem = L - row * G::RPS, col = rem / G::NP, j = (rem - col * G::NP) ^ G::swz(col);
+        const bool inside = row < G::IH && col < G::IW;
+        rel[k] = inside ? (row * W + col) * (C * 2) + 16 * j : 0;
+        rc[k] = inside ? row << 8 | col : -1;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds);
+    auto fill = [&](unsigned u, int slot) {
+        const bool exists = u < total;
+        const T2 t = tile_of(exists ? u : 0u);
+        const int y0 = 2 * t.oy0 - 1, x0 = 2 * t.ox0 - 1;
+        const char* origin = reinterpret_cast<const char*>(x) + (((long)t.b * H + y0) * W + x0) * (long)(C * 2);
+        const unsigned lb = lds0 + slot * G::BUF + wave * 1024;
+        if (exists && y0 >= 0 && y0 + G::IH <= H && x0 >= 0 && x0 + G::IW <= W) {  // no padding in sight (all but the frame's border tiles): scalar base + the lane's fixed offset
+#pragma unroll
+            for (int k = 0; k < G::PER_WAVE; ++k) lds_dma16(origin /*scalar: the tile index is*/, (unsigned)rel[k], lb + k * 8192);  // pad slots (offset 0) are never read: anything valid will do
+        } else {
+#pragma unroll
+            for (int k = 0; k < G::PER_WAVE; ++k) {
+                const int yy = y0 + (rc[k] >> 8), xx = x0 + (rc[k] & 255);
+                const bool ok = exists && rc[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                lds_dma16(ok ? (const void*)(origin + rel[k]) : zero, lb + k * 8192);
+            }
         }
     };
-    long tile = blockIdx.x;
+    unsigned tile = blockIdx.x;
     if (tile >= total) return;
-    T2 t = tile_of(tile);
-    fetch(t);
-    for (;;) {
 #pragma unroll
-        for (int k = 0; k < NFILL; ++k) {
-            const int it = tid + k * kFT, q = it >> 2, part = it & 3;
-            const bool ok = okmask >> k & 1;
-            uint4 r = pre[k];
-            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
-            if (it < DT_IH * DT_IW * 4) *reinterpret_cast<uint4*>(xt + (size_t)(q / DT_IW) * RP + (size_t)(q % DT_IW) * PP + 16 * part) = r;
-        }
-        __syncthreads();
-        const long next = tile + gridDim.x;
-        if (next < total) fetch(tile_of(next));
+    for (int a = 0; a < G::NBUF - 1; ++a) fill(tile + a * gridDim.x, a);
+    // operand addressing: pixel (row 2 g + (p >> 4), col p & 15) of the group; tap (ky, kx) reads tile pixel (2 row + ky, 2 col + kx)
+    const int c2 = 2 * (p & 15);
+    int colofs[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) colofs[kx] = (c2 + kx) * G::NP;
+    int slot = 0, plain_stores = 0;  // how many of the last tiles in a row stored every pixel (capped at NBUF - 1)
+    for (;;) {
+        // This tile's loads have landed once no more operations are pending than were issued after them: the look-ahead tiles' loads
+        // (NBUF - 2 tiles) and the output stores of the NBUF - 1 tiles before this one -- two per group when the tile lay inside the frame
+        // (vmcnt counts loads and stores in issue order), an unknown number (the compiler may branch around them) when it did not.
+        if (plain_stores == G::NBUF - 1 && (C == 32 || kh == 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_WAVE * (G::NBUF - 2) + 2 * (C == 32 ? 1 : G::GROUPS) * (G::NBUF - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_WAVE * (G::NBUF - 2)) : "memory");
+        __syncthreads();  // every wave's share has landed; every wave is done with the buffer filled next
         {
-            const int r = 2 * g + (p >> 4), c = p & 15;  // output pixel of this lane inside the tile
+            int nslot = slot + G::NBUF - 1;
+            nslot -= nslot >= G::NBUF ? G::NBUF : 0;
+            fill(tile + (G::NBUF - 1) * gridDim.x, nslot);
+        }
+        const T2 t = tile_of(tile);
+        const bool whole = t.oy0 + G::OH <= Ho && t.ox0 + G::OW <= Wo;
+        const unsigned char* bt = lds + slot * G::BUF;
+#pragma unroll 1
+        for (int g = g0; g < (C == 32 ? g0 + 1 : G::GROUPS); ++g) {
+            const int r = 2 * g + (p >> 4);
             float16_t d, d1;
 #pragma unroll
             for (int v = 0; v < 16; ++v) d[v] = 0.f, d1[v] = 0.f;
-            const unsigned char* src = xt + (size_t)(2 * r) * RP + (size_t)(2 * c) * PP + 16 * h;  // tap (ky, kx) reads input (2 r - 1 + ky, 2 c - 1 + kx) = tile row 2 r + ky, col 2 c + kx
-            auto frag = [&](int i) { return *reinterpret_cast<const uint4*>(src + (size_t)(i / 8) * RP + (size_t)(i / 2 % 4) * PP + 32 * (i & 1)); };  // i = 2 tap + K-step
-            constexpr int AHEAD = 6;  // pixel operands in flight ahead of the MFMA that takes them; two accumulators halve the dependent chain
+            const unsigned char* src = bt + (size_t)(2 * r) * (G::RPS * 16);
+            auto frag = [&](int i) {  // i-th weight fragment's pixel operand
+                const int tap = C == 32 ? i >> 1 : 8 * kh + (i >> 2), s2 = C == 32 ? i & 1 : i & 3, ky = tap >> 2, kx = tap & 3;
+                return *reinterpret_cast<const uint4*>(src + ky * (G::RPS * 16) + (colofs[kx] + ((2 * s2 + h) ^ G::swz(c2 + kx))) * 16);
+            };
+            constexpr int AHEAD = 6;
             uint4 bq[AHEAD];
 #pragma unroll
             for (int i = 0; i < AHEAD; ++i) bq[i] = frag(i);
@@ -620,21 +680,39 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_32(const __half* __restr
             }
 #pragma unroll
             for (int v = 0; v < 16; ++v) d[v] += d1[v];
-            const int yo = t.oy0 + r, xo = t.ox0 + c;
-            if (yo < Ho && xo < Wo) {
-                half8_t o0, o1;
+            if constexpr (C == 64) {  // K halves meet in the LDS
+                float4* part = reinterpret_cast<float4*>(lds + G::NBUF * G::BUF + ((g & 1) * 4 + nt) * 4096);
+                if (kh == 1) {
 #pragma unroll
-                for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)d[v]; o1[v] = (_Float16)d[8 + v]; }
-                __half* dst = out + ((t.b * Ho + yo) * (size_t)Wo + xo) * CO + 32 * nt + 16 * h;
+                    for (int v4 = 0; v4 < 4; ++v4) part[v4 * 64 + lane] = float4{d[4 * v4], d[4 * v4 + 1], d[4 * v4 + 2], d[4 * v4 + 3]};
+                }
+                __syncthreads();
+                if (kh == 1) continue;
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const float4 q = part[v4 * 64 + lane];
+                    d[4 * v4] += q.x; d[4 * v4 + 1] += q.y; d[4 * v4 + 2] += q.z; d[4 * v4 + 3] += q.w;
+                }
+            }
+            const int yo = t.oy0 + r, xo = t.ox0 + (p & 15);
+            half8_t o0, o1;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)d[v]; o1[v] = (_Float16)d[8 + v]; }
+            __half* dst = out + (((size_t)t.b * Ho + yo) * Wo + xo) * CO + 32 * nt + 16 * h;
+            if (whole) {  // every lane stores: exactly two stores, counted on above
+                reinterpret_cast<uint4*>(dst)[0] = __builtin_bit_cast(uint4, o0);
+                reinterpret_cast<uint4*>(dst)[1] = __builtin_bit_cast(uint4, o1);
+            } else if (yo < Ho && xo < Wo) {
                 reinterpret_cast<uint4*>(dst)[0] = __builtin_bit_cast(uint4, o0);
                 reinterpret_cast<uint4*>(dst)[1] = __builtin_bit_cast(uint4, o1);
             }
         }
-        if (next >= total) break;
-        tile = next;
-        t = tile_of(tile);
-        __syncthreads();  // everyone is done reading xt
+        plain_stores = whole ? (plain_stores < G::NBUF - 1 ? plain_stores + 1 : plain_stores) : 0;
+        if (tile + gridDim.x >= total) break;
+        tile += gridDim.x;
+        slot = slot + 1 == G::NBUF ? 0 : slot + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of tiles past the end still target this workgroup's LDS
 }
 
 // ---- uint8 frame -> conv_in output (MST_Plus_Plus.conv_in :275, 3 -> 31 channels, 3x3, zero padding 1) in one kernel --------------------
@@ -842,14 +920,22 @@ extern "C" int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H,
 extern "C" int avx_mst_down4x4(avx_ctx* ctx, const void* x, const void* wpack16, void* out, int B, int H, int W, int C, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, x && wpack16 && out && B > 0 && H > 0 && W > 0, "avx_mst_down4x4: NULL pointer or empty tensor");
-    AVX_REQUIRE(ctx, C == 32, "avx_mst_down4x4: C=%d (32: the full-resolution encoder step, 31 -> 62 channels stored 32 -> 64)", C);
+    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_down4x4: C=%d (32 or 64: the encoder steps 31 -> 62 and 62 -> 124 channels as stored)", C);
     AVX_REQUIRE(ctx, H % 2 == 0 && W % 2 == 0, "avx_mst_down4x4: H and W must be even (the model pads frames to multiples of 8)");
+    AVX_REQUIRE(ctx, (long)B * H * W * C * 2 < (1l << 31), "avx_mst_down4x4: input larger than 2 GiB");
     AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack16 | (uintptr_t)out)) & 15u) == 0, "avx_mst_down4x4: pointers must be 16-byte aligned");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
-    const long total = (long)B * ((H / 2 + DT_OH - 1) / DT_OH) * ((W / 2 + DT_OW - 1) / DT_OW);
     const long cap = (long)ctx->num_cus;
-    hipLaunchKernelGGL(k_mst_down4x4_32, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (__half*)out, B, H, W);
+    if (C == 32) {
+        using G = DownGeo<32>;
+        const long total = (long)B * ((H / 2 + G::OH - 1) / G::OH) * ((W / 2 + G::OW - 1) / G::OW);
+        hipLaunchKernelGGL(k_mst_down4x4_dma<32>, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (__half*)out, (const void*)ctx->d_zero, B, H, W);
+    } else {
+        using G = DownGeo<64>;
+        const long total = (long)B * ((H / 2 + G::OH - 1) / G::OH) * ((W / 2 + G::OW - 1) / G::OW);
+        hipLaunchKernelGGL(k_mst_down4x4_dma<64>, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (__half*)out, (const void*)ctx->d_zero, B, H, W);
+    }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

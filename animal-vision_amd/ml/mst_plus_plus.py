@@ -109,7 +109,7 @@ def pack_fragments16(w_kn: torch.Tensor) -> torch.Tensor:
 
 def pack_down4x4(w: torch.Tensor) -> torch.Tensor:
     """(Cout, Cin, 4, 4) float16 stride-2 conv weight -> [16 taps][Cout/32][Cin/16][64][8] fragments (tap = 4 ky + kx), the A operands
-    of csrc/mst_fused.hip::k_mst_down4x4_32."""
+    of csrc/mst_fused.hip::k_mst_down4x4_dma."""
     return torch.stack([pack_fragments16(w[:, :, t // 4, t % 4].t().contiguous()) for t in range(16)]).contiguous()
 
 
@@ -260,12 +260,12 @@ class _AvxOps:
         return out
 
     def down4x4(self, x: torch.Tensor, wpack16: torch.Tensor) -> torch.Tensor:
-        """Conv2d(32 -> 64, 4, stride 2, padding 1) on (b, h, w, 32) float16 through an LDS halo tile with the wave's weights
-        held in registers (csrc/mst_fused.hip::k_mst_down4x4_32)."""
+        """Conv2d(c -> 2c, 4, stride 2, padding 1), c = 32 or 64, on (b, h, w, c) float16: halo tiles brought in by LDS-direct loads,
+        the wave's weights held in registers (csrc/mst_fused.hip::k_mst_down4x4_dma)."""
         from .._lib import lib
 
         b, h, w, c = x.shape
-        assert x.is_contiguous() and c == 32 and h % 2 == 0 and w % 2 == 0
+        assert x.is_contiguous() and c in (32, 64) and h % 2 == 0 and w % 2 == 0
         out = torch.empty((b, h // 2, w // 2, 2 * c), dtype=torch.float16, device=x.device)
         ctx = self.ctx(x.device)
         ctx._check(lib.avx_mst_down4x4(ctx._h, x.data_ptr(), wpack16.data_ptr(), out.data_ptr(), b, h, w, c, torch.cuda.current_stream(x.device).cuda_stream))
@@ -666,7 +666,7 @@ class MSTPlusPlus(torch.nn.Module):
             fea = self._msab(fea, f"{p}.encoder_layers.{i}.0", heads)
             skips.append(fea)
             dkey = f"{p}.encoder_layers.{i}.1.weight"
-            if _AVX.fused_ok(fea) and _AVX._down and fea.shape[-1] == 32 and fea.is_contiguous():  # full resolution: the hand-written implicit GEMM
+            if _AVX.fused_ok(fea) and _AVX._down and fea.shape[-1] in (32, 64) and fea.is_contiguous():  # both encoder steps: the hand-written implicit GEMM
                 fea = _AVX.down4x4(fea, self._prep(dkey + ".frag16", lambda: pack_down4x4(self._w(dkey, (0, 1)))))
             else:
                 fea = self._conv_nhwc(fea, self._w(dkey, (0, 1)), stride=2, padding=1)

@@ -5,9 +5,9 @@ import torch.nn.functional as F
 from animal_vision_amd.ml.mst_plus_plus import _AVX, pack_down4x4
 
 dev = torch.device("cuda")
-for (h, w) in [(2160, 3840), (1080, 1920)]:
-    x = torch.randn(1, h, w, 32, device=dev).half()
-    wt = (torch.randn(64, 32, 4, 4, device=dev) * 0.08).half()
+for (h, w, c) in [(2160, 3840, 32), (1080, 1920, 32), (1080, 1920, 64), (540, 960, 64)]:
+    x = torch.randn(1, h, w, c, device=dev).half()
+    wt = (torch.randn(2 * c, c, 4, 4, device=dev) * 0.08).half()
     wq = pack_down4x4(wt)
     xn = x.permute(0, 3, 1, 2)
     wn = wt.contiguous(memory_format=torch.channels_last)
@@ -22,5 +22,5 @@ for (h, w) in [(2160, 3840), (1080, 1920)]:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
-        gb = (h * w * 64 + h * w // 4 * 128) / 1e9
-        print(f"{h}x{w} {name}: {ms*1e3:.1f} us  {gb/ms*1e3:.0f} GB/s  {os.environ.get('AVX_DOWN_ABLATE','')}")
+        gb = (h * w * 2 * c + h * w // 4 * 4 * c) / 1e9
+        print(f"{h}x{w}x{c} {name}: {ms*1e3:.1f} us  {gb/ms*1e3:.0f} GB/s  {os.environ.get('AVX_DOWN_ABLATE','')}")
