@@ -73,6 +73,13 @@ __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
 #endif
 }
 
+// two float32 -> packed float16 pair, round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    const half2_t v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 // acc += a.f16[half] * b.f16[half] in float32 (v_fma_mix_f32: both float16 operands are converted inside the FMA; the
 // compiler only folds the conversions when float32 denormals are flushed, which these translation units do not ask for)
 __device__ __forceinline__ void fma_mix_lo(float& acc, unsigned a, unsigned b) {

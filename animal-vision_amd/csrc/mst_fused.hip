@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
                                                              const __half* __restrict__ taps2 /*[9][C]*/, const float* __restrict__ bias /*[C]*/,
                                                              __half* __restrict__ out, int B, int H, int W, const uint4* __restrict__ wvpack /*[C/32][C/16][64] or NULL*/) {
     constexpr int NO = C / 8, NS = C / 16, NT = C / 32, PP = C * 2 + 16;
-    constexpr int VRP = (VS * PP + 255) / 256 * 256, MRP = (MS * PP + 255) / 256 * 256;
+    constexpr int VRP = (VS * PP + 255) / 256 * 256, MRP = VRP;  // one row pitch for both maps (the second region is sized for the x tile anyway): a phase B item's source and destination offsets coincide
     constexpr int NFILL = (VS * VS * NO + kFT - 1) / kFT;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* vt = smem;                                  // [VS][VRP]: [VS px][PP]  v on the halo region
@@ -292,20 +292,33 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
 
     // which halo pixel / 16-byte part a thread stages, and where it lands in LDS, does not depend on the tile: computed once
     uint4 pre[NFILL];
-    int f_dy[NFILL], f_dx[NFILL], f_off[NFILL], f_lds[NFILL];
+    int f_lds[NFILL];       // LDS byte offset (-1: none)
+    unsigned f_rel[NFILL];  // global BYTE offset relative to the halo origin (y0 - 2, x0 - 2): unsigned 32-bit, so the load is scalar base + lane offset
 #pragma unroll
     for (int k = 0; k < NFILL; ++k) {
         const int it = tid + k * kFT, itc = it < VS * VS * NO ? it : 0, q = itc / NO, part16 = itc % NO;
-        f_dy[k] = q / VS - 2; f_dx[k] = q % VS - 2; f_off[k] = 8 * part16;
         f_lds[k] = it < VS * VS * NO ? (q / VS) * VRP + (q % VS) * PP + 16 * part16 : -1;
+        f_rel[k] = (unsigned)(((q / VS) * W + q % VS) * C + 8 * part16) * 2u;
     }
     auto fetch = [&](const Tile& t) {
+        const __half* src = fromx ? x : v;
+        if (t.y0 >= 2 && t.y0 + VS - 2 <= H && t.x0 >= 2 && t.x0 + VS - 2 <= W) {  // halo inside the frame (all but the border tiles): scalar origin + fixed lane offsets
+            const char* origin = reinterpret_cast<const char*>(src + ((t.b * H + t.y0 - 2) * (size_t)W + t.x0 - 2) * C);
 #pragma unroll
-        for (int k = 0; k < NFILL; ++k) {
-            const int yy = t.y0 + f_dy[k], xx = t.x0 + f_dx[k];
+            for (int k = 0; k < NFILL; ++k) {
+                unsigned o = f_rel[k];
+                asm volatile("" : "+v"(o));  // keeps the zero-extension here: hoisted out of the tile loop it becomes a 64-bit lane address (two VGPRs per load, spilled)
+                pre[k] = *reinterpret_cast<const uint4*>(origin + o);
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {  // border tiles: where the element sits is read back from its LDS offset (registers are what this kernel is short of)
+            const int fl = f_lds[k] < 0 ? 0 : f_lds[k], row = fl / VRP, col = (fl - row * VRP) / PP, f_off = (fl - row * VRP - col * PP) / 2;
+            const int yy = t.y0 + row - 2, xx = t.x0 + col - 2;
             const bool ok = f_lds[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
             const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            uint4 r = *reinterpret_cast<const uint4*>((fromx ? x : v) + ((t.b * H + yc) * (size_t)W + xc) * C + f_off[k]);
+            uint4 r = *reinterpret_cast<const uint4*>(src + ((t.b * H + yc) * (size_t)W + xc) * C + f_off);
             r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
             pre[k] = r;
         }
@@ -318,15 +331,13 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
     };
     // phase B items of this lane (pixels of the 18 x 18 map: part * per + lane + 64 i): LDS offsets and image offsets, once
     constexpr int NB = (((MS * MS + (8 / NO) - 1) / (8 / NO)) + 63) / 64;
-    int b_src[NB], b_dst[NB], b_dy[NB], b_dx[NB];
+    int b_src[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int q = part * per + lane + 64 * i;
         const bool ok = q < (part + 1) * per && q < MS * MS;
         const int qc = ok ? q : 0, my = qc / MS, mx = qc % MS;
-        b_src[i] = ok ? my * VRP + mx * PP + 16 * oct : -1;
-        b_dst[i] = my * MRP + mx * PP + 16 * oct;
-        b_dy[i] = my - 1; b_dx[i] = mx - 1;
+        b_src[i] = ok ? my * VRP + mx * PP + 16 * oct : -1;  // in vt: the window's first tap; in mt: the pixel itself
     }
     long tile = blockIdx.x;
     if (tile >= total) return;
@@ -360,6 +371,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
             __syncthreads();  // vt complete; the x tile is dead: its region becomes mt
         }
         // ---- phase B: mid = gelu(dw1(v)) on the 18 x 18 region, zero outside the image ----
+        const bool mid_inside = t.y0 >= 1 && t.y0 + MS - 1 <= H && t.x0 >= 1 && t.x0 + MS - 1 <= W;  // scalar: no per-pixel test, no masking below
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (b_src[i] < 0) continue;
@@ -376,8 +388,11 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
                 fma_mix_lo(acc[4], hv.z, wv.z); fma_mix_hi(acc[5], hv.z, wv.z);
                 fma_mix_lo(acc[6], hv.w, wv.w); fma_mix_hi(acc[7], hv.w, wv.w);
             }
-            const int yy = t.y0 + b_dy[i], xx = t.x0 + b_dx[i];
-            const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            bool inside = true;
+            if (!mid_inside) {  // border tiles only
+                const int my = b_src[i] / MRP, mx = (b_src[i] - my * MRP) / PP, yy = t.y0 + my - 1, xx = t.x0 + mx - 1;
+                inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            }
             half8_t o;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
@@ -386,9 +401,11 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
                 o[j + 1] = (_Float16)gv.y;
             }
             uint4 ov = __builtin_bit_cast(uint4, o);
-            const uint32_t keep = inside ? 0xffffffffu : 0u;  // the second conv's zero padding applies to THIS map
-            ov.x &= keep; ov.y &= keep; ov.z &= keep; ov.w &= keep;
-            *reinterpret_cast<uint4*>(mt + b_dst[i]) = ov;
+            if (!mid_inside) {
+                const uint32_t keep = inside ? 0xffffffffu : 0u;  // the second conv's zero padding applies to THIS map
+                ov.x &= keep; ov.y &= keep; ov.z &= keep; ov.w &= keep;
+            }
+            *reinterpret_cast<uint4*>(mt + b_src[i]) = ov;
         }
         __syncthreads();  // mt complete
         const long next = tile + gridDim.x;
@@ -433,14 +450,24 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
                 for (int n = 0; n < NT; ++n) {
                     const half8_t r0 = __builtin_bit_cast(half8_t, xr[2 * n]), r1 = __builtin_bit_cast(half8_t, xr[2 * n + 1]);
                     const float* bb = bl + h * (C / 2) + 16 * n;
-                    half8_t o0, o1;
+                    // ((D + float16(pe)) + bias) + x, the float16 operands taken as they are by v_fma_mix_f32 (a * 1.0 + c: the same sum, no conversion instructions)
+                    constexpr unsigned kOnes = 0x3c003c00u;
+                    const uint4 xa = xr[2 * n], xb = xr[2 * n + 1];
+                    const unsigned xw[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    (void)r0; (void)r1;
+                    unsigned ow[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        o0[j] = (_Float16)(D[n][j] + (float)(_Float16)pe[2 * n][j] + bb[j] + (float)r0[j]);
-                        o1[j] = (_Float16)(D[n][8 + j] + (float)(_Float16)pe[2 * n + 1][j] + bb[8 + j] + (float)r1[j]);
+                    for (int j = 0; j < 8; ++j) {  // output channels 2 j, 2 j + 1 of this lane's 16
+                        const float* pj = j < 4 ? &pe[2 * n][2 * j] : &pe[2 * n + 1][2 * j - 8];
+                        const unsigned pk = pack_f16(pj[0], pj[1]);  // pos_emb's own float16 rounding
+                        float s0 = D[n][2 * j], s1 = D[n][2 * j + 1];
+                        fma_mix_lo(s0, pk, kOnes); fma_mix_hi(s1, pk, kOnes);
+                        s0 += bb[2 * j]; s1 += bb[2 * j + 1];
+                        fma_mix_lo(s0, xw[j], kOnes); fma_mix_hi(s1, xw[j], kOnes);
+                        ow[j] = pack_f16(s0, s1);
                     }
-                    reinterpret_cast<uint4*>(out + off)[2 * n] = __builtin_bit_cast(uint4, o0);
-                    reinterpret_cast<uint4*>(out + off)[2 * n + 1] = __builtin_bit_cast(uint4, o1);
+                    reinterpret_cast<uint4*>(out + off)[2 * n] = uint4{ow[0], ow[1], ow[2], ow[3]};
+                    reinterpret_cast<uint4*>(out + off)[2 * n + 1] = uint4{ow[4], ow[5], ow[6], ow[7]};
                 }
             }
         }
@@ -454,7 +481,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
 template <int C, int MINW>
 int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpack, const void* taps1, const void* taps2, const float* bias, void* out, int B,
                      int H, int W, hipStream_t s, const void* wvpack) {
-    constexpr int PP = C * 2 + 16, VRP = (VS * PP + 255) / 256 * 256, MRP = (MS * PP + 255) / 256 * 256;
+    constexpr int PP = C * 2 + 16, VRP = (VS * PP + 255) / 256 * 256, MRP = VRP;
     const size_t lds = (size_t)2 * VS * VRP + (size_t)2 * 9 * C * 2 + sizeof(float) * C;  // second region sized for the x tile (>= mt)
     (void)MRP;
     const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
