@@ -73,6 +73,18 @@ __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
 #endif
 }
 
+// a.f16[half] * b.f16[half] + c in float32, c a separate operand
+__device__ __forceinline__ float fma_mix_lo_c(unsigned a, unsigned b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi_c(unsigned a, unsigned b, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // two float32 -> packed float16 pair, round to nearest even (v_cvt_pk_f16_f32)
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));

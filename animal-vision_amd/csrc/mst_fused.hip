@@ -71,7 +71,26 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
 
     // ---- phase 0, split: fetch the raw rows of this wave's halo pixel groups (wave w: groups w and w + 8) ----
     uint4 raw[2][LNV];
+    unsigned f_rel[2];  // this lane's halo pixel (group wave + 8 gi), as a byte offset from the halo origin (y0 - 1, x0 - 1): scalar base + lane offset when the halo lies inside the frame
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int q = 32 * (wave + 8 * gi) + p, qq = q < NHALO ? q : NHALO - 1;
+        f_rel[gi] = (unsigned)(((qq / HS) * W + qq % HS) * C + h * (C / 2)) * 2u;
+    }
     auto fetch = [&](const Tile& t) {
+        if (t.y0 >= 1 && t.y0 + HS - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W) {  // all but the frame's border tiles: no clamping, no 64-bit lane arithmetic
+            const char* origin = reinterpret_cast<const char*>(x + ((t.b * H + t.y0 - 1) * (size_t)W + t.x0 - 1) * C);
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                if (wave + 8 * gi >= NGRP) break;
+                unsigned o = f_rel[gi];
+                asm volatile("" : "+v"(o));  // keeps the zero-extension here (hoisted out of the tile loop it becomes a 64-bit lane address)
+                const uint4* src = reinterpret_cast<const uint4*>(origin + o);
+#pragma unroll
+                for (int v = 0; v < LNV; ++v) raw[gi][v] = src[v];
+            }
+            return;
+        }
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             const int g = wave + 8 * gi;
@@ -90,35 +109,37 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
         for (int gi = 0; gi < 2; ++gi) {
             const int g = wave + 8 * gi;
             if (g >= NGRP) break;
-            float f[8 * LNV];
-#pragma unroll
-            for (int v = 0; v < LNV; ++v) {
-                const half8_t h8 = __builtin_bit_cast(half8_t, raw[gi][v]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[8 * v + j] = (float)h8[j];
-            }
+            // float16 values enter through v_fma_mix_f32 (x * 1.0 + c): the sum and the centring cost one instruction per element, no conversions
+            constexpr unsigned kOnes = 0x3c003c00u;
             auto is_pad = [&](int i) { return ((h * (C / 2) + i) & 31) == 31; };
+            auto word = [&](int i) { const uint4 u = raw[gi][i / 8]; const int k = (i / 2) & 3; return k == 0 ? u.x : k == 1 ? u.y : k == 2 ? u.z : u.w; };
             float s1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8 * LNV; ++i) s1 += is_pad(i) ? 0.f : f[i];
-            const float mean = (s1 + __shfl_xor(s1, 32)) / cnt;
-            float s2 = 0.f;
+            for (int i = 0; i < 8 * LNV; ++i) {
+                const float t = (i & 1) ? fma_mix_hi_c(word(i), kOnes, s1) : fma_mix_lo_c(word(i), kOnes, s1);
+                s1 = is_pad(i) ? s1 : t;
+            }
+            const float mean = (s1 + __shfl_xor(s1, 32)) / cnt, nmean = -mean;
+            float d[8 * LNV], s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8 * LNV; ++i) {
-                const float d = is_pad(i) ? 0.f : f[i] - mean;
-                s2 = __builtin_fmaf(d, d, s2);
+                const float t = (i & 1) ? fma_mix_hi_c(word(i), kOnes, nmean) : fma_mix_lo_c(word(i), kOnes, nmean);
+                d[i] = is_pad(i) ? 0.f : t;
+                s2 = __builtin_fmaf(d[i], d[i], s2);
             }
             const float rstd = rsqrtf((s2 + __shfl_xor(s2, 32)) / cnt + eps);
             unsigned char* dst = yt + (size_t)(32 * g + p) * YPITCH + h * C;  // h * (C/2) channels * 2 bytes
 #pragma unroll
             for (int v = 0; v < LNV; ++v) {
-                half8_t o;
+                unsigned o[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 8; j += 2) {
                     const int i = 8 * v + j, c = h * (C / 2) + i;
-                    o[j] = is_pad(i) ? (_Float16)0.f : (_Float16)((f[i] - mean) * rstd * gl[c] + gl[C + c]);
+                    const float a = is_pad(i) ? 0.f : __builtin_fmaf(d[i] * rstd, gl[c], gl[C + c]);
+                    const float bq = is_pad(i + 1) ? 0.f : __builtin_fmaf(d[i + 1] * rstd, gl[c + 1], gl[C + c + 1]);
+                    o[j / 2] = pack_f16(a, bq);
                 }
-                *reinterpret_cast<uint4*>(dst + 16 * v) = __builtin_bit_cast(uint4, o);
+                *reinterpret_cast<uint4*>(dst + 16 * v) = uint4{o[0], o[1], o[2], o[3]};
             }
         }
     };
@@ -149,6 +170,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     layernorm();
     for (;;) {
         const long next = tile + gridDim.x;
+        const bool halo_inside = t.y0 >= 1 && t.y0 + HS - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W;  // scalar
         float16_t D[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -173,8 +195,11 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
 #pragma unroll
                     for (int s = 0; s < KS1; ++s) d = mfma16(w1f[s], __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(ysrc + 32 * s)), d);
                     if (p1_dst[j] >= 0) {
-                        const int yy = t.y0 + p1_dy[j], xx = t.x0 + p1_dx[j];
-                        const uint32_t keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;  // zeros outside the image
+                        uint32_t keep = 0xffffffffu;
+                        if (!halo_inside) {  // border tiles: zeros outside the image
+                            const int yy = t.y0 + p1_dy[j], xx = t.x0 + p1_dx[j];
+                            keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
+                        }
                         half8_t o0, o1;
 #pragma unroll
                         for (int v = 0; v < 16; v += 2) {
@@ -182,7 +207,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                             if (v < 8) { o0[v] = (_Float16)gv.x; o0[v + 1] = (_Float16)gv.y; } else { o1[v - 8] = (_Float16)gv.x; o1[v - 7] = (_Float16)gv.y; }
                         }
                         uint4 u0 = __builtin_bit_cast(uint4, o0), u1 = __builtin_bit_cast(uint4, o1);
-                        u0.x &= keep; u0.y &= keep; u0.z &= keep; u0.w &= keep; u1.x &= keep; u1.y &= keep; u1.z &= keep; u1.w &= keep;
+                        if (!halo_inside) { u0.x &= keep; u0.y &= keep; u0.z &= keep; u0.w &= keep; u1.x &= keep; u1.y &= keep; u1.z &= keep; u1.w &= keep; }
                         unsigned char* dst = ht + p1_dst[j] + 64 * ct;
                         reinterpret_cast<uint4*>(dst)[0] = u0;
                         reinterpret_cast<uint4*>(dst)[1] = u1;
@@ -231,13 +256,17 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 const size_t off = ((t.b * H + yo) * (size_t)W + xo) * C + 16 * h;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const half8_t r0 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(x + off + 32 * n)[0]);
-                    const half8_t r1 = __builtin_bit_cast(half8_t, reinterpret_cast<const uint4*>(x + off + 32 * n)[1]);
-                    half8_t o0, o1;
+                    const uint4 xa = reinterpret_cast<const uint4*>(x + off + 32 * n)[0], xb = reinterpret_cast<const uint4*>(x + off + 32 * n)[1];
+                    const unsigned xw[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    unsigned ow[8];
 #pragma unroll
-                    for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)(D[n][v] + (float)r0[v]); o1[v] = (_Float16)(D[n][8 + v] + (float)r1[v]); }
-                    reinterpret_cast<uint4*>(out + off + 32 * n)[0] = __builtin_bit_cast(uint4, o0);
-                    reinterpret_cast<uint4*>(out + off + 32 * n)[1] = __builtin_bit_cast(uint4, o1);
+                    for (int j = 0; j < 8; ++j) {  // D + x with the float16 residual taken as it is (v_fma_mix_f32, x * 1.0 + D: the same sum, no conversion instruction)
+                        float s0 = D[n][2 * j], s1 = D[n][2 * j + 1];
+                        fma_mix_lo(s0, xw[j], 0x3c003c00u); fma_mix_hi(s1, xw[j], 0x3c003c00u);
+                        ow[j] = pack_f16(s0, s1);
+                    }
+                    reinterpret_cast<uint4*>(out + off + 32 * n)[0] = uint4{ow[0], ow[1], ow[2], ow[3]};
+                    reinterpret_cast<uint4*>(out + off + 32 * n)[1] = uint4{ow[4], ow[5], ow[6], ow[7]};
                 }
             }
         }

@@ -1,16 +1,13 @@
 #!/bin/bash
-# same-box A/B of two builds: animal-vision_amd/libavx_head.so (the previous build, copied there by hand) vs libavx.so
-set -o pipefail
+# Same-box A/B of builds of the library: animal-vision_amd/libavx_<tag>.so (built from other trees) against the current libavx.so (tag "cur"),
+# alternating, on one bench workload.  usage: bash tools/gpu_ab_lib.sh <workload> <rounds> <steps> <tag> [<tag> ...]
+WL=${1:-honeybee_mst_4k}; R=${2:-3}; S=${3:-12}; shift 3
 L=animal-vision_amd
-cp $L/libavx.so $L/libavx_new.so
-for round in 1 2; do
-  for which in head new; do
-    cp $L/libavx_$which.so $L/libavx.so
-    for wl in ${WLS:-cat_1080p dog_1080p wolf_1080p lion_1080p squirrel_1080p}; do
-      ${ENVV:-env} timeout -k 10 200 python bench.py --workload $wl --no-cpu-baseline --no-e2e > gpurun_out/ab.json 2> gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; cp $L/libavx_new.so $L/libavx.so; exit 1; }
-      python -c "
-import json; r=json.load(open('gpurun_out/ab.json')); print('$which', '$wl', r['value'], 'MP/s', r['roofline']['us_per_launch'], 'us')"
-    done
+cp $L/libavx.so /tmp/libavx_cur.so
+for r in $(seq $R); do
+  for v in "$@" cur; do
+    if [ $v = cur ]; then cp /tmp/libavx_cur.so $L/libavx.so; else cp $L/libavx_$v.so $L/libavx.so; fi
+    timeout -k 10 200 python bench.py --workload $WL --no-cpu-baseline --no-e2e --no-legs --steps $S 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$v', d['ms_per_step'], d['parity_checked'])"
   done
 done
-cp $L/libavx_new.so $L/libavx.so
+cp /tmp/libavx_cur.so $L/libavx.so
