@@ -820,54 +820,62 @@ __global__ __launch_bounds__(256) void k_mst_conv_in_u8(const uint8_t* __restric
 
 // The same on the matrix cores: K = 27 (+ 5 zero slots) x N = 32 is two v_mfma_f32_32x32x16_f16 per 32 pixels.  The inputs are float16
 // already (autocast's conv input) and the weights are the model's float16 values, so the products are exact and only the float32 summation
-// order differs from the scalar form above.  A lane (pixel p, half h) gathers the 16 k-slots its B fragments carry (k = 16 s + 8 h + j ->
-// tap k / 3, channel k % 3), the A fragments are built once per thread from the 27 x 32 table (output-channel rows permuted so that the
-// lane ends up with 16 contiguous channels: pack_fragments16's order).  The kernel is then bound by its 64 B/px of output.
+// order differs from the scalar form above.  The K order of a product is free: lane half h = 0 carries taps 0-4 (15 slots + a zero), h = 1
+// taps 5-8 (12 slots + four zeros), so a lane reads FIVE (four) source pixels, three bytes each, whose offsets from the output pixel are
+// fixed per lane -- not 16 separately addressed bytes.  float16(u8 / 255) == float16(u8 * (1 / 255)) for all 256 values (checked
+// exhaustively): a multiplication, not 27 IEEE divisions per pixel.  The A fragments are built once per thread from the 27 x 32 table in the
+// same slot order (output-channel rows permuted so that the lane ends up with 16 contiguous channels: pack_fragments16's order).  1,130
+// vector instructions per pixel before, bound by them; now by its 64 B/px of output.
 __global__ __launch_bounds__(256) void k_mst_conv_in_u8_mfma(const uint8_t* __restrict__ frame /*[H][W][3]*/, const float* __restrict__ w /*[27][32]*/,
                                                              __half* __restrict__ out /*[Hp][Wp][32]*/, int H, int W, int pt, int pl, int Hp, int Wp) {
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
     const int col = 16 * ((p % 8) / 4) + 4 * (p / 8) + p % 4;  // output channel of this lane's A row
+    const int tap0 = 5 * h, ntap = 5 - h;                      // this lane half's taps: [tap0, tap0 + ntap)
     half8_t af[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = 16 * s + 8 * h + j;
-            af[s][j] = k < 27 ? (_Float16)w[k * 32 + col] : (_Float16)0.f;
+            const int q = 8 * s + j, k = 3 * tap0 + q;  // slot q of this half = (tap tap0 + q / 3, channel q % 3)
+            af[s][j] = q < 3 * ntap ? (_Float16)w[k * 32 + col] : (_Float16)0.f;
         }
+    int dy[5], dx[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int tap = tap0 + (t < ntap ? t : 0);
+        dy[t] = tap / 3 - 1; dx[t] = tap % 3 - 1;
+    }
     const size_t total = (size_t)Hp * Wp, ngroups = (total + 31) / 32;
+    const float inv255 = 1.0f / 255.0f;
     for (size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += (size_t)gridDim.x * 4) {
         const size_t i = g * 32 + p, ic = i < total ? i : total - 1;
         const int y = (int)(ic / Wp), x = (int)(ic - (size_t)y * Wp);
-        half8_t bf[2];
+        float v[16];
+        v[15] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int t = 0; t < 5; ++t) {
+            const int yy = y + dy[t], xx = x + dx[t];
+            const bool ok = t < ntap && yy >= 0 && yy < Hp && xx >= 0 && xx < Wp;  // the conv's zero padding applies to the PADDED frame
+            int sy = (ok ? yy : 0) - pt, sx = (ok ? xx : 0) - pl;                  // reflect (no edge repeat) back into the frame
+            sy = sy < 0 ? -sy : (sy >= H ? 2 * (H - 1) - sy : sy);
+            sx = sx < 0 ? -sx : (sx >= W ? 2 * (W - 1) - sx : sx);
+            const uint8_t* q = frame + ((size_t)sy * W + sx) * 3;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * h + j, t = k / 3, c = k - 3 * t;
-                float v = 0.f;
-                if (k < 27) {
-                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    const bool ok = yy >= 0 && yy < Hp && xx >= 0 && xx < Wp;  // the conv's zero padding applies to the PADDED frame
-                    int sy = (ok ? yy : 0) - pt, sx = (ok ? xx : 0) - pl;       // reflect (no edge repeat) back into the frame
-                    sy = sy < 0 ? -sy : (sy >= H ? 2 * (H - 1) - sy : sy);
-                    sx = sx < 0 ? -sx : (sx >= W ? 2 * (W - 1) - sx : sx);
-                    const float q = (float)frame[((size_t)sy * W + sx) * 3 + c] / 255.0f;
-                    v = ok ? q : 0.f;
-                }
-                bf[s][j] = (_Float16)v;
-            }
+            for (int c = 0; c < 3; ++c) v[3 * t + c] = ok ? (float)q[c] * inv255 : 0.f;
+        }
+        const half8_t b0 = __builtin_bit_cast(half8_t, uint4{pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7])});
+        const half8_t b1 = __builtin_bit_cast(half8_t, uint4{pack_f16(v[8], v[9]), pack_f16(v[10], v[11]), pack_f16(v[12], v[13]), pack_f16(v[14], v[15])});
         float16_t d;
 #pragma unroll
         for (int vv = 0; vv < 16; ++vv) d[vv] = 0.f;
-        d = mfma16(af[0], bf[0], d);
-        d = mfma16(af[1], bf[1], d);
+        d = mfma16(af[0], b0, d);
+        d = mfma16(af[1], b1, d);
         if (i < total) {
-            half8_t o0, o1;
+            unsigned o[8];
 #pragma unroll
-            for (int vv = 0; vv < 8; ++vv) { o0[vv] = (_Float16)d[vv]; o1[vv] = (_Float16)d[8 + vv]; }
-            reinterpret_cast<uint4*>(out + i * 32 + 16 * h)[0] = __builtin_bit_cast(uint4, o0);
-            reinterpret_cast<uint4*>(out + i * 32 + 16 * h)[1] = __builtin_bit_cast(uint4, o1);
+            for (int vv = 0; vv < 8; ++vv) o[vv] = pack_f16(d[2 * vv], d[2 * vv + 1]);
+            reinterpret_cast<uint4*>(out + i * 32 + 16 * h)[0] = uint4{o[0], o[1], o[2], o[3]};
+            reinterpret_cast<uint4*>(out + i * 32 + 16 * h)[1] = uint4{o[4], o[5], o[6], o[7]};
         }
     }
 }
