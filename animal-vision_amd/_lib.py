@@ -249,6 +249,7 @@ _SIGS = {
     "avx_sobel3_plane": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "avx_mst_gram": (_i, [_vp, _vp, _i, _sz, _i, _i, _vp, _vp, _vp, _vp]),
     "avx_mst_qkv_gram": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "avx_mst_qkv_gram16": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "avx_mst_ln_gemm_gelu": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _sz, _i, _vp, _vp]),
     "avx_mst_convt2x2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_convt2x2_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

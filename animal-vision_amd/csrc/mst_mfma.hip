@@ -758,6 +758,140 @@ __global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ 
     }
 }
 
+// ---- the same pass on v_mfma_f32_32x32x16_f16 (gfx950's double-rate form) ------------------------------------------------------------------
+// k_mst_qkv above is BOUND by its K = 8 MFMAs (64 cycles each: 144 per 32 pixels at C = 128 is 70 us of matrix-core time per 4K launch at a
+// sixteenth of the pixels, 77 us at C = 64, 93 at C = 32); the K = 16 form does the same products in a quarter of the cycles and leaves
+// the pass to its one read of x.  Fragment order (ml/mst_plus_plus.py::pack_qkv16): step q, lane half h, element j <-> input channel
+// h C/2 + 8 q + j -- again the order in which a lane holds its contiguous half row, one 16-byte load per step.  A "pixels x channels"
+// accumulator (lane = channel, registers v <-> pixels 8 (v / 4) + 4 h + v % 4) packs into TWO K = 16 operands of the Gram MFMA (registers
+// 0-7 and 8-15: the K order is free and k and q use the same one).  Norms: sum of squares of the float16-rounded values, taken from the
+// packed pair by v_fma_mix_f32 (no conversion back).  NW waves per workgroup: 8 at C = 128, where the 98 KB of weights in LDS allow one
+// workgroup per CU and four waves left every SIMD alone with its latencies.
+__device__ __forceinline__ float16_t mfma16(half8_t a, half8_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) void k_mst_qkv16(const __half* __restrict__ x, const uint4* __restrict__ wpack /*[3*HD][C/16][64]*/, size_t n,
+                                                      __half* __restrict__ v_out /*[n][C] or NULL*/, float* __restrict__ partial /*[blocks][HD][34][32]*/) {
+    constexpr int KS = C / 16, HD = C / 32, NT = 3 * HD;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* wl = reinterpret_cast<uint4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < NT * KS * 64; i += 64 * NW) wl[i] = wpack[i];
+    __syncthreads();
+    auto W = [&](int t, int s) { return __builtin_bit_cast(half8_t, wl[(t * KS + s) * 64 + lane]); };
+    float16_t G[HD];
+    float nq[HD], nk[HD];
+#pragma unroll
+    for (int hd = 0; hd < HD; ++hd) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) G[hd][v] = 0.f;
+        nq[hd] = 0.f;
+        nk[hd] = 0.f;
+    }
+    const size_t ntiles = (n + 31) / 32;
+    const int p = lane & 31, h = lane >> 5;
+    auto load_row = [&](size_t tile, uint4 (&u)[KS]) {  // rows past the end: the last row's bytes, zeroed when they are used
+        const size_t row = tile * 32 + p;
+        const uint4* src = reinterpret_cast<const uint4*>(x + (row < n ? row : n - 1) * (size_t)C + h * (C / 2));
+#pragma unroll
+        for (int q = 0; q < KS; ++q) u[q] = src[q];
+    };
+    constexpr bool PF = C <= 64;  // next tile's row in flight under this tile's MFMAs (C = 128: the registers go to the four Gram accumulators)
+    uint4 xn[KS];
+    size_t tile = (size_t)blockIdx.x * NW + wave;
+    if (PF && tile < ntiles) load_row(tile, xn);
+    for (; tile < ntiles; tile += (size_t)gridDim.x * NW) {
+        const size_t row = tile * 32 + p;
+        half8_t xf[KS];
+        if (!PF) load_row(tile, xn);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) xf[q] = __builtin_bit_cast(half8_t, row < n ? xn[q] : uint4{0u, 0u, 0u, 0u});
+        if (PF && tile + (size_t)gridDim.x * NW < ntiles) load_row(tile + (size_t)gridDim.x * NW, xn);
+        if constexpr (C > 32) asm volatile("" ::: "memory");  // keep the weight fragments in LDS: hoisted out of this loop they cost 6 C VGPRs
+#pragma unroll
+        for (int hd = 0; hd < HD; ++hd) {
+            float16_t dq, dk;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { dq[v] = 0.f; dk[v] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dq = mfma16(xf[s], W(hd, s), dq);        // D[pixel][q channel]
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dk = mfma16(xf[s], W(HD + hd, s), dk);   // D[pixel][k channel]
+            unsigned aq[8], ak[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                aq[j] = pack_f16(dq[2 * j], dq[2 * j + 1]);
+                ak[j] = pack_f16(dk[2 * j], dk[2 * j + 1]);
+                fma_mix_lo(nq[hd], aq[j], aq[j]); fma_mix_hi(nq[hd], aq[j], aq[j]);
+                fma_mix_lo(nk[hd], ak[j], ak[j]); fma_mix_hi(nk[hd], ak[j], ak[j]);
+            }
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)  // G[i][j] += sum_px k[px][i] q[px][j], 16 pixels per instruction
+                G[hd] = mfma16(__builtin_bit_cast(half8_t, uint4{ak[4 * b2], ak[4 * b2 + 1], ak[4 * b2 + 2], ak[4 * b2 + 3]}),
+                               __builtin_bit_cast(half8_t, uint4{aq[4 * b2], aq[4 * b2 + 1], aq[4 * b2 + 2], aq[4 * b2 + 3]}), G[hd]);
+        }
+        if (v_out)  // NULL: the attention tail forms v from x itself (avx_mst_attn_tail_x): this pass only reads
+#pragma unroll
+        for (int hd = 0; hd < HD; ++hd) {
+            float16_t dv;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dv[v] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dv = mfma16(W(2 * HD + hd, s), xf[s], dv);  // D[v channel (permuted)][pixel]
+            if (row < n) {
+                unsigned o[8];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) o[v] = pack_f16(dv[2 * v], dv[2 * v + 1]);
+                uint4* dst = reinterpret_cast<uint4*>(v_out + row * (size_t)C + 32 * hd + 16 * h);
+                dst[0] = uint4{o[0], o[1], o[2], o[3]};
+                dst[1] = uint4{o[4], o[5], o[6], o[7]};
+            }
+        }
+    }
+    // block partial: [hd][34][32] = 32 Gram rows (i = k channel, j = q channel), then sum q^2, then sum k^2
+    __syncthreads();  // the weights in LDS are dead: the same bytes hold the per-wave results now
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int hd = 0; hd < HD; ++hd) {
+        float* mine = red + ((size_t)wave * HD + hd) * 34 * 32;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) mine[(8 * (v / 4) + 4 * h + (v % 4)) * 32 + p] = G[hd][v];
+        const float sq = nq[hd] + __shfl_xor(nq[hd], 32), sk = nk[hd] + __shfl_xor(nk[hd], 32);
+        if (h == 0) { mine[32 * 32 + p] = sq; mine[33 * 32 + p] = sk; }
+    }
+    __syncthreads();
+    for (int i = tid; i < HD * 34 * 32; i += 64 * NW) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[(size_t)w * HD * 34 * 32 + i];
+        partial[(size_t)blockIdx.x * HD * 34 * 32 + i] = s;
+    }
+}
+
+template <int C, int NW>
+int launch_qkv16(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
+    constexpr int KS = C / 16, HD = C / 32;
+    const size_t wbytes = (size_t)3 * HD * KS * 64 * sizeof(uint4), rbytes = sizeof(float) * NW * HD * 34 * 32;
+    const size_t lds = wbytes > rbytes ? wbytes : rbytes;
+    const size_t ntiles = (n + 31) / 32;
+    long blocks = (long)((ntiles + NW - 1) / NW);
+    long per_cu = (long)(160 * 1024 / lds);
+    if (per_cu > 16 / NW * 2) per_cu = 16 / NW * 2;  // at most 8 waves per SIMD's worth of workgroups
+    if (per_cu < 1) per_cu = 1;
+    const long cap = (long)ctx->num_cus * per_cu;
+    if (blocks > cap) blocks = cap;
+    int rc = avx_ensure_scratch(ctx, ws, sizeof(float) * (size_t)blocks * HD * 34 * 32);
+    if (rc) return rc;
+    float* partial = (float*)ws->d_scratch;
+    auto k = k_mst_qkv16<C, NW>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * NW), lds, s, (const __half*)x, (const uint4*)wpack, n, (__half*)v_out, partial);
+    AVX_HIP(ctx, hipGetLastError());
+    const int tot = HD * 34 * 32;
+    hipLaunchKernelGGL(k_mst_qkv_final, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, partial, (int)blocks, HD, gram, nq, nk);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 template <int C>
 int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_t n, void* v_out, float* gram, float* nq, float* nk, hipStream_t s) {
     constexpr int KS = C / 8, HD = C / 32;
@@ -825,6 +959,20 @@ int avx_mst_qkv_gram(avx_ctx* ctx, const void* x, const void* wpack, size_t n_pi
     if (C == 32) return launch_qkv<32>(ctx, ws, x, wpack, n_pix, v_out, gram, nq, nk, s);
     if (C == 64) return launch_qkv<64>(ctx, ws, x, wpack, n_pix, v_out, gram, nq, nk, s);
     return launch_qkv<128>(ctx, ws, x, wpack, n_pix, v_out, gram, nq, nk, s);
+}
+
+int avx_mst_qkv_gram16(avx_ctx* ctx, const void* x, const void* wpack16, size_t n_pix, int C, void* v_out, float* gram, float* nq, float* nk, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack16 && gram && nq && nk && n_pix > 0, "avx_mst_qkv_gram16: NULL pointer or empty tensor");  // v_out may be NULL
+    AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_qkv_gram16: C=%d (32, 64 or 128: 31-channel groups stored 32 wide)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack16 | (uintptr_t)v_out)) & 15u) == 0, "avx_mst_qkv_gram16: pointers must be 16-byte aligned");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    if (C == 32) return launch_qkv16<32, 4>(ctx, ws, x, wpack16, n_pix, v_out, gram, nq, nk, s);
+    if (C == 64) return launch_qkv16<64, 4>(ctx, ws, x, wpack16, n_pix, v_out, gram, nq, nk, s);
+    return launch_qkv16<128, 8>(ctx, ws, x, wpack16, n_pix, v_out, gram, nq, nk, s);
 }
 
 int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* wpack, size_t rows, int C, void* out,

@@ -107,6 +107,31 @@ def pack_fragments16(w_kn: torch.Tensor) -> torch.Tensor:
     return torch.take(w_kn.contiguous(), idx)
 
 
+def pack_qkv16(wqkv: torch.Tensor) -> torch.Tensor:
+    """(c x 3c) float16 weight [W_q^T | W_k^T | W_v^T] of `qkv = x @ w` -> the v_mfma_f32_32x32x16_f16 fragments of
+    csrc/mst_mfma.hip::k_mst_qkv16: [3c/32 tiles][c/16 steps][64 lanes][8]; step q, lane half h, element j carries input channel
+    h c/2 + 8 q + j (the order in which a lane holds its contiguous half row of x); lane % 32 = m is output channel 32 t + m for the
+    q and k tiles ("pixels x channels" results) and 32 t + perm(m) for the v tiles (the weight is the A operand there and its rows are
+    permuted so a result lane ends up with 16 contiguous channels, perm as in pack_fragments16)."""
+    K, N = wqkv.shape
+    assert N == 3 * K and K % 32 == 0
+    dev = wqkv.device
+    key = (K, N, "qkv16", str(dev))
+    idx = _FRAG_INDEX.get(key)
+    if idx is None:
+        lane = torch.arange(64, device=dev)
+        m, h = lane % 32, lane // 32
+        perm = 16 * ((m % 8) // 4) + 4 * (m // 8) + m % 4
+        t = torch.arange(N // 32, device=dev)
+        col = 32 * t[:, None] + torch.where(t[:, None] >= 2 * (K // 32), perm[None, :], m[None, :])                       # (N/32, 64)
+        q = torch.arange(K // 16, device=dev)
+        j = torch.arange(8, device=dev)
+        k = h[None, :, None] * (K // 2) + 8 * q[:, None, None] + j[None, None, :]                                         # (K/16, 64, 8)
+        idx = (k[None] * N + col[:, None, :, None]).contiguous()                                                          # (N/32, K/16, 64, 8)
+        _FRAG_INDEX[key] = idx
+    return torch.take(wqkv.contiguous(), idx)
+
+
 def pack_down4x4(w: torch.Tensor) -> torch.Tensor:
     """(Cout, Cin, 4, 4) float16 stride-2 conv weight -> [16 taps][Cout/32][Cin/16][64][8] fragments (tap = 4 ky + kx), the A operands
     of csrc/mst_fused.hip::k_mst_down4x4_dma."""
@@ -130,6 +155,7 @@ class _AvxOps:
         self._tail = os.environ.get("AVX_MST_NO_TAIL", "") == ""  # A/B: the attention tail (pos_emb + v @ M + bias + x) in one pass
         self._tailx = os.environ.get("AVX_MST_NO_TAILX", "") == ""  # A/B: the tail forms v = x W_v^T itself, the Gram pass writes no v
         self._down = os.environ.get("AVX_MST_NO_DOWN4X4", "") == ""  # A/B: hand-written 32 -> 64 stride-2 conv instead of MIOpen's implicit GEMM
+        self._qkv16 = os.environ.get("AVX_MST_NO_QKV16", "") == ""  # A/B: the Gram pass on K = 16 MFMAs
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
         self._ctx = {}
@@ -172,9 +198,9 @@ class _AvxOps:
         """The matrix-core kernels take float16 rows of 32, 64 or 128 channels."""
         return self.enabled and x.is_cuda and x.dtype == torch.float16 and x.shape[-1] in (32, 64, 128) and self._mfma
 
-    def qkv_gram(self, x2: torch.Tensor, wpack: torch.Tensor, heads: int, want_v: bool = True):
+    def qkv_gram(self, x2: torch.Tensor, wpack: torch.Tensor, heads: int, want_v: bool = True, k16: bool = False):
         """x2 (b, n, c) float16 -> v (b, n, c) (None when not wanted: the pass then only reads), gram (b, heads, 32, 32), nq (b, c), nk (b, c)
-        (csrc/mst_mfma.hip)."""
+        (csrc/mst_mfma.hip).  k16: wpack is pack_qkv16's (the K = 16 MFMA kernel), else pack_fragments' (K = 8)."""
         from .._lib import lib
 
         b, n, c = x2.shape
@@ -185,9 +211,9 @@ class _AvxOps:
         nq = torch.empty((b, c), dtype=torch.float32, device=x2.device)
         nk = torch.empty((b, c), dtype=torch.float32, device=x2.device)
         st = torch.cuda.current_stream(x2.device).cuda_stream
+        fn = lib.avx_mst_qkv_gram16 if k16 else lib.avx_mst_qkv_gram
         for i in range(b):
-            ctx._check(lib.avx_mst_qkv_gram(ctx._h, x2[i].data_ptr(), wpack.data_ptr(), n, c, v[i].data_ptr() if want_v else None, g[i].data_ptr(), nq[i].data_ptr(),
-                                            nk[i].data_ptr(), st))
+            ctx._check(fn(ctx._h, x2[i].data_ptr(), wpack.data_ptr(), n, c, v[i].data_ptr() if want_v else None, g[i].data_ptr(), nq[i].data_ptr(), nk[i].data_ptr(), st))
         return v, g, nq, nk
 
     def ln_gemm_gelu(self, x2: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wpack: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -545,9 +571,12 @@ class MSTPlusPlus(torch.nn.Module):
                                                          self._w(p + ".to_v.weight", (0, 1))], 0).t().contiguous())
         d = c // heads  # 32: 31 real channels + the zero padding
         if _AVX.fused_ok(x):  # one pass over x: q, k live only in MFMA accumulators, v is the only tensor written
-            wpk = self._prep(p + ".qkv.frag", lambda: torch.cat([pack_fragments(wqkv[:, : 2 * c], False), pack_fragments(wqkv[:, 2 * c :], True)], 0).contiguous())
             tailx = _AVX._tail and _AVX._tailx and c in (32, 64)  # the tail forms v itself: this pass writes nothing but the Gram partials
-            v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads, want_v=not tailx)
+            if _AVX._qkv16:  # K = 16 MFMAs: a quarter of the matrix-core cycles (the K = 8 kernel is bound by them)
+                wpk = self._prep(p + ".qkv.frag16", lambda: pack_qkv16(wqkv))
+            else:
+                wpk = self._prep(p + ".qkv.frag", lambda: torch.cat([pack_fragments(wqkv[:, : 2 * c], False), pack_fragments(wqkv[:, 2 * c :], True)], 0).contiguous())
+            v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads, want_v=not tailx, k16=_AVX._qkv16)
             if self.capture_attn is not None:
                 self._capture(gram, nq, nk, p, heads)
             # softmax(gram / (nk nq^T) * rescale) and M = blockdiag(attn_h^T) @ W_proj^T in one small launch, M already in fragment order

@@ -343,6 +343,10 @@ int avx_mst_gram(avx_ctx* ctx, const void* qkv, int dtype, size_t n_pix, int C, 
  * first 1x1 conv (:145, C -> 4C) -> GELU (:146); out: rows x 4C float16. */
 int avx_mst_qkv_gram(avx_ctx* ctx, const void* x, const void* wpack, size_t n_pix, int C, void* v_out, float* gram, float* nq, float* nk,
                      void* stream);
+/* avx_mst_qkv_gram on v_mfma_f32_32x32x16_f16: the same results (products are exact, float32 sums in another order) from wpack16 =
+ * ml/mst_plus_plus.py::pack_qkv16 ([3C/32 tiles][C/16 steps][64 lanes] x 8 halves; q / k tiles in natural channel order, v tiles row-permuted). */
+int avx_mst_qkv_gram16(avx_ctx* ctx, const void* x, const void* wpack16, size_t n_pix, int C, void* v_out, float* gram, float* nq, float* nk,
+                       void* stream);
 int avx_mst_ln_gemm_gelu(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* wpack, size_t rows, int C,
                          void* out, void* stream);
 
