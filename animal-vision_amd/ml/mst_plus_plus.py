@@ -294,7 +294,10 @@ class _AvxOps:
         assert x.is_contiguous() and c in (32, 64) and h % 2 == 0 and w % 2 == 0
         out = torch.empty((b, h // 2, w // 2, 2 * c), dtype=torch.float16, device=x.device)
         ctx = self.ctx(x.device)
-        ctx._check(lib.avx_mst_down4x4(ctx._h, x.data_ptr(), wpack16.data_ptr(), out.data_ptr(), b, h, w, c, torch.cuda.current_stream(x.device).cuda_stream))
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        per = max(1, (2**31 - 1) // (h * w * c * 2))  # the kernel addresses its input with 32-bit byte offsets: frames per launch
+        for i in range(0, b, per):
+            ctx._check(lib.avx_mst_down4x4(ctx._h, x[i : i + per].data_ptr(), wpack16.data_ptr(), out[i : i + per].data_ptr(), min(per, b - i), h, w, c, st))
         return out
 
     def conv3x3_lds(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:

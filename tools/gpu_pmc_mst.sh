@@ -70,3 +70,4 @@ for k in sorted(agg):
     if "SQ_BUSY_CYCLES" in m and "SQ_ACTIVE_INST_VALU" in m:
         print(f"   VALU active / wave-cycles-per-SIMD: {m['SQ_ACTIVE_INST_VALU'] / max(m.get('SQ_WAVE_CYCLES', 1), 1):.3f}")
 PY
+rm -rf gpurun_out/pmc_mst/p[0-9]*/  # the raw counter CSVs are hundreds of MB: only summary.txt and traffic.json travel back
