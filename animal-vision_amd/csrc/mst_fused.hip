@@ -46,6 +46,29 @@ constexpr int NGRP = (NHALO + 31) / 32;  // 11 pixel groups of 32
 __device__ __forceinline__ float16_t mfma16(half8_t a, half8_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 struct Tile { int x0, y0; long b; };
+// Tiles blockIdx.x, + gridDim.x, ... of a (frames x ty x tx) grid WITHOUT a division per tile: the coordinates advance by the step's own
+// (dx, dy, db) with carries -- scalar adds and compares.  tile_of(t) = (t % tx, (t / tx) % ty, t / (tx ty)) as 64-bit divisions cost ~150
+// vector instructions per tile and wave (there is no scalar divide): a fifth of the attention tail's instruction stream.
+struct TileWalk {
+    int xi, yi, dx, dy, tx, ty;
+    long b, db;
+    __device__ __forceinline__ void init(long t0, long step, int tx_, int ty_) {
+        tx = tx_; ty = ty_;
+        auto uni = [](long v) { return (long)(unsigned)__builtin_amdgcn_readfirstlane((int)v) | (long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32; };  // the divisions run on the vector unit
+        xi = (int)uni(t0 % tx); yi = (int)uni((t0 / tx) % ty); b = uni(t0 / ((long)tx * ty));
+        dx = (int)uni(step % tx); dy = (int)uni((step / tx) % ty); db = uni(step / ((long)tx * ty));
+    }
+    __device__ __forceinline__ void advance() {
+        xi += dx;
+        const int cx = xi >= tx ? 1 : 0;
+        xi -= cx ? tx : 0;
+        yi += dy + cx;
+        const int cy = yi >= ty ? 1 : 0;
+        yi -= cy ? ty : 0;
+        b += db + cy;
+    }
+    __device__ __forceinline__ Tile tile(int side) const { return Tile{xi * side, yi * side, b}; }
+};
 
 template <int C, int HPASS, int MINW>
 __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -66,7 +89,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     for (int i = tid; i < C; i += kFT) { gl[i] = gamma[i]; gl[C + i] = beta[i]; }
     const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
     const long total = (long)B * ty * tx;
-    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };
+    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };  // (TileWalk measured 2 % slower in THIS kernel: the divisions run on the scalar unit beside a saturated vector unit)
     const float cnt = (float)(NT * 31);
 
     // ---- phase 0, split: fetch the raw rows of this wave's halo pixel groups (wave w: groups w and w + 8) ----
@@ -312,7 +335,6 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
     for (int i = tid; i < C; i += kFT) bl[i] = bias ? bias[i] : 0.f;
     const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
     const long total = (long)B * ty * tx;
-    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };
     // phase B role: a wave keeps ONE channel octet (its first-conv taps are wave-uniform LDS reads: broadcasts) and walks pixels of the 18 x 18 map
     const int oct = wave % NO, part = wave / NO, nparts = 8 / NO, per = (MS * MS + nparts - 1) / nparts;
     half8_t mf[NT * NS];
@@ -370,7 +392,11 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
     }
     long tile = blockIdx.x;
     if (tile >= total) return;
-    Tile t = tile_of(tile);
+    TileWalk walk, ahead;  // this tile, the next one
+    walk.init(tile, gridDim.x, tx, ty);
+    ahead = walk;
+    ahead.advance();
+    Tile t = walk.tile(TS);
     fetch(t);
     for (;;) {
         fill();
@@ -438,7 +464,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
         }
         __syncthreads();  // mt complete
         const long next = tile + gridDim.x;
-        if (next < total) fetch(tile_of(next));  // in flight during phase C
+        if (next < total) fetch(ahead.tile(TS));  // in flight during phase C
         // ---- phase C: dw2(mid) + v @ M + bias + x for this wave's 32 pixels (rows 2 wave, 2 wave + 1) ----
         {
             const int r = 2 * wave + (p >> 4), c = p & 15;
@@ -502,7 +528,9 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
         }
         if (next >= total) break;
         tile = next;
-        t = tile_of(tile);
+        walk = ahead;
+        ahead.advance();
+        t = walk.tile(TS);
         __syncthreads();  // everyone is done reading vt / mt
     }
 }
@@ -538,9 +566,24 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
     for (int i = tid; i < 18 * 64; i += kFT) wl[i] = wpack[i];
     const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
     const long total = (long)B * ty * tx;
-    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };
     uint4 pre[NFILL];
+    unsigned f_rel[NFILL];  // this thread's halo elements as byte offsets from the halo origin (y0 - 1, x0 - 1)
+#pragma unroll
+    for (int k = 0; k < NFILL; ++k) {
+        const int it = tid + k * kFT, itc = it < HS * HS * 4 ? it : 0, q = itc >> 2, part = itc & 3;
+        f_rel[k] = (unsigned)(((q / HS) * W + q % HS) * C + 8 * part) * 2u;
+    }
     auto fetch = [&](const Tile& t) {
+        if (t.y0 >= 1 && t.y0 + HS - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W) {  // halo inside the frame: scalar origin + fixed lane offsets
+            const char* origin = reinterpret_cast<const char*>(x + ((t.b * H + t.y0 - 1) * (size_t)W + t.x0 - 1) * C);
+#pragma unroll
+            for (int k = 0; k < NFILL; ++k) {
+                unsigned o = f_rel[k];
+                asm volatile("" : "+v"(o));  // keeps the zero-extension here (see k_mst_attn_tail)
+                pre[k] = *reinterpret_cast<const uint4*>(origin + o);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NFILL; ++k) {
             const int it = tid + k * kFT, q = it >> 2, part = it & 3;
@@ -554,7 +597,11 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
     };
     long tile = blockIdx.x;
     if (tile >= total) return;
-    Tile t = tile_of(tile);
+    TileWalk walk, ahead;  // this tile, the next one
+    walk.init(tile, gridDim.x, tx, ty);
+    ahead = walk;
+    ahead.advance();
+    Tile t = walk.tile(TS);
     fetch(t);
     for (;;) {
 #pragma unroll
@@ -564,7 +611,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
         }
         __syncthreads();
         const long next = tile + gridDim.x;
-        if (next < total) fetch(tile_of(next));
+        if (next < total) fetch(ahead.tile(TS));
         {
             const int r = 2 * wave + (p >> 4), c = p & 15;
             const int yo = t.y0 + r, xo = t.x0 + c;
@@ -592,7 +639,9 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
         }
         if (next >= total) break;
         tile = next;
-        t = tile_of(tile);
+        walk = ahead;
+        ahead.advance();
+        t = walk.tile(TS);
         __syncthreads();  // everyone is done reading xt
     }
 }
@@ -652,7 +701,7 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_dma(const __half* __rest
     const int tx = (Wo + G::OW - 1) / G::OW, ty = (Ho + G::OH - 1) / G::OH;
     const unsigned total = (unsigned)B * ty * tx;
     struct T2 { int ox0, oy0, b; };
-    auto tile_of = [&](unsigned u) { const unsigned row = u / (unsigned)tx; return T2{(int)(u - row * tx) * G::OW, (int)(row % (unsigned)ty) * G::OH, (int)(row / (unsigned)ty)}; };
+    auto tile_at = [&](const TileWalk& w) { return T2{w.xi * G::OW, w.yi * G::OH, (int)w.b}; };  // coordinates advance with the walk: no division per tile
     // this lane's slots of a tile: tile-relative pixel and byte offset, fixed for the launch
     int rel[G::PER_WAVE], rc[G::PER_WAVE];
 #pragma unroll
@@ -663,9 +712,9 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_dma(const __half* __rest
         rc[k] = inside ? row << 8 | col : -1;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds);
-    auto fill = [&](unsigned u, int slot) {
-        const bool exists = u < total;
-        const T2 t = tile_of(exists ? u : 0u);
+    auto fill = [&](unsigned u, const TileWalk& w, int slot) {
+        const bool exists = u < total;  // past the end: the walk's coordinates mean nothing and every lane reads zeros
+        const T2 t = tile_at(w);
         const int y0 = 2 * t.oy0 - 1, x0 = 2 * t.ox0 - 1;
         const char* origin = reinterpret_cast<const char*>(x) + (((long)t.b * H + y0) * W + x0) * (long)(C * 2);
         const unsigned lb = lds0 + slot * G::BUF + wave * 1024;
@@ -683,8 +732,11 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_dma(const __half* __rest
     };
     unsigned tile = blockIdx.x;
     if (tile >= total) return;
+    TileWalk walk, look;  // this tile; the one NBUF - 1 steps ahead, whose loads are issued next
+    walk.init(tile, gridDim.x, tx, ty);
+    look = walk;
 #pragma unroll
-    for (int a = 0; a < G::NBUF - 1; ++a) fill(tile + a * gridDim.x, a);
+    for (int a = 0; a < G::NBUF - 1; ++a) { fill(tile + a * gridDim.x, look, a); look.advance(); }
     // operand addressing: pixel (row 2 g + (p >> 4), col p & 15) of the group; tap (ky, kx) reads tile pixel (2 row + ky, 2 col + kx)
     const int c2 = 2 * (p & 15);
     int colofs[4];
@@ -701,9 +753,10 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_dma(const __half* __rest
         {
             int nslot = slot + G::NBUF - 1;
             nslot -= nslot >= G::NBUF ? G::NBUF : 0;
-            fill(tile + (G::NBUF - 1) * gridDim.x, nslot);
+            fill(tile + (G::NBUF - 1) * gridDim.x, look, nslot);
+            look.advance();
         }
-        const T2 t = tile_of(tile);
+        const T2 t = tile_at(walk);
         const bool whole = t.oy0 + G::OH <= Ho && t.ox0 + G::OW <= Wo;
         const unsigned char* bt = lds + slot * G::BUF;
 #pragma unroll 1
@@ -766,6 +819,7 @@ __global__ __launch_bounds__(kFT, 2) void k_mst_down4x4_dma(const __half* __rest
         plain_stores = whole ? (plain_stores < G::NBUF - 1 ? plain_stores + 1 : plain_stores) : 0;
         if (tile + gridDim.x >= total) break;
         tile += gridDim.x;
+        walk.advance();
         slot = slot + 1 == G::NBUF ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of tiles past the end still target this workgroup's LDS
