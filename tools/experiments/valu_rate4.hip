@@ -25,6 +25,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             if (OP == 8) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
             if (OP == 9) asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(a[i]));
             if (OP == 10) asm volatile("v_med3_f32 %0, %0, %0, %0" : "+v"(a[i]));
+            if (OP == 11) asm volatile("v_pk_fma_f16 %0, %0, %0, %0" : "+v"(a[i]));
+            if (OP == 12) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) % NCH]), "v"(a[(i + 2) % NCH]));
+            if (OP == 13) asm volatile("v_pk_mul_f16 %0, %0, %0" : "+v"(a[i]));
+            if (OP == 14) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) % NCH]), "v"(a[(i + 2) % NCH]));
+            if (OP == 15) asm volatile("v_pk_max_f16 %0, %0, %0" : "+v"(a[i]));
         }
     }
     float s = 0;
@@ -58,5 +63,6 @@ int main() {
     printf("ns per wave64 instruction per SIMD (8 chains / 16 chains per wave), w waves per SIMD\n");
     ROW("v_fma_f32 (same reg)", 0) ROW("v_fma_f32 (3 regs)", 1) ROW("v_mul_f32", 2) ROW("v_pk_fma_f32 (same reg)", 3) ROW("v_pk_fma_f32 (3 regs)", 4)
     ROW("v_pk_mul_f32", 5) ROW("v_fma_mix_f32", 6) ROW("v_exp_f32", 7) ROW("v_rcp_f32", 8) ROW("v_cvt_pk_f16_f32", 9) ROW("v_med3_f32", 10)
+    ROW("v_pk_fma_f16 (same reg)", 11) ROW("v_pk_fma_f16 (3 regs)", 12) ROW("v_pk_mul_f16", 13) ROW("v_dot2_f32_f16", 14) ROW("v_pk_max_f16", 15)
     return 0;
 }
