@@ -569,111 +569,119 @@ __global__ __launch_bounds__(kT) void k_mst_posemb(const __half* __restrict__ v,
     constexpr int CV = C / 8, PH = TH + 2, PW = TW + 2;
     static_assert(PH % 2 == 0 && kT % CV == 0, "row pairs in phase 1; fixed channel group per thread");
     extern __shared__ __align__(16) unsigned char smem[];
-    float* wl = reinterpret_cast<float*>(smem);                                     // [2][9][C] taps, tap-major
-    float* bl = wl + 2 * 9 * C;                                                     // [C] bias
+    __half* wl = reinterpret_cast<__half*>(smem);                                   // [2][9][C] taps, tap-major, float16 (the model's own values: the float32 table holds them exactly)
+    float* bl = reinterpret_cast<float*>(wl + 2 * 9 * C);                           // [C] bias
     unsigned char* mid = reinterpret_cast<unsigned char*>(bl + C);                  // [PH][PW][C] float16
     const int tid = threadIdx.x;
-    for (int i = tid; i < 9 * C; i += kT) { const int c = i / 9, t = i - 9 * c; wl[t * C + c] = w1[i]; wl[9 * C + t * C + c] = w2[i]; }
+    for (int i = tid; i < 9 * C; i += kT) { const int c = i / 9, t = i - 9 * c; wl[t * C + c] = __float2half(w1[i]); wl[9 * C + t * C + c] = __float2half(w2[i]); }
     for (int i = tid; i < C; i += kT) bl[i] = bias ? bias[i] : 0.f;
     const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
     const long total = (long)B * ty * tx;
-    auto taps = [&](const float* wbase, int t, int cg, float2_t (&wt)[4]) {
-        const float4 a = *reinterpret_cast<const float4*>(wbase + t * C + cg * 8);
-        const float4 c = *reinterpret_cast<const float4*>(wbase + t * C + cg * 8 + 4);
-        wt[0] = float2_t{a.x, a.y}; wt[1] = float2_t{a.z, a.w}; wt[2] = float2_t{c.x, c.y}; wt[3] = float2_t{c.z, c.w};
+    const int cg = tid % CV;  // kT % CV == 0: a thread keeps its channel group, so each phase holds its 72 taps (nine 16-byte registers of float16) for the launch
+    auto taps = [&](const __half* wbase, uint4 (&wt)[9]) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const uint4*>(wbase + t * C + cg * 8);
     };
+    // float16 data x float16 taps, float32 accumulation: one v_fma_mix_f32 per MAC, no conversion instructions (mst_common.h)
+    auto mac8 = [&](float (&acc)[8], const uint4& hv, const uint4& wv) {
+        fma_mix_lo(acc[0], hv.x, wv.x); fma_mix_hi(acc[1], hv.x, wv.x);
+        fma_mix_lo(acc[2], hv.y, wv.y); fma_mix_hi(acc[3], hv.y, wv.y);
+        fma_mix_lo(acc[4], hv.z, wv.z); fma_mix_hi(acc[5], hv.z, wv.z);
+        fma_mix_lo(acc[6], hv.w, wv.w); fma_mix_hi(acc[7], hv.w, wv.w);
+    };
+    __syncthreads();
     for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int x0 = (int)(tile % tx) * TW, y0 = (int)((tile / tx) % ty) * TH;
         const long b = tile / ((long)tx * ty);
-        __syncthreads();  // the previous tile's phase 2 is done with `mid` (and the tables are loaded, first time round)
-        const int cg = tid % CV;  // kT % CV == 0: a thread keeps its channel group, so each phase holds its 72 taps in registers
-        float2_t wt[9][4];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) taps(wl, t, cg, wt[t]);
+        // every pixel phase 1 touches (rows y0 - 2 .. y0 + TH + 1, columns x0 - 2 .. x0 + TW + 1) inside the frame: no clamping, no masks
+        const bool interior = y0 >= 2 && y0 + TH + 2 <= H && x0 >= 2 && x0 + TW + 2 <= W;
+        __syncthreads();  // the previous tile's phase 2 is done with `mid`
+        uint4 wt1[9];  // reloaded per tile and phase (nine LDS reads): resident for the launch, the two sets cost 72 registers and a wave of occupancy
+        taps(wl, wt1);
 #pragma unroll 1
         for (int it = tid; it < (PH / 2) * PW * CV; it += kT) {  // one item = two vertically adjacent pixels of the halo region
             const int pp = it / CV, c = pp % PW, r = 2 * (pp / PW);
             const int yy = y0 - 1 + r, xx = x0 - 1 + c;
             uint4 raw[4][3];
+            if (interior) {
+                const __half* base = v + ((b * H + yy - 1) * (size_t)W + xx - 1) * C + cg * 8;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)  // branch-free: clamped addresses, out-of-image taps zeroed below
+                for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int y2 = yy - 1 + rr, x2 = xx + kx - 1;
-                    const int yc = y2 < 0 ? 0 : (y2 >= H ? H - 1 : y2), xc = x2 < 0 ? 0 : (x2 >= W ? W - 1 : x2);
-                    raw[rr][kx] = *reinterpret_cast<const uint4*>(v + ((b * H + yc) * (size_t)W + xc) * C + cg * 8);
-                }
-            float2_t acc[2][4];
+                    for (int kx = 0; kx < 3; ++kx) raw[rr][kx] = *reinterpret_cast<const uint4*>(base + ((size_t)rr * W + kx) * C);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)  // branch-free: clamped addresses, out-of-image taps zeroed
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int y2 = yy - 1 + rr, x2 = xx + kx - 1;
+                        const bool ok = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+                        const int yc = y2 < 0 ? 0 : (y2 >= H ? H - 1 : y2), xc = x2 < 0 ? 0 : (x2 >= W ? W - 1 : x2);
+                        uint4 rw = *reinterpret_cast<const uint4*>(v + ((b * H + yc) * (size_t)W + xc) * C + cg * 8);
+                        rw.x = ok ? rw.x : 0u; rw.y = ok ? rw.y : 0u; rw.z = ok ? rw.z : 0u; rw.w = ok ? rw.w : 0u;
+                        raw[rr][kx] = rw;
+                    }
+            }
+            float acc[2][8];
 #pragma unroll
             for (int o2 = 0; o2 < 2; ++o2)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[o2][q] = float2_t{0.f, 0.f};
+                for (int q = 0; q < 8; ++q) acc[o2][q] = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int y2 = yy - 1 + rr, x2 = xx + kx - 1;
-                    const bool ok = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
-                    uint4 rw = raw[rr][kx];
-                    rw.x = ok ? rw.x : 0u; rw.y = ok ? rw.y : 0u; rw.z = ok ? rw.z : 0u; rw.w = ok ? rw.w : 0u;
-                    const half8_t h8 = __builtin_bit_cast(half8_t, rw);
-                    float2_t f[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) f[q] = float2_t{(float)h8[2 * q], (float)h8[2 * q + 1]};
+                for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                     for (int o2 = 0; o2 < 2; ++o2) {  // input row rr is tap row ky = rr - o2 of output o2
                         const int ky = rr - o2;
                         if (ky < 0 || ky > 2) continue;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[o2][q] = __builtin_elementwise_fma(f[q], wt[ky * 3 + kx][q], acc[o2][q]);
+                        mac8(acc[o2], raw[rr][kx], wt1[ky * 3 + kx]);
                     }
-                }
 #pragma unroll
             for (int o2 = 0; o2 < 2; ++o2) {
                 const int ym = yy + o2;
-                const bool inside = ym >= 0 && ym < H && xx >= 0 && xx < W;
-                half8_t o;
+                const bool inside = interior || (ym >= 0 && ym < H && xx >= 0 && xx < W);
+                unsigned o[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float2_t g = gelu_fast2(acc[o2][q]);
-                    o[2 * q] = inside ? (_Float16)g.x : (_Float16)0.f;
-                    o[2 * q + 1] = inside ? (_Float16)g.y : (_Float16)0.f;
+                    const float2_t g = gelu_fast2(float2_t{acc[o2][2 * q], acc[o2][2 * q + 1]});
+                    o[q] = inside ? pack_f16(g.x, g.y) : 0u;
                 }
-                *reinterpret_cast<uint4*>(mid + (((size_t)(r + o2) * PW + c) * C + cg * 8) * 2) = __builtin_bit_cast(uint4, o);
+                *reinterpret_cast<uint4*>(mid + (((size_t)(r + o2) * PW + c) * C + cg * 8) * 2) = uint4{o[0], o[1], o[2], o[3]};
             }
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) taps(wl + 9 * C, t, cg, wt[t]);
         __syncthreads();
+        uint4 wt2[9];
+        taps(wl + 9 * C, wt2);
 #pragma unroll 1
         for (int it = tid; it < TH * TW * CV; it += kT) {
             const int pp = it / CV, c = pp % TW, r = pp / TW;
             const int yo = y0 + r, xo = x0 + c;
             if (yo >= H || xo >= W) continue;
-            float2_t acc[4] = {float2_t{0.f, 0.f}, float2_t{0.f, 0.f}, float2_t{0.f, 0.f}, float2_t{0.f, 0.f}};
+            float acc[8];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const half8_t h8 = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(mid + (((size_t)(r + t / 3) * PW + c + t % 3) * C + cg * 8) * 2));
+            for (int q = 0; q < 8; ++q) acc[q] = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_elementwise_fma(float2_t{(float)h8[2 * q], (float)h8[2 * q + 1]}, wt[t][q], acc[q]);
-            }
+            for (int t = 0; t < 9; ++t) mac8(acc, *reinterpret_cast<const uint4*>(mid + (((size_t)(r + t / 3) * PW + c + t % 3) * C + cg * 8) * 2), wt2[t]);
             const size_t off = ((b * H + yo) * (size_t)W + xo) * C + cg * 8;
-            half8_t rr = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (res) rr = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(res + off));
-            half8_t o;
+            uint4 rr = uint4{0u, 0u, 0u, 0u};
+            if (res) rr = *reinterpret_cast<const uint4*>(res + off);
+            const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+            unsigned o[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                o[2 * q] = (_Float16)(acc[q].x + (float)rr[2 * q] + bl[cg * 8 + 2 * q]);
-                o[2 * q + 1] = (_Float16)(acc[q].y + (float)rr[2 * q + 1] + bl[cg * 8 + 2 * q + 1]);
+            for (int q = 0; q < 4; ++q) {  // (acc + residual) + bias, the float16 residual taken as it is (x * 1.0 + acc)
+                float s0 = acc[2 * q], s1 = acc[2 * q + 1];
+                fma_mix_lo(s0, rw[q], 0x3c003c00u); fma_mix_hi(s1, rw[q], 0x3c003c00u);
+                o[q] = pack_f16(s0 + bl[cg * 8 + 2 * q], s1 + bl[cg * 8 + 2 * q + 1]);
             }
-            *reinterpret_cast<uint4*>(out + off) = __builtin_bit_cast(uint4, o);
+            *reinterpret_cast<uint4*>(out + off) = uint4{o[0], o[1], o[2], o[3]};
         }
     }
 }
 
 template <int C, int TH, int TW>
 int launch_posemb(avx_ctx* ctx, const void* v, const float* w1, const float* w2, const void* res, const float* bias, void* out, int B, int H, int W, hipStream_t s) {
-    const size_t lds = sizeof(float) * (2 * 9 * C + C) + (size_t)(TH + 2) * (TW + 2) * C * 2;
+    const size_t lds = sizeof(__half) * 2 * 9 * C + sizeof(float) * C + (size_t)(TH + 2) * (TW + 2) * C * 2;
     const long total = (long)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const long cap = (long)ctx->num_cus * (lds > 40 * 1024 ? 3 : 5);
     auto k = k_mst_posemb<C, TH, TW>;
