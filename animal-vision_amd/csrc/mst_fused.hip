@@ -426,6 +426,12 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
             __syncthreads();  // vt complete; the x tile is dead: its region becomes mt
         }
         // ---- phase B: mid = gelu(dw1(v)) on the 18 x 18 region, zero outside the image ----
+        constexpr bool HOIST = C == 64;  // two waves per SIMD: the nine tap vectors of this wave's octet are read once per tile, not once per item (a third of phase B's LDS reads)
+        uint4 wt1[HOIST ? 9 : 1];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wt1[tap] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(t1l) + (size_t)tap * C * 2 + 16 * oct);
+        }
         const bool mid_inside = t.y0 >= 1 && t.y0 + MS - 1 <= H && t.x0 >= 1 && t.x0 + MS - 1 <= W;  // scalar: no per-pixel test, no masking below
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const uint4 hv = *reinterpret_cast<const uint4*>(src + (tap / 3) * VRP + (tap % 3) * PP);
-                const uint4 wv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(t1l) + (size_t)tap * C * 2 + 16 * oct);
+                const uint4 wv = HOIST ? wt1[HOIST ? tap : 0] : *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(t1l) + (size_t)tap * C * 2 + 16 * oct);
                 fma_mix_lo(acc[0], hv.x, wv.x); fma_mix_hi(acc[1], hv.x, wv.x);
                 fma_mix_lo(acc[2], hv.y, wv.y); fma_mix_hi(acc[3], hv.y, wv.y);
                 fma_mix_lo(acc[4], hv.z, wv.z); fma_mix_hi(acc[5], hv.z, wv.z);
