@@ -509,13 +509,11 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail(const __half* __res
             if (live) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const half8_t r0 = __builtin_bit_cast(half8_t, xr[2 * n]), r1 = __builtin_bit_cast(half8_t, xr[2 * n + 1]);
                     const float* bb = bl + h * (C / 2) + 16 * n;
                     // ((D + float16(pe)) + bias) + x, the float16 operands taken as they are by v_fma_mix_f32 (a * 1.0 + c: the same sum, no conversion instructions)
                     constexpr unsigned kOnes = 0x3c003c00u;
                     const uint4 xa = xr[2 * n], xb = xr[2 * n + 1];
                     const unsigned xw[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                    (void)r0; (void)r1;
                     unsigned ow[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {  // output channels 2 j, 2 j + 1 of this lane's 16
