@@ -149,17 +149,26 @@ __global__ __launch_bounds__(kT) void k_mst_qkv(const __half* __restrict__ x, co
 // one wave per output element over the block partials (same shape as csrc/mst.hip's: deterministic tree)
 __global__ void k_mst_qkv_final(const float* __restrict__ partial, int nblocks, int heads, float* gram /*[heads][32][32]*/, float* nq /*[heads*32]*/,
                                 float* nk) {
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (i >= heads * 34 * 32) return;
-    float s = 0.f;
-    for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * heads * 34 * 32 + i];
+    // a wave sums FOUR neighbouring entries over the workgroups' partials: lane l takes workgroups l, l + 64, ... with 16-byte loads (a quarter
+    // of each 64-byte sector it touches instead of a sixteenth: the one-entry form moved 32x the bytes it summed), then the lanes combine
+    const int i0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4, lane = threadIdx.x & 63, tot = heads * 34 * 32;
+    if (i0 >= tot) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = lane; b < nblocks; b += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * tot + i0);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    for (int o = 32; o > 0; o >>= 1) { s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o); }
     if (lane != 0) return;
-    const int hd = i / (34 * 32), e = i - hd * 34 * 32, r = e >> 5, c = e & 31;
-    if (r < 32) gram[(hd * 32 + r) * 32 + c] = s;
-    else if (r == 32) nq[hd * 32 + c] = __fsqrt_rn(s);
-    else nk[hd * 32 + c] = __fsqrt_rn(s);
+    const float r4[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q, hd = i / (34 * 32), e = i - hd * 34 * 32, r = e >> 5, c = e & 31;
+        if (r < 32) gram[(hd * 32 + r) * 32 + c] = r4[q];
+        else if (r == 32) nq[hd * 32 + c] = __fsqrt_rn(r4[q]);
+        else nk[hd * 32 + c] = __fsqrt_rn(r4[q]);
+    }
 }
 
 // ---- LayerNorm -> 1x1 conv (C -> 4C) -> GELU -----------------------------------------------------------------------
@@ -895,7 +904,7 @@ int launch_qkv16(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, siz
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * NW), lds, s, (const __half*)x, (const uint4*)wpack, n, (__half*)v_out, partial);
     AVX_HIP(ctx, hipGetLastError());
     const int tot = HD * 34 * 32;
-    hipLaunchKernelGGL(k_mst_qkv_final, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, partial, (int)blocks, HD, gram, nq, nk);
+    hipLaunchKernelGGL(k_mst_qkv_final, dim3((tot / 4 * 64 + 255) / 256), dim3(256), 0, s, partial, (int)blocks, HD, gram, nq, nk);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
@@ -917,7 +926,7 @@ int launch_qkv(avx_ctx* ctx, avx_ws* ws, const void* x, const void* wpack, size_
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, n, (__half*)v_out, partial);
     AVX_HIP(ctx, hipGetLastError());
     const int tot = HD * 34 * 32;
-    hipLaunchKernelGGL(k_mst_qkv_final, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, partial, (int)blocks, HD, gram, nq, nk);
+    hipLaunchKernelGGL(k_mst_qkv_final, dim3((tot / 4 * 64 + 255) / 256), dim3(256), 0, s, partial, (int)blocks, HD, gram, nq, nk);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
