@@ -560,14 +560,27 @@ int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpa
 // (:199, :228, :277).  The register-only form (csrc/mst_mfma.hip::k_mst_conv3x3) fetches every tap's row from L2 per wave -- nine
 // reads of each pixel, 470 MB of fetch traffic per 1080p launch against 133 MB of input; here a workgroup stages its 18 x 18 halo
 // region once (next tile's rows in flight during the MFMAs) and the nine taps are 16-byte LDS reads.  Implicit GEMM, K = 9 x 32.
-template <int MINW>
+// GRAM: the MSAB block that follows the conv starts with the Gram pass over exactly this output (q = out W_q^T, k = out W_k^T, k^T q and the column
+// norms over all pixels, MS_MSA :118-129).  The lane that has just rounded its pixel's 16 channels to float16 holds them in the K = 16 operand order
+// of avx_mst_qkv_gram16 (channel 16 h + 8 s + j), so the pass runs here on registers -- four projection MFMAs, two Gram MFMAs per 32 pixels --
+// and the 531 MB re-read of the tensor (121 us per 4K launch) does not happen.  Per-workgroup partial sums, reduced by k_mst_qkv_final as there.
+template <int MINW, bool GRAM>
 __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __restrict__ x /*[B][H][W][32]*/, const uint4* __restrict__ wpack /*[9][2][64]*/,
-                                                               const __half* __restrict__ add /*or NULL*/, __half* __restrict__ out, int B, int H, int W) {
+                                                               const __half* __restrict__ add /*or NULL*/, __half* __restrict__ out, int B, int H, int W,
+                                                               const uint4* __restrict__ wqk /*[2][2][64]: pack_qkv16's q and k tiles*/, float* __restrict__ partial /*[blocks][34][32]*/) {
     constexpr int C = 32, PP = C * 2 + 16, RP = (HS * PP + 255) / 256 * 256, NFILL = (HS * HS * 4 + kFT - 1) / kFT;
     __shared__ __align__(16) unsigned char xt[HS * RP];
     __shared__ uint4 wl[18 * 64];  // the 18 A fragments (9 taps x 2 K-steps): in registers they cost 72 VGPRs and a wave of occupancy
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
     for (int i = tid; i < 18 * 64; i += kFT) wl[i] = wpack[i];
+    __shared__ uint4 wq[GRAM ? 4 * 64 : 1];
+    float16_t G;
+    float nq = 0.f, nk = 0.f;
+    if constexpr (GRAM) {
+        if (tid < 4 * 64) wq[tid] = wqk[tid];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) G[v] = 0.f;
+    }
     const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
     const long total = (long)B * ty * tx;
     uint4 pre[NFILL];
@@ -632,13 +645,37 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
                     d = mfma16(__builtin_bit_cast(half8_t, wl[(2 * tap + s2) * 64 + lane]), __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(src + (size_t)(tap / 3) * RP + (size_t)(tap % 3) * PP + 32 * s2)), d);
-            if (live) {
+            half8_t o0, o1;
+            {
                 const half8_t r0 = __builtin_bit_cast(half8_t, ar[0]), r1 = __builtin_bit_cast(half8_t, ar[1]);
-                half8_t o0, o1;
 #pragma unroll
                 for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)(d[v] + (float)r0[v]); o1[v] = (_Float16)(d[8 + v] + (float)r1[v]); }
+            }
+            if (live) {
                 reinterpret_cast<uint4*>(out + off)[0] = __builtin_bit_cast(uint4, o0);
                 reinterpret_cast<uint4*>(out + off)[1] = __builtin_bit_cast(uint4, o1);
+            }
+            if constexpr (GRAM) {
+                if (!live) { o0 = half8_t{0, 0, 0, 0, 0, 0, 0, 0}; o1 = o0; }  // pixels past the frame's edge take no part in the sums
+                float16_t dq, dk;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { dq[v] = 0.f; dk[v] = 0.f; }
+                dq = mfma16(o0, __builtin_bit_cast(half8_t, wq[0 * 64 + lane]), dq);  // D[pixel][q channel]
+                dq = mfma16(o1, __builtin_bit_cast(half8_t, wq[1 * 64 + lane]), dq);
+                dk = mfma16(o0, __builtin_bit_cast(half8_t, wq[2 * 64 + lane]), dk);  // D[pixel][k channel]
+                dk = mfma16(o1, __builtin_bit_cast(half8_t, wq[3 * 64 + lane]), dk);
+                unsigned aq[8], ak[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    aq[j] = pack_f16(dq[2 * j], dq[2 * j + 1]);
+                    ak[j] = pack_f16(dk[2 * j], dk[2 * j + 1]);
+                    fma_mix_lo(nq, aq[j], aq[j]); fma_mix_hi(nq, aq[j], aq[j]);
+                    fma_mix_lo(nk, ak[j], ak[j]); fma_mix_hi(nk, ak[j], ak[j]);
+                }
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+                    G = mfma16(__builtin_bit_cast(half8_t, uint4{ak[4 * b2], ak[4 * b2 + 1], ak[4 * b2 + 2], ak[4 * b2 + 3]}),
+                               __builtin_bit_cast(half8_t, uint4{aq[4 * b2], aq[4 * b2 + 1], aq[4 * b2 + 2], aq[4 * b2 + 3]}), G);
             }
         }
         if (next >= total) break;
@@ -647,6 +684,35 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
         ahead.advance();
         t = walk.tile(TS);
         __syncthreads();  // everyone is done reading xt
+    }
+    if constexpr (GRAM) {  // this workgroup's partial: [34][32] = 32 Gram rows (i = k channel, j = q channel), sum q^2, sum k^2 (as k_mst_qkv16)
+        static_assert(sizeof(xt) >= sizeof(float) * 4 * 34 * 32, "the halo tile's LDS holds four waves' results at a time");
+        float* red = reinterpret_cast<float*>(xt);
+        const float sq = nq + __shfl_xor(nq, 32), sk = nk + __shfl_xor(nk, 32);
+        float sum[3] = {0.f, 0.f, 0.f};  // entries tid, tid + 512, tid + 1024 of the 1,088
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // waves 0-3, then waves 4-7
+            __syncthreads();
+            if ((wave >> 2) == half) {
+                float* mine = red + (size_t)(wave & 3) * 34 * 32;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) mine[(8 * (v / 4) + 4 * h + (v % 4)) * 32 + p] = G[v];
+                if (h == 0) { mine[32 * 32 + p] = sq; mine[33 * 32 + p] = sk; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = tid + q * kFT;
+                if (i < 34 * 32)
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) sum[q] += red[(size_t)w4 * 34 * 32 + i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int i = tid + q * kFT;
+            if (i < 34 * 32) partial[(size_t)blockIdx.x * 34 * 32 + i] = sum[q];
+        }
     }
 }
 
@@ -1010,10 +1076,34 @@ extern "C" int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpac
     hipStream_t s = avx_pick_stream(ctx, stream);
     const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
     const long cap = (long)ctx->num_cus * 3;
-    hipLaunchKernelGGL(k_mst_conv3x3_lds<6>, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (const __half*)add,
-                       (__half*)out, B, H, W);
+    hipLaunchKernelGGL((k_mst_conv3x3_lds<6, false>), dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (const __half*)add,
+                       (__half*)out, B, H, W, (const uint4*)nullptr, (float*)nullptr);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
+}
+
+// avx_mst_conv3x3_lds followed by avx_mst_qkv_gram16 (v_out = NULL) on its output, in one pass (B = 1: the Gram matrix is per frame)
+extern "C" int avx_mst_conv3x3_lds_gram(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int H, int W, int C, const void* wqk16, float* gram,
+                                        float* nq, float* nk, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack16 && out && wqk16 && gram && nq && nk && H > 0 && W > 0, "avx_mst_conv3x3_lds_gram: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32, "avx_mst_conv3x3_lds_gram: C=%d (32: the 31-channel full-resolution convs)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack16 | (uintptr_t)add | (uintptr_t)out | (uintptr_t)wqk16)) & 15u) == 0, "avx_mst_conv3x3_lds_gram: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, x != out, "avx_mst_conv3x3_lds_gram: in-place convolution is not possible");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const long total = (long)((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    const long cap = (long)ctx->num_cus * 2;  // 2 workgroups per CU: the epilogue's accumulators cost the third one's registers
+    const long blocks = total < cap ? total : cap;
+    int rc = avx_ensure_scratch(ctx, ws, sizeof(float) * (size_t)blocks * 34 * 32);
+    if (rc) return rc;
+    float* partial = (float*)ws->d_scratch;
+    hipLaunchKernelGGL((k_mst_conv3x3_lds<4, true>), dim3((unsigned)blocks), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (const __half*)add, (__half*)out, 1, H, W,
+                       (const uint4*)wqk16, partial);
+    AVX_HIP(ctx, hipGetLastError());
+    return avx_mst_qkv_final_launch(ctx, partial, (int)blocks, 1, gram, nq, nk, s);
 }
 
 extern "C" int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right,

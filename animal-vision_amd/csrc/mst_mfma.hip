@@ -962,6 +962,13 @@ int launch_ffn2(avx_ctx* ctx, const void* hid, const float* w9, const void* w2pa
 
 }  // namespace
 
+int avx_mst_qkv_final_launch(avx_ctx* ctx, const float* partial, int blocks, int heads, float* gram, float* nq, float* nk, hipStream_t s) {
+    const int tot = heads * 34 * 32;
+    hipLaunchKernelGGL(k_mst_qkv_final, dim3((tot / 4 * 64 + 255) / 256), dim3(256), 0, s, partial, blocks, heads, gram, nq, nk);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
 extern "C" {
 
 int avx_mst_qkv_gram(avx_ctx* ctx, const void* x, const void* wpack, size_t n_pix, int C, void* v_out, float* gram, float* nq, float* nk, void* stream) {

@@ -156,6 +156,7 @@ class _AvxOps:
         self._tailx = os.environ.get("AVX_MST_NO_TAILX", "") == ""  # A/B: the tail forms v = x W_v^T itself, the Gram pass writes no v
         self._down = os.environ.get("AVX_MST_NO_DOWN4X4", "") == ""  # A/B: hand-written 32 -> 64 stride-2 conv instead of MIOpen's implicit GEMM
         self._qkv16 = os.environ.get("AVX_MST_NO_QKV16", "") == ""  # A/B: the Gram pass on K = 16 MFMAs
+        self._convgram = os.environ.get("AVX_MST_NO_CONVGRAM", "") == ""  # A/B: the embedding conv carries the first block's Gram pass as its epilogue
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
         self._ctx = {}
@@ -299,6 +300,25 @@ class _AvxOps:
         for i in range(0, b, per):
             ctx._check(lib.avx_mst_down4x4(ctx._h, x[i : i + per].data_ptr(), wpack16.data_ptr(), out[i : i + per].data_ptr(), min(per, b - i), h, w, c, st))
         return out
+
+    def conv3x3_lds_gram(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor, wqk16: torch.Tensor):
+        """conv3x3_lds and, as its epilogue, the Gram pass of the MSAB block that follows (csrc/mst_fused.hip::k_mst_conv3x3_lds<., true>):
+        -> (out, gram (b, 1, 32, 32), nq (b, 32), nk (b, 32)) as qkv_gram(out, ..., want_v=False) would return them."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        x = x.contiguous()
+        add = add.contiguous() if add is not None else None
+        out = torch.empty_like(x)
+        g = torch.empty((b, 1, 32, 32), dtype=torch.float32, device=x.device)
+        nq = torch.empty((b, c), dtype=torch.float32, device=x.device)
+        nk = torch.empty((b, c), dtype=torch.float32, device=x.device)
+        ctx = self.ctx(x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        for i in range(b):
+            ctx._check(lib.avx_mst_conv3x3_lds_gram(ctx._h, x[i].data_ptr(), wpack16.data_ptr(), add[i].data_ptr() if add is not None else None, out[i].data_ptr(), h, w, c,
+                                                    wqk16.data_ptr(), g[i].data_ptr(), nq[i].data_ptr(), nk[i].data_ptr(), st))
+        return out, g, nq, nk
 
     def conv3x3_lds(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:
         """conv3x3 through an LDS halo tile (csrc/mst_fused.hip::k_mst_conv3x3_lds): every input pixel is fetched once."""
@@ -566,7 +586,7 @@ class MSTPlusPlus(torch.nn.Module):
         y = F.conv2d(x.permute(0, 3, 1, 2), w, **kw)  # NCHW view of channels-last memory: no copy
         return y.permute(0, 2, 3, 1)
 
-    def _ms_msa(self, x: torch.Tensor, p: str, heads: int) -> torch.Tensor:
+    def _ms_msa(self, x: torch.Tensor, p: str, heads: int, pre=None) -> torch.Tensor:
         b, h, w, c = x.shape  # c = heads * 32
         n = h * w
         x2 = x.reshape(b, n, c)
@@ -579,7 +599,10 @@ class MSTPlusPlus(torch.nn.Module):
                 wpk = self._prep(p + ".qkv.frag16", lambda: pack_qkv16(wqkv))
             else:
                 wpk = self._prep(p + ".qkv.frag", lambda: torch.cat([pack_fragments(wqkv[:, : 2 * c], False), pack_fragments(wqkv[:, 2 * c :], True)], 0).contiguous())
-            v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads, want_v=not tailx, k16=_AVX._qkv16)
+            if pre is not None and tailx:  # (gram, nq, nk) came with x, from the epilogue of the conv that produced it
+                v, (gram, nq, nk) = None, pre
+            else:
+                v, gram, nq, nk = _AVX.qkv_gram(x2, wpk, heads, want_v=not tailx, k16=_AVX._qkv16)
             if self.capture_attn is not None:
                 self._capture(gram, nq, nk, p, heads)
             # softmax(gram / (nk nq^T) * rescale) and M = blockdiag(attn_h^T) @ W_proj^T in one small launch, M already in fragment order
@@ -685,17 +708,28 @@ class MSTPlusPlus(torch.nn.Module):
         y = self._dw(y, p + ".fn.net.2.weight", gelu=True)
         return (y.reshape(b, h * w, 4 * c) @ w2).reshape(b, h, w, c) + x
 
-    def _msab(self, x: torch.Tensor, p: str, heads: int) -> torch.Tensor:
+    def _msab(self, x: torch.Tensor, p: str, heads: int, pre=None) -> torch.Tensor:
         """MSAB :176-186; both residual adds happen inside _ms_msa / _ffn (fused into their last launch on the GPU)."""
-        x = self._ms_msa(x, p + ".blocks.0.0", heads)
+        x = self._ms_msa(x, p + ".blocks.0.0", heads, pre)
         return self._ffn(x, p + ".blocks.0.1")
 
     def _mst(self, x: torch.Tensor, p: str) -> torch.Tensor:
-        fea = self._conv3(x, p + ".embedding.weight")
+        pre = None
+        ekey, a0 = p + ".embedding.weight", f"{p}.encoder_layers.0.0.blocks.0.0"
+        if _AVX.fused_ok(x) and x.shape[-1] == 32 and _AVX._conv_lds and _AVX._convgram and _AVX._qkv16 and _AVX._tail and _AVX._tailx:
+            # the embedding conv hands the first block its Gram matrix and column norms: the block's own pass over the conv's output is not run
+            wq = self._prep(ekey + ".frag9k16", lambda: torch.stack([pack_fragments16(self._w(ekey, (0, 1))[:, :, t // 3, t % 3].t().contiguous()) for t in range(9)]).contiguous())
+            wqkv = self._prep(a0 + ".qkv", lambda: torch.cat([self._w(a0 + ".to_q.weight", (0, 1)), self._w(a0 + ".to_k.weight", (0, 1)),
+                                                              self._w(a0 + ".to_v.weight", (0, 1))], 0).t().contiguous())
+            wqk = self._prep(a0 + ".qkv.frag16", lambda: pack_qkv16(wqkv))  # tiles 0 (q) and 1 (k) are what the epilogue reads
+            fea, g, nq, nk = _AVX.conv3x3_lds_gram(x, wq, None, wqk)
+            pre = (g, nq, nk)
+        else:
+            fea = self._conv3(x, ekey)
         skips: List[torch.Tensor] = []
         heads = 1
         for i in range(2):
-            fea = self._msab(fea, f"{p}.encoder_layers.{i}.0", heads)
+            fea = self._msab(fea, f"{p}.encoder_layers.{i}.0", heads, pre if i == 0 else None)
             skips.append(fea)
             dkey = f"{p}.encoder_layers.{i}.1.weight"
             if _AVX.fused_ok(fea) and _AVX._down and fea.shape[-1] in (32, 64) and fea.is_contiguous():  # both encoder steps: the hand-written implicit GEMM

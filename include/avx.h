@@ -365,6 +365,10 @@ int avx_mst_conv_in_u8(avx_ctx* ctx, const uint8_t* frame_hwc, int H, int W, int
 /* avx_mst_conv3x3_add through an LDS halo tile (16 x 16 pixels, every input pixel fetched once): wpack16 = the nine taps' C x C
  * weights as v_mfma_f32_32x32x16_f16 A fragments ([9][2][64][8] float16, ml/mst_plus_plus.py::pack_fragments16 per tap). */
 int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int B, int H, int W, int C, void* stream);
+/* avx_mst_conv3x3_lds with the Gram pass of the MSAB block that follows (avx_mst_qkv_gram16 with v_out = NULL on the conv's output, wqk16 = the q and k
+ * tiles of pack_qkv16) as its epilogue: the output is not read again for it.  One frame (the Gram matrix is per frame). */
+int avx_mst_conv3x3_lds_gram(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int H, int W, int C, const void* wqk16, float* gram,
+                             float* nq, float* nk, void* stream);
 /* MST.encoder_layers[i][1] at full resolution (MST_Plus_Plus.py:206-208): Conv2d(C -> 2C, 4, stride 2, padding 1, bias=False) on (B, H, W, C)
  * float16 -> (B, H/2, W/2, 2C), C = 32; wpack16 = [16 taps][2C/32][C/16] fragments (pack_fragments16 of W[:, :, ky, kx]^T). */
 int avx_mst_down4x4(avx_ctx* ctx, const void* x, const void* wpack16, void* out, int B, int H, int W, int C, void* stream);
