@@ -31,6 +31,7 @@ namespace {
 constexpr int kT = 256;  // 4 waves, each marching over its own 32-pixel tiles
 
 __device__ __forceinline__ float16_t mfma(half4_t a, half4_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float16_t mfma16(half8_t a, half8_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // lane (p = lane & 31, h = lane >> 5) loads channels [h*C/2, (h+1)*C/2) of pixel tile*32 + p; rows past n read as zero
 template <int C>
@@ -707,21 +708,32 @@ int launch_posemb(avx_ctx* ctx, const void* v, const float* w1, const float* w2,
 // With `skip` / `wskip` the decoder's 1x1 fusion conv over [up | skip] (:257) rides along: its `up` half is folded into the taps on
 // the host (W_tap @ W_up^T, a C x C/2 matrix per tap; bias likewise) and its `skip` half is a second product on the output pixel's
 // own skip row -- `up` and the concatenation never exist, and the level's input is read once instead of being written and re-read.
-template <int C>
+// GRAM (C = 64 -> 32 output channels): the Gram pass of the MSAB block that follows runs on the rounded output in registers, as in
+// csrc/mst_fused.hip::k_mst_conv3x3_lds<., true> (a lane holds channels 16 h + v of its output pixel: the K = 16 operand order of k_mst_qkv16).
+template <int C, bool GRAM = false>
 __global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ x /*[B][H][W][C]*/, const uint2* __restrict__ wpack /*[4][C/64][C/8][64]*/,
                                                      const float* __restrict__ bias /*[C/2]*/, const __half* __restrict__ skip /*[B][2H][2W][C/2] or NULL*/,
                                                      const uint2* __restrict__ wskip /*[C/64][C/16][64]*/, __half* __restrict__ out /*[B][2H][2W][C/2]*/, int B,
-                                                     int H, int W) {
+                                                     int H, int W, const uint4* __restrict__ wqk = nullptr /*[2][2][64]*/, float* __restrict__ partial = nullptr /*[blocks][34][32]*/) {
     constexpr int KS = C / 8, CO = C / 2, NT = CO / 32, KSS = CO / 8;
+    static_assert(!GRAM || C == 64, "the Gram epilogue is for the 32-channel output level");
     extern __shared__ __align__(16) unsigned char smem[];
     uint2* wl = reinterpret_cast<uint2*>(smem);
     float* bl = reinterpret_cast<float*>(smem + (size_t)4 * NT * KS * 64 * sizeof(uint2));
     uint2* wsl = reinterpret_cast<uint2*>(bl + CO);
+    uint4* wq = reinterpret_cast<uint4*>(wsl + NT * KSS * 64);  // GRAM only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 4 * NT * KS * 64; i += kT) wl[i] = wpack[i];
     for (int i = tid; i < CO; i += kT) bl[i] = bias[i];
     if (skip)
         for (int i = tid; i < NT * KSS * 64; i += kT) wsl[i] = wskip[i];
+    float16_t G;
+    float nq = 0.f, nk = 0.f;
+    if constexpr (GRAM) {
+        for (int i = tid; i < 4 * 64; i += kT) wq[i] = wqk[i];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) G[v] = 0.f;
+    }
     __syncthreads();
     const int xt = (W + 31) / 32;
     const long total = (long)B * H * xt;
@@ -770,7 +782,47 @@ __global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ 
 #pragma unroll
                 for (int v = 0; v < 16; ++v) o[v] = (_Float16)(d[v] + bl[32 * t + 16 * h + v]);
                 if (xw < W) store_tile16(out + opix * CO + 32 * t + 16 * h, o);
+                if constexpr (GRAM) {
+                    half8_t o0, o1;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) { o0[v] = xw < W ? o[v] : (_Float16)0.f; o1[v] = xw < W ? o[8 + v] : (_Float16)0.f; }  // columns past the edge take no part
+                    float16_t dq, dk;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) { dq[v] = 0.f; dk[v] = 0.f; }
+                    dq = mfma16(o0, __builtin_bit_cast(half8_t, wq[0 * 64 + lane]), dq);  // D[pixel][q channel]
+                    dq = mfma16(o1, __builtin_bit_cast(half8_t, wq[1 * 64 + lane]), dq);
+                    dk = mfma16(o0, __builtin_bit_cast(half8_t, wq[2 * 64 + lane]), dk);  // D[pixel][k channel]
+                    dk = mfma16(o1, __builtin_bit_cast(half8_t, wq[3 * 64 + lane]), dk);
+                    unsigned aq[8], ak[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        aq[j] = pack_f16(dq[2 * j], dq[2 * j + 1]);
+                        ak[j] = pack_f16(dk[2 * j], dk[2 * j + 1]);
+                        fma_mix_lo(nq, aq[j], aq[j]); fma_mix_hi(nq, aq[j], aq[j]);
+                        fma_mix_lo(nk, ak[j], ak[j]); fma_mix_hi(nk, ak[j], ak[j]);
+                    }
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2)
+                        G = mfma16(__builtin_bit_cast(half8_t, uint4{ak[4 * b2], ak[4 * b2 + 1], ak[4 * b2 + 2], ak[4 * b2 + 3]}),
+                                   __builtin_bit_cast(half8_t, uint4{aq[4 * b2], aq[4 * b2 + 1], aq[4 * b2 + 2], aq[4 * b2 + 3]}), G);
+                }
             }
+        }
+    }
+    if constexpr (GRAM) {  // this workgroup's partial: [34][32] = 32 Gram rows, sum q^2, sum k^2 (as k_mst_qkv16); the weights in LDS are dead
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        float* mine = red + (size_t)wave * 34 * 32;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) mine[(8 * (v / 4) + 4 * h + (v % 4)) * 32 + p] = G[v];
+        const float sq = nq + __shfl_xor(nq, 32), sk = nk + __shfl_xor(nk, 32);
+        if (h == 0) { mine[32 * 32 + p] = sq; mine[33 * 32 + p] = sk; }
+        __syncthreads();
+        for (int i = tid; i < 34 * 32; i += kT) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) sum += red[(size_t)w4 * 34 * 32 + i];
+            partial[(size_t)blockIdx.x * 34 * 32 + i] = sum;
         }
     }
 }
@@ -784,7 +836,6 @@ __global__ __launch_bounds__(kT) void k_mst_convt2x2(const __half* __restrict__ 
 // 0-7 and 8-15: the K order is free and k and q use the same one).  Norms: sum of squares of the float16-rounded values, taken from the
 // packed pair by v_fma_mix_f32 (no conversion back).  NW waves per workgroup: 8 at C = 128, where the 98 KB of weights in LDS allow one
 // workgroup per CU and four waves left every SIMD alone with its latencies.
-__device__ __forceinline__ float16_t mfma16(half8_t a, half8_t b, float16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 template <int C, int NW>
 __global__ __launch_bounds__(64 * NW) void k_mst_qkv16(const __half* __restrict__ x, const uint4* __restrict__ wpack /*[3*HD][C/16][64]*/, size_t n,
                                                       __half* __restrict__ v_out /*[n][C] or NULL*/, float* __restrict__ partial /*[blocks][HD][34][32]*/) {
@@ -1109,6 +1160,34 @@ int avx_mst_convt2x2_fuse(avx_ctx* ctx, const void* x, const void* wpack, const 
     if (ctx && ((((uintptr_t)skip | (uintptr_t)wskip)) & 15u)) return avx_fail(ctx, AVX_ERR_INVALID, "avx_mst_convt2x2_fuse: pointers must be 16-byte aligned");
     return convt2x2_impl(ctx, x, wpack, bias, skip, wskip, out, B, H, W, C, stream);
 }
+// avx_mst_convt2x2_fuse at C = 64 (32 output channels) followed by avx_mst_qkv_gram16 (v_out = NULL) on its output, in one pass; one frame
+int avx_mst_convt2x2_fuse_gram(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, const void* skip, const void* wskip, void* out, int H, int W, int C,
+                               const void* wqk16, float* gram, float* nq, float* nk, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack && bias && skip && wskip && out && wqk16 && gram && nq && nk && H > 0 && W > 0, "avx_mst_convt2x2_fuse_gram: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 64, "avx_mst_convt2x2_fuse_gram: C=%d (64 input channels: the decoder step back to full resolution)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack | (uintptr_t)out | (uintptr_t)skip | (uintptr_t)wskip | (uintptr_t)wqk16)) & 15u) == 0,
+                "avx_mst_convt2x2_fuse_gram: pointers must be 16-byte aligned");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    const long total = (long)H * ((W + 31) / 32);
+    long blocks = (total + 3) / 4;
+    const long cap = (long)ctx->num_cus * 4;
+    if (blocks > cap) blocks = cap;
+    int rc = avx_ensure_scratch(ctx, ws, sizeof(float) * (size_t)blocks * 34 * 32);
+    if (rc) return rc;
+    float* partial = (float*)ws->d_scratch;
+    size_t lds = (size_t)4 * 1 * 8 * 64 * sizeof(uint2) + sizeof(float) * 32 + (size_t)1 * 4 * 64 * sizeof(uint2) + (size_t)4 * 64 * sizeof(uint4);
+    if (lds < sizeof(float) * 4 * 34 * 32) lds = sizeof(float) * 4 * 34 * 32;  // the four waves' results land where the weights were
+    auto k = k_mst_convt2x2<64, true>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (const __half*)skip, (const uint2*)wskip, (__half*)out, 1, H, W,
+                       (const uint4*)wqk16, partial);
+    AVX_HIP(ctx, hipGetLastError());
+    return avx_mst_qkv_final_launch(ctx, partial, (int)blocks, 1, gram, nq, nk, s);
+}
 static int convt2x2_impl(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, const void* skip, const void* wskip, void* out, int B, int H, int W,
                          int C, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
@@ -1123,13 +1202,13 @@ static int convt2x2_impl(avx_ctx* ctx, const void* x, const void* wpack, const f
     if (blocks > cap) blocks = cap;
     if (C == 64) {
         const size_t lds = (size_t)4 * 1 * 8 * 64 * sizeof(uint2) + sizeof(float) * 32 + (size_t)1 * 4 * 64 * sizeof(uint2);
-        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mst_convt2x2<64>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (const __half*)skip,
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_mst_convt2x2<64, false>), dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (const __half*)skip,
                            (const uint2*)wskip, (__half*)out, B, H, W);
     } else {
         const size_t lds = (size_t)4 * 2 * 16 * 64 * sizeof(uint2) + sizeof(float) * 64 + (size_t)2 * 8 * 64 * sizeof(uint2);
-        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mst_convt2x2<128>, dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (const __half*)skip,
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mst_convt2x2<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_mst_convt2x2<128, false>), dim3((unsigned)blocks), dim3(kT), lds, s, (const __half*)x, (const uint2*)wpack, bias, (const __half*)skip,
                            (const uint2*)wskip, (__half*)out, B, H, W);
     }
     AVX_HIP(ctx, hipGetLastError());

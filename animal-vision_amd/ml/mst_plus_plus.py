@@ -246,6 +246,25 @@ class _AvxOps:
             ctx._check(lib.avx_mst_convt2x2_fuse(ctx._h, x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), skip.data_ptr(), wskip.data_ptr(), out.data_ptr(), b, h, w, c, st))
         return out
 
+    def convt2x2_gram(self, x: torch.Tensor, wpack: torch.Tensor, bias: torch.Tensor, skip: torch.Tensor, wskip: torch.Tensor, wqk16: torch.Tensor):
+        """convt2x2 with skip / wskip at c = 64 and, as its epilogue, the Gram pass of the MSAB block that follows (csrc/mst_mfma.hip::k_mst_convt2x2<64, true>):
+        -> (out, gram (b, 1, 32, 32), nq (b, 32), nk (b, 32))."""
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        assert c == 64 and skip.is_contiguous() and skip.shape == (b, 2 * h, 2 * w, 32)
+        x = x.contiguous()
+        out = torch.empty((b, 2 * h, 2 * w, 32), dtype=torch.float16, device=x.device)
+        g = torch.empty((b, 1, 32, 32), dtype=torch.float32, device=x.device)
+        nq = torch.empty((b, 32), dtype=torch.float32, device=x.device)
+        nk = torch.empty((b, 32), dtype=torch.float32, device=x.device)
+        ctx = self.ctx(x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        for i in range(b):
+            ctx._check(lib.avx_mst_convt2x2_fuse_gram(ctx._h, x[i].data_ptr(), wpack.data_ptr(), bias.data_ptr(), skip[i].data_ptr(), wskip.data_ptr(), out[i].data_ptr(), h, w, c,
+                                                      wqk16.data_ptr(), g[i].data_ptr(), nq[i].data_ptr(), nk[i].data_ptr(), st))
+        return out, g, nq, nk
+
     def posemb(self, v: torch.Tensor, w1_c9: torch.Tensor, w2_c9: torch.Tensor, residual: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
         """dw3x3(gelu(dw3x3(v))) + residual + bias on (b, h, w, c) float16 in one pass (csrc/mst_mfma.hip::k_mst_posemb)."""
         from .._lib import lib
@@ -751,6 +770,14 @@ class MSTPlusPlus(torch.nn.Module):
                 gb = self._prep(kw + ".upfuse.bias", lambda: (self._w(f"{p}.decoder_layers.{i}.0.bias", (0,)).float() @ wf_[:ch].float()).contiguous())
                 wbot_ = self._prep(f"{p}.fuse{i}.bot", lambda: pack_fragments(wf_[ch:].contiguous(), True))
                 heads //= 2
+                a2 = f"{p}.decoder_layers.{i}.2.blocks.0.0"
+                if ch == 32 and _AVX._convgram and _AVX._qkv16 and _AVX._tail and _AVX._tailx:  # back at full resolution: the block's Gram pass rides on this launch
+                    wqkv2 = self._prep(a2 + ".qkv", lambda: torch.cat([self._w(a2 + ".to_q.weight", (0, 1)), self._w(a2 + ".to_k.weight", (0, 1)),
+                                                                       self._w(a2 + ".to_v.weight", (0, 1))], 0).t().contiguous())
+                    wqk2 = self._prep(a2 + ".qkv.frag16", lambda: pack_qkv16(wqkv2))
+                    fea, g2, nq2, nk2 = _AVX.convt2x2_gram(fea, gt, gb, skips[1 - i].contiguous(), wbot_, wqk2)
+                    fea = self._msab(fea, f"{p}.decoder_layers.{i}.2", heads, (g2, nq2, nk2))
+                    continue
                 fea = _AVX.convt2x2(fea, gt, gb, skips[1 - i].contiguous(), wbot_)
                 fea = self._msab(fea, f"{p}.decoder_layers.{i}.2", heads)
                 continue

@@ -369,6 +369,9 @@ int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const 
  * tiles of pack_qkv16) as its epilogue: the output is not read again for it.  One frame (the Gram matrix is per frame). */
 int avx_mst_conv3x3_lds_gram(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int H, int W, int C, const void* wqk16, float* gram,
                              float* nq, float* nk, void* stream);
+/* The same for the decoder's step back to full resolution: avx_mst_convt2x2_fuse at C = 64 with the following block's Gram pass as its epilogue. */
+int avx_mst_convt2x2_fuse_gram(avx_ctx* ctx, const void* x, const void* wpack, const float* bias, const void* skip, const void* wskip, void* out, int H, int W, int C,
+                               const void* wqk16, float* gram, float* nq, float* nk, void* stream);
 /* MST.encoder_layers[i][1] at full resolution (MST_Plus_Plus.py:206-208): Conv2d(C -> 2C, 4, stride 2, padding 1, bias=False) on (B, H, W, C)
  * float16 -> (B, H/2, W/2, 2C), C = 32; wpack16 = [16 taps][2C/32][C/16] fragments (pack_fragments16 of W[:, :, ky, kx]^T). */
 int avx_mst_down4x4(avx_ctx* ctx, const void* x, const void* wpack16, void* out, int B, int H, int W, int C, void* stream);
