@@ -868,6 +868,8 @@ def hbm_bytes_per_px(stage: int = 3) -> float:
         return b
 
     per_stage = 2 * msab(32) + 2 * msab(64) / 4 + msab(128) / 16
+    if _AVX._convgram and _AVX._qkv16 and _AVX._tail and _AVX._tailx and _AVX._conv_lds and _AVX._upfuse:
+        per_stage -= 2 * 64.0          # both full-resolution blocks take their Gram matrix from the conv that produces their input: no read of x for it
     t32, t64, t128 = 64.0, 128.0 / 4, 256.0 / 16
     convs = (2 * t32) + (3 * t32)                # embedding; mapping + x
     convs += (t32 + t64) + (t64 + t128)          # two strided 4x4 convs
