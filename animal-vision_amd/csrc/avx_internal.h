@@ -86,9 +86,9 @@ int avx_ensure_scratch(avx_ctx* ctx, avx_ws* ws, size_t bytes);
 // Per-row table (row gains / streak taps) -> ws->d_row_gain: grows the buffer, uploads only when the bytes differ from the last upload.
 int avx_upload_row_table(avx_ctx* ctx, avx_ws* ws, const void* host, size_t bytes, hipStream_t s);
 int avx_const_upload(avx_ctx* ctx, avx_ws* ws, int slot, const void* host, size_t bytes, hipStream_t s, void** dev_out);
-int avx_lanes(avx_ctx* ctx, int want);
+int avx_lanes(avx_ctx* ctx, int want);  // creates the frame-lane streams on first use; returns how many exist (<= want), 0 on failure
 // mst_mfma.hip: reduce the per-workgroup Gram partials ([blocks][heads][34][32]) of a Gram pass into gram / nq / nk (k_mst_qkv_final)
-int avx_mst_qkv_final_launch(avx_ctx* ctx, const float* partial, int blocks, int heads, float* gram, float* nq, float* nk, hipStream_t s);  // creates the frame-lane streams on first use; returns how many exist (<= want), 0 on failure
+int avx_mst_qkv_final_launch(avx_ctx* ctx, const float* partial, int blocks, int heads, float* gram, float* nq, float* nk, hipStream_t s);
 
 #define AVX_HIP(ctx, call)                                                                          \
     do {                                                                                            \

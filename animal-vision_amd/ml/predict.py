@@ -71,6 +71,23 @@ class MSTPlusPlusPredictor:
         self.model = model.to(self.device).eval()
         if self.half:
             self.model = self.model.half()
+        self._prepared = False
+
+    def prepare(self) -> "MSTPlusPlusPredictor":
+        """Build every derived weight tensor of the model (packed MFMA fragments, stacked QKV, folded up-fuse weights, gather
+        indices: MSTPlusPlus._prep fills its cache lazily with torch kernels on whichever stream runs the first frame) NOW, on
+        the current stream, and wait for them: afterwards frames may be enqueued on any number of streams without one of them
+        reading a cache entry another stream is still writing.  The derived tensors do not depend on the frame size, so one
+        small frame through the same route builds them all.  Idempotent; a no-op on the CPU."""
+        if self._prepared or self.device.type != "cuda":
+            return self
+        torch = self.torch
+        with torch.cuda.device(self.device):
+            probe = torch.zeros((32, 32, 3), dtype=torch.uint8, device=self.device)
+            self.predict_device_nhwc(probe)
+            torch.cuda.synchronize(self.device)
+        self._prepared = True
+        return self
 
     def predict_device_nhwc(self, frame_dev):
         """uint8 (H,W,3) torch tensor on the device -> (H, W, 32) contiguous channels-last cube: bands 0..30 and one
@@ -139,13 +156,14 @@ class MstHoneybeeStreamOp:
 
         self.pred, self.H, self.W = predictor, H, W
         self.ctx = bee_op._ctx()
+        predictor.prepare()  # every derived weight exists and is complete before the slot streams start (they share the cache, unsynchronised)
         self._t_in = [torch.empty((H, W, 3), dtype=torch.uint8, device=predictor.device) for _ in range(depth)]
         self._t_out = [torch.empty((H, W, 3), dtype=torch.uint8, device=predictor.device) for _ in range(depth)]
         self._bufs = [(DeviceBuffer(self.ctx, a.data_ptr(), a.numel(), owned=False), DeviceBuffer(self.ctx, b.data_ptr(), b.numel(), owned=False))
                       for a, b in zip(self._t_in, self._t_out)]
         self._by_in = {bi.ptr: k for k, (bi, _) in enumerate(self._bufs)}
-        self._op32 = None
         self._bee = bee_op
+        self._op32 = None
         self._streams = {}
 
     def slot_buffers(self, k: int):
@@ -161,6 +179,15 @@ class MstHoneybeeStreamOp:
         with torch.cuda.stream(ext):
             cube = self.pred.predict_device_nhwc(self._t_in[k])
             if self._op32 is None:
-                self._op32 = self._bee.padded_clone(cube.shape[-1])
+                self._op32 = self._bee.padded_clone(cube.shape[-1])  # host-side tables only (uploaded per call through the workspace of `stream`)
             self._op32.run_device(None, d_out, 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=0, hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
             cube.record_stream(ext)
+
+    def release_streams(self):
+        """Called by pipeline.FramePipeline.close(): its slot streams are about to be destroyed, so the ExternalStream wrappers
+        (and the allocator pools torch keyed by them) must not outlive them."""
+        torch = self.pred.torch
+        if self._streams:
+            torch.cuda.synchronize(self.pred.device)
+            self._streams.clear()
+            torch.cuda.empty_cache()

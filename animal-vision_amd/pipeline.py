@@ -45,6 +45,7 @@ class StreamStats:
     pixels: int = 0
     seconds: float = 0.0
     ranks: int = 1
+    host_copy_seconds: float = 0.0  # this rank's (after reduce_stats: the slowest rank's) time in pageable <-> pinned frame copies
 
     @property
     def megapixels_per_second(self) -> float:
@@ -59,10 +60,10 @@ def reduce_stats(local: StreamStats, dist=None) -> StreamStats:
 
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     s = torch.tensor([float(local.frames), float(local.pixels)], dtype=torch.float64, device=dev)
-    t = torch.tensor([local.seconds], dtype=torch.float64, device=dev)
+    t = torch.tensor([local.seconds, local.host_copy_seconds], dtype=torch.float64, device=dev)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return StreamStats(int(s[0].item()), int(s[1].item()), float(t.item()), dist.get_world_size())
+    return StreamStats(int(s[0].item()), int(s[1].item()), float(t[0].item()), dist.get_world_size(), float(t[1].item()))
 
 
 # ---------------------------------------------------------------- device pipeline -------------------
@@ -130,6 +131,10 @@ class FramePipeline:
     def close(self):
         for s in self.slots:
             self.ctx.sync(s.stream)
+        release = getattr(self.op, "release_streams", None)  # ops that wrap the slot streams (ml/predict.py::MstHoneybeeStreamOp) drop the wrappers first
+        if release is not None:
+            release()
+        for s in self.slots:
             self.ctx.stream_destroy(s.stream)
             s.h_in.free(); s.h_out.free()
             if not self._lent:
@@ -139,8 +144,10 @@ class FramePipeline:
     def _retire(self, s: _Slot, emit: Callable[[int, np.ndarray], None]):
         if s.busy:
             self.ctx.sync(s.stream)
+            t0 = time.perf_counter()
             out = np.empty_like(s.h_out.array)
             _pcopy(out, s.h_out.array)
+            self._copy_s += time.perf_counter() - t0
             emit(s.index, out)
             s.busy = False
 
@@ -149,13 +156,16 @@ class FramePipeline:
         from ._lib import lib
 
         ctx, n, t0 = self.ctx, 0, time.perf_counter()
+        self._copy_s = 0.0
         nbytes = self.H * self.W * 3
         for k, (index, frame) in enumerate(frames):
             s = self.slots[k % self.depth]
             self._retire(s, emit)
             if frame.shape != (self.H, self.W, 3) or frame.dtype != np.uint8:
                 raise ValueError(f"frame {index}: expected uint8 {(self.H, self.W, 3)}, got {frame.dtype} {frame.shape}")
+            tc = time.perf_counter()
             _pcopy(s.h_in.array, frame)
+            self._copy_s += time.perf_counter() - tc
             ctx._check(lib.avx_memcpy_h2d(ctx._h, s.d_in.ptr, s.h_in.ptr, nbytes, s.stream))
             self.op.run_device(s.d_in, s.d_out, 1, self.H, self.W, stream=s.stream)
             if self.split_compare:
@@ -169,7 +179,7 @@ class FramePipeline:
             n += 1
         for j in range(self.depth):  # drain in submission order
             self._retire(self.slots[(n + j) % self.depth], emit)
-        return StreamStats(n, n * self.H * self.W, time.perf_counter() - t0)
+        return StreamStats(n, n * self.H * self.W, time.perf_counter() - t0, 1, self._copy_s)
 
 
 def run_video(animal_op, renderer, *, rank: int = 0, world: int = 1, depth: int = 3, split_compare: bool = False, dist=None,

@@ -158,6 +158,23 @@ def test_tapetum_bloom_and_rod_vision_vs_oracle(oracle):
             np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7)
 
 
+def test_tapetum_bloom_and_rod_vision_vs_reference_golden():
+    """The same two helpers on the device against the REFERENCE's outputs (tests/golden/bloom_rod.npz, tools/make_goldens.py::g_bloom_rod:
+    animal_utils.py:183-204, :261-305 run with the shared Gaussian injected): blur bit-exact by the shared contract, elementwise float32,
+    `power` within the device's powf."""
+    from animal_vision_amd.animals import animal_utils as au
+    from conftest import load_golden
+    from test_oracle_golden import _bloom_rod_cases
+
+    for what, f, kw, want in _bloom_rod_cases(load_golden("bloom_rod")):
+        got = (au.apply_tapetum_bloom if what == "bloom" else au.apply_rod_vision)(f.copy(), **kw)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        if what == "bloom":
+            np.testing.assert_allclose(got, want, rtol=0, atol=3e-7)
+        else:
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7)
+
+
 def test_uv_helpers_by_name_vs_oracle(oracle):
     """animal_vision_amd.uv_helpers: every function name of the reference's uv_helpers.py, NumPy in / NumPy out on the device, against
     the oracle's restatements (blurs and resizes bit-exact, elementwise float32 within the device's powf / cosf)."""

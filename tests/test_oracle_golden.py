@@ -97,6 +97,30 @@ def test_a10_helpers_bit_exact(oracle):
     assert np.array_equal(oracle.apply_s_cone_vertical_gain(x.copy(), 1.0, 0.6, band=(0.4, 0.2, 0.5), clamp=False), g["scone_band"])
 
 
+def _bloom_rod_cases(g):
+    a = g["in_a"]
+    frames = {"a": a, "b": (a * 1.3 - 0.1).astype(np.float32), "c": a.astype(np.float64)}
+    for k, f in frames.items():
+        for j, kw in enumerate(({}, dict(strength=0.3, sigma=1.5))):
+            yield "bloom", f, kw, g[f"bloom_{k}_{j}"]
+        for j, kw in enumerate(({}, dict(chroma_scale=0.15, luminance_boost=1.1, gamma=0.6))):
+            yield "rod", f, kw, g[f"rod_{k}_{j}"]
+
+
+def test_a10_bloom_and_rod_vision_vs_reference(oracle):
+    """apply_tapetum_bloom / apply_rod_vision (animal_utils.py:183-204, :261-305): the oracle's restatement against the reference's own
+    lines run by tools/make_goldens.py::g_bloom_rod with the shared Gaussian injected (cv2 itself: parity unpinned).  Bit-exact except
+    rod vision's np.power, whose float32 SIMD implementation is host dependent: 1 ulp."""
+    g = load_golden("bloom_rod")
+    for what, f, kw, want in _bloom_rod_cases(g):
+        got = (oracle.apply_tapetum_bloom if what == "bloom" else oracle.apply_rod_vision)(f.copy(), **kw)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        if what == "bloom":
+            assert np.array_equal(got, want), (what, kw, f.dtype)
+        else:
+            np.testing.assert_allclose(got, want, rtol=2.5e-7, atol=0, err_msg=str((what, kw, f.dtype)))
+
+
 def test_uv_helpers_bit_exact(oracle):
     g = load_golden("uv_helpers")
     lam31, lam81 = g["lam31"], g["lam81"]

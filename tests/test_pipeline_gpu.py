@@ -176,6 +176,42 @@ def test_uv_species_stream_through_pipeline():
             assert np.array_equal(got[i], split_compose(f, want[i]) if split else want[i]), (split, i)
 
 
+def test_mst_honeybee_stream_op_cold_start_equals_one_frame_route(oracle):
+    """The north-star stream route (ml/predict.py::MstHoneybeeStreamOp: MST++ cube -> honeybee tail, one slot stream per frame in
+    flight) from a COLD predictor: the model's derived weights (packed fragments, stacked QKV, folded up-fuse weights) are built
+    by torch kernels, and frames 1 and 2 run on other streams than frame 0 -- every frame of the stream, those included, must equal the
+    one-frame-at-a-time route `predictor.honeybee(frame)` byte for byte, and that route's tail the oracle's on the same cube.
+    A second pipeline over the same op (new slot streams; the first ones are destroyed) must give the same frames."""
+    from animal_vision_amd.animals import HoneyBee
+    from animal_vision_amd.ml import MSTPlusPlusPredictor, MstHoneybeeStreamOp
+    from animal_vision_amd.pipeline import FramePipeline
+    from animal_vision_amd.synthetic import structured_frame
+
+    H, W = 96, 160
+    frames = [structured_frame(20 + i, H, W) for i in range(7)]
+    pred = MSTPlusPlusPredictor(None, seed=0, half=True)  # cold: nothing derived yet
+    op = MstHoneybeeStreamOp(pred, HoneyBee()._operator(), H, W, depth=3)
+    got = {}
+    pipe = FramePipeline(op, H, W, depth=3)
+    pipe.run(((i, f) for i, f in enumerate(frames)), lambda i, o: got.__setitem__(i, o))
+    pipe.close()
+    assert not op._streams  # the wrappers of the destroyed slot streams are gone
+    bee = HoneyBee()._operator()
+    want = [pred.honeybee(f, bee) for f in frames]
+    for i in range(len(frames)):
+        assert np.array_equal(got[i], want[i]), i
+    # the one-frame route's tail against the oracle tail on the device's own cube (the forward pass is tests/test_mstpp.py's subject)
+    lam = np.linspace(400.0, 700.0, 31, dtype=np.float32)
+    w0, _ = oracle.honeybee_tail(*oracle.honeybee_catches(pred.predict(frames[1]), lam), np.uint8)
+    _bee_close(want[1], w0, "tail vs oracle")
+    got2 = {}
+    pipe = FramePipeline(op, H, W, depth=3)
+    pipe.run(((i, f) for i, f in enumerate(frames[:4])), lambda i, o: got2.__setitem__(i, o))
+    pipe.close()
+    for i in range(4):
+        assert np.array_equal(got2[i], want[i]), ("second pipeline", i)
+
+
 def test_baseline_config0_png_through_image_renderer(tmp_path, oracle):
     """BASELINE.json configs[0]: dog.py on one 640x480 PNG via ImageRenderer (the reference's own CPU-runnable case),
     here PNG -> get_image -> Dog().visualize on the device -> save PNG -> read back == the oracle's frame, bit for bit."""

@@ -193,6 +193,25 @@ def g_dichromat():
     save("dichromat", **out)
 
 
+def g_bloom_rod():
+    """a10's two helpers that no species calls (animal_utils.py:183-204 apply_tapetum_bloom, :261-305 apply_rod_vision; cat.py:50-59
+    names them in a commented block): the reference's own lines on seeded linear images, cv2.GaussianBlur injected as this repo's
+    OpenCV restatement (PARITY UNPINNED for the blur itself, as everywhere).  Inputs inside and outside [0, 1], float32 and float64."""
+    BLUR_MODE["mode"] = "oracle"
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:49, 0:67]
+    img = (0.5 + 0.45 * np.sin(xx / 7.0)[..., None] * np.cos(yy[..., None] / 5.0 + np.arange(3)) + 0.05 * rng.standard_normal((49, 67, 3))).astype(np.float32)
+    frames = {"a": img, "b": (img * 1.3 - 0.1).astype(np.float32), "c": img.astype(np.float64)}  # the test derives b and c from in_a the same way
+    out = {"in_a": img}
+    for k, f in frames.items():
+        for j, kw in enumerate(({}, dict(strength=0.3, sigma=1.5))):
+            out[f"bloom_{k}_{j}"] = ref_au.apply_tapetum_bloom(f.copy(), **kw)
+        for j, kw in enumerate(({}, dict(chroma_scale=0.15, luminance_boost=1.1, gamma=0.6))):
+            out[f"rod_{k}_{j}"] = ref_au.apply_rod_vision(f.copy(), **kw)
+        assert out[f"bloom_{k}_0"].dtype == f.dtype and out[f"rod_{k}_0"].dtype == f.dtype
+    save("bloom_rod", **out)
+
+
 def g_uv():
     """a12, a15-a18, a20, a21 + hsv/snow-glare on seeded planes (pure NumPy reference code)."""
     rng = np.random.default_rng(11)
@@ -416,6 +435,52 @@ def g_mstpp_large():
     save("mstpp_large", **out)
 
 
+def g_mstpp_4k():
+    """a25 at the HEADLINE size: the reference module (same seeded fp16-rounded weights as g_mstpp) on ONE structured
+    3840x2160 frame in float32 on the CPU.  Stored: three 64x64 crops of the output (float32), the 15 attention matrices
+    and the output's mean |y| / rms -- the Gram / norm sums of MS_MSA (:127-129) run over 8.3 M pixels here, four times
+    longer than anything g_mstpp_large pins.  Separate fixture (mstpp_4k.npz) so the other sizes need not be re-run."""
+    import resource
+    import time
+
+    import torch
+
+    arch = _load("_ref_mstpp", os.path.join(REF, "ml/MST_plus_plus/predict_code/architecture/MST_Plus_Plus.py"))
+    torch.manual_seed(0)
+    model = arch.MST_Plus_Plus().eval()
+    sd = {k: v.half().float() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    out = {}
+    real_softmax = torch.Tensor.softmax
+    nm, seed, (h, w), crops = "4k", 8, (2160, 3840), ((0, 0), (1000, 1900), (2096, 3776))
+    x = (structured_frame(seed, h, w).astype(np.float32) / 255.0).transpose(2, 0, 1)[None]
+    attn = []
+
+    def spy(self, *a, **k):
+        r = real_softmax(self, *a, **k)
+        attn.append(r.detach().float().numpy().copy())
+        return r
+
+    torch.Tensor.softmax = spy
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            y = model(torch.from_numpy(x)).numpy()[0]  # (31, h, w)
+    finally:
+        torch.Tensor.softmax = real_softmax
+    print(f"   {nm}: reference float32 forward {time.time() - t0:.1f} s, |y| mean {np.abs(y).mean():.4f} max {np.abs(y).max():.4f}, "
+          f"peak RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20:.1f} GiB")
+    assert len(attn) == 15
+    out[f"seed_{nm}"] = np.array([seed, h, w])
+    for i, a in enumerate(attn):
+        out[f"attn_{nm}_{i}"] = a[0]
+    out[f"crops_{nm}"] = np.array(crops)
+    for j, (cy, cx) in enumerate(crops):
+        out[f"y_{nm}_crop{j}"] = y[:, cy:cy + 64, cx:cx + 64].copy()
+    out[f"ymeanabs_{nm}"] = np.array([np.abs(y).mean(), np.sqrt((y.astype(np.float64) ** 2).mean())])
+    save("mstpp_4k", **out)
+
+
 def g_geometry():
     """8f row 1 helpers of the reference (uv_helpers.panorama_warp, classic_rgb_to_hsi_scaled, cat FOV helpers)
     driven with the injected resize/remap, plus the full Cat (cat.py:73-112 re-enacted: the file does not parse)."""
@@ -524,8 +589,8 @@ def g_uv_species():
     save("uv_species", **out)
 
 
-GENERATORS = {"srgb_tables": g_srgb_tables, "matrices": g_matrices, "dichromat": g_dichromat, "uv": g_uv,
-              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp, "mstpp_large": g_mstpp_large, "geometry": g_geometry, "mantis": g_mantis, "uv_species": g_uv_species}
+GENERATORS = {"srgb_tables": g_srgb_tables, "matrices": g_matrices, "dichromat": g_dichromat, "bloom_rod": g_bloom_rod, "uv": g_uv,
+              "lobes": g_lobes, "honeybee": g_honeybee, "mstpp": g_mstpp, "mstpp_large": g_mstpp_large, "mstpp_4k": g_mstpp_4k, "geometry": g_geometry, "mantis": g_mantis, "uv_species": g_uv_species}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
