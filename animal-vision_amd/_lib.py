@@ -266,6 +266,7 @@ _SIGS = {
     "avx_mst_attn_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_attn_tail_x": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_ffn_fused": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "avx_mst_ffn_fused_mx": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_dw_gemm_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_dwconv3x3_nhwc_add": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "avx_dwconv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

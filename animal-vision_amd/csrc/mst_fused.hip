@@ -33,6 +33,7 @@
 
 namespace {
 
+typedef float float4_t __attribute__((ext_vector_type(4)));
 constexpr int kFT = 512;              // 8 waves
 constexpr int TS = 16;                // output tile side
 constexpr int HS = TS + 2;            // halo tile side
@@ -70,11 +71,23 @@ struct TileWalk {
     __device__ __forceinline__ Tile tile(int side) const { return Tile{xi * side, yi * side, b}; }
 };
 
-template <int C, int HPASS, int MINW>
+// DWM (round 3): the depthwise 3x3 conv runs on the MATRIX pipe.  A depthwise conv contracts over taps only, so as a matrix product its weight
+// operand is diagonal in the channels; the waste is bounded by letting the 16 rows of a v_mfma_f32_16x16x32_f16 result be 8 channels (one
+// "octet": what a lane's 16-byte LDS read holds) x 2 vertically adjacent output rows: the two rows share input rows, so the 3 x 3 taps of both
+// are covered by 4 input rows x 3 column shifts = 12 K-slots of 8 channels = THREE MFMAs per 8 channels x 2 rows x 16 pixels (256 outputs;
+// 36 v_fma_mix_f32 per lane before).  Slot q = lane / 16 of MFMA i carries input row r = q, column shift i; the weight fragment (dwpack, built
+// on the host: ml/mst_plus_plus.py::pack_dw_mfma) of lane (m = 8 s + c, q) holds w[c][r - s][i] at element c when 0 <= r - s <= 2, zero elsewhere.
+// Phase 2 becomes 2a + 2b: (2a) wave w owns octet w of the pass (8 w + 64 o2 ... for 128-channel passes two of them), its three weight
+// fragments stay in registers, and it walks the 8 row pairs of the tile: 3 LDS reads, 3 MFMAs, GELU of the lane's 4 results, one 8-byte LDS
+// store -- IN PLACE: output rows 2p, 2p + 1 land in halo rows 2p, 2p + 1 (columns 0 ... 15), which no later row pair of this octet reads and
+// no other wave touches (its bytes are another octet's); (2b) after a barrier the second GEMM reads its B fragments from that map with the
+// same 16-byte reads the depthwise conv used to issue.  One ADDRESS register serves all of 2a (row pair, column shift and octet are
+// immediates), the taps need no LDS, and the vector unit is left with the GELUs.
+template <int C, int HPASS, int MINW, bool DWM>
 __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, const uint4* __restrict__ w1pack /*[4C/32][C/16][64]*/, const __half* __restrict__ taps /*[9][4C]*/,
                                                           const uint4* __restrict__ w2pack /*[C/32][4C/16][64]*/, __half* __restrict__ out /*[B][H][W][C], != x*/, int B,
-                                                          int H, int W) {
+                                                          int H, int W, const uint4* __restrict__ dwpack /*[4C/8][3][64], DWM only*/) {
     constexpr int HID = 4 * C, NPASS = HID / HPASS, KS1 = C / 16, KS2 = HPASS / 16, NT = C / 32, YPITCH = C * 2 + 16, LNV = C / 16;
     constexpr int HPITCH = HPASS * 2 + 16, RPITCH = (HS * HPITCH + 255) / 256 * 256, NCT = HPASS / 32;  // channel tiles of 32 per pass
     static_assert(C == 32 || C == 64 || C == 128, "31-, 62- or 124-channel blocks (stored 32 / 64 / 128 wide)");
@@ -85,7 +98,8 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     __half* tapl = reinterpret_cast<__half*>(ht + (size_t)HS * RPITCH);  // [9][HID]
     float* gl = reinterpret_cast<float*>(tapl + 9 * HID);            // [C] gamma, [C] beta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
-    for (int i = tid; i < 9 * HID; i += kFT) tapl[i] = taps[i];
+    if constexpr (!DWM)
+        for (int i = tid; i < 9 * HID; i += kFT) tapl[i] = taps[i];
     for (int i = tid; i < C; i += kFT) { gl[i] = gamma[i]; gl[C + i] = beta[i]; }
     const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
     const long total = (long)B * ty * tx;
@@ -202,6 +216,13 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; ++pass) {
             __syncthreads();  // yt complete (pass 0) / ht no longer read by the previous pass's phase 2
+            half8_t af[DWM ? HPASS / 64 : 1][3];  // DWM: this wave's depthwise weight fragments of the pass (in flight during phase 1)
+            if constexpr (DWM) {
+#pragma unroll
+                for (int o2 = 0; o2 < HPASS / 64; ++o2)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) af[o2][i] = __builtin_bit_cast(half8_t, dwpack[((size_t)(pass * (HPASS / 8) + 8 * o2 + wave) * 3 + i) * 64 + lane]);
+            }
             // ---- phase 1: hidden = GELU(W1 y) for hidden channels [HPASS pass + 32 ct, + 32), ct = wave % NCT, pixel groups wave / NCT, + 8 / NCT, ... ----
             {
                 const int ct = wave % NCT;
@@ -240,6 +261,35 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             __syncthreads();  // ht complete
             if (PREFETCH && pass == NPASS - 1 && next < total) fetch(tile_of(next));  // next tile's raw rows: in flight during phase 2
             if constexpr (NPASS > 1) load_w2(pass);
+            if constexpr (DWM) {
+                // ---- phase 2a: depthwise 3x3 on the matrix pipe + GELU, in place in the hidden tile (see the kernel's head comment) ----
+                constexpr int NOCT = HPASS / 64;  // octets of this pass per wave
+                const int n16 = lane & 15, q = lane >> 4;
+                unsigned char* rbase = ht + (size_t)q * RPITCH + (size_t)n16 * HPITCH + 16 * wave;                               // + 2p RPITCH + i HPITCH + 128 o2
+                unsigned char* wbase = ht + (size_t)(q >> 1) * RPITCH + (size_t)n16 * HPITCH + 16 * wave + 8 * (q & 1);        // + 2p RPITCH + 128 o2
+#pragma unroll
+                for (int o2 = 0; o2 < NOCT; ++o2) {
+#pragma unroll
+                    for (int pr = 0; pr < TS / 2; ++pr) {
+                        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 128 * o2)), acc, 0, 0, 0);
+                        const float2_t g0 = gelu_fast2(float2_t{acc[0], acc[1]}), g1 = gelu_fast2(float2_t{acc[2], acc[3]});
+                        *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 128 * o2) = uint2{pack_f16(g0.x, g0.y), pack_f16(g1.x, g1.y)};
+                    }
+                }
+                __syncthreads();  // the GELU'd depthwise map is complete
+                // ---- phase 2b: second GEMM, this wave's 32 output pixels (rows 2 wave, 2 wave + 1), B fragments from the map ----
+                const int r = 2 * wave + (p >> 4), c = p & 15;
+                const unsigned char* zb = ht + (size_t)r * RPITCH + (size_t)c * HPITCH + 16 * h;
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) {
+                    const half8_t bf = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(zb + 32 * s));
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) D[n] = mfma16(w2f[n * KS2 + s], bf, D[n]);
+                }
+            } else
             // ---- phase 2: depthwise 3x3 + GELU + W2, this wave's 32 output pixels (rows 2 wave, 2 wave + 1) ----
             {
                 const int r = 2 * wave + (p >> 4), c = p & 15;
@@ -1006,10 +1056,27 @@ __global__ __launch_bounds__(256) void k_mst_conv_in_u8_mfma(const uint8_t* __re
 
 }  // namespace
 
+static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid, const void* dwpack,
+                            const void* w2pack, void* out, int B, int H, int W, int C, void* stream);
+
 extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
                                  const void* w2pack, void* out, int B, int H, int W, int C, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
-    AVX_REQUIRE(ctx, x && gamma && beta && w1pack && taps_9xhid && w2pack && out && B > 0 && H > 0 && W > 0, "avx_mst_ffn_fused: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, taps_9xhid, "avx_mst_ffn_fused: NULL pointer");
+    return ffn_fused_launch(ctx, x, gamma, beta, eps, w1pack, taps_9xhid, nullptr, w2pack, out, B, H, W, C, stream);
+}
+
+// The same with the depthwise conv on the matrix pipe: dwpack = its weights as v_mfma_f32_16x16x32_f16 A fragments (ml/mst_plus_plus.py::pack_dw_mfma).
+extern "C" int avx_mst_ffn_fused_mx(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* dwpack,
+                                    const void* w2pack, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, dwpack && (((uintptr_t)dwpack) & 15u) == 0, "avx_mst_ffn_fused_mx: dwpack NULL or not 16-byte aligned");
+    return ffn_fused_launch(ctx, x, gamma, beta, eps, w1pack, nullptr, dwpack, w2pack, out, B, H, W, C, stream);
+}
+
+static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid, const void* dwpack,
+                            const void* w2pack, void* out, int B, int H, int W, int C, void* stream) {
+    AVX_REQUIRE(ctx, x && gamma && beta && w1pack && w2pack && out && B > 0 && H > 0 && W > 0, "avx_mst_ffn_fused: NULL pointer or empty tensor");
     AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_ffn_fused: C=%d (32, 64 or 128: 31-channel groups stored 32 wide)", C);
     AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)w1pack | (uintptr_t)w2pack | (uintptr_t)out | (uintptr_t)taps_9xhid)) & 15u) == 0,
                 "avx_mst_ffn_fused: pointers must be 16-byte aligned");
@@ -1023,15 +1090,17 @@ extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma
     const long cap = (long)ctx->num_cus * (small ? 2 : 1);
     const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * rpitch + (size_t)9 * 4 * C * 2 + sizeof(float) * 2 * C;
     const dim3 grid((unsigned)(total < cap ? total : cap));
-#define AVX_FFN(CV, HP, MW)                                                                                                                      \
+#define AVX_FFN1(CV, HP, MW, DW)                                                                                                                 \
     {                                                                                                                                            \
-        auto k = k_mst_ffn_fused<CV, HP, MW>;                                                                                                    \
+        auto k = k_mst_ffn_fused<CV, HP, MW, DW>;                                                                                                \
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
         hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid,      \
-                           (const uint4*)w2pack, (__half*)out, B, H, W);                                                                         \
+                           (const uint4*)w2pack, (__half*)out, B, H, W, (const uint4*)dwpack);                                                   \
     }
+#define AVX_FFN(CV, HP, MW) { if (dwpack) AVX_FFN1(CV, HP, MW, true) else AVX_FFN1(CV, HP, MW, false) }
     if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2) else if (C == 64) AVX_FFN(64, 128, 2) else AVX_FFN(128, 64, 2)
 #undef AVX_FFN
+#undef AVX_FFN1
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -132,6 +132,28 @@ def pack_qkv16(wqkv: torch.Tensor) -> torch.Tensor:
     return torch.take(wqkv.contiguous(), idx)
 
 
+def pack_dw_mfma(w: torch.Tensor) -> torch.Tensor:
+    """(Ch, 1, 3, 3) float16 depthwise 3x3 weight -> the A fragments of csrc/mst_fused.hip's matrix-pipe depthwise conv:
+    [Ch/8 octets][3 column shifts][64 lanes][8].  The 16 result rows of a v_mfma_f32_16x16x32_f16 are m = 8 s + c: channel c of the octet
+    at output row s (two vertically adjacent rows); K slot q = lane // 16 of MFMA i carries input row r = q (of the four rows the pair
+    needs) shifted by i columns, element j = channel j of the octet.  The weight matrix is diagonal in the channels: lane (m, q) holds
+    w[8 o + c][r - s][i] at element c when 0 <= r - s <= 2 and zeros elsewhere."""
+    ch = w.shape[0]
+    assert ch % 8 == 0 and tuple(w.shape[1:]) == (1, 3, 3)
+    dev = w.device
+    lane = torch.arange(64, device=dev)
+    m, q = lane % 16, lane // 16
+    s_, c = m // 8, m % 8
+    dy = q - s_                                                     # (64,)
+    ok = (dy >= 0) & (dy <= 2)
+    w8 = w.reshape(ch // 8, 8, 3, 3)                                # [o][c][dy][dx]
+    vals = w8[:, c, dy.clamp(0, 2), :]                              # (O, 64, 3): [o][lane][dx]
+    vals = torch.where(ok[None, :, None], vals, torch.zeros_like(vals))
+    out = torch.zeros((ch // 8, 3, 64, 8), dtype=w.dtype, device=dev)
+    out[:, :, lane, c] = vals.permute(0, 2, 1)                      # element c of lane
+    return out.contiguous()
+
+
 def pack_down4x4(w: torch.Tensor) -> torch.Tensor:
     """(Cout, Cin, 4, 4) float16 stride-2 conv weight -> [16 taps][Cout/32][Cin/16][64][8] fragments (tap = 4 ky + kx), the A operands
     of csrc/mst_fused.hip::k_mst_down4x4_dma."""
@@ -158,6 +180,7 @@ class _AvxOps:
         self._qkv16 = os.environ.get("AVX_MST_NO_QKV16", "") == ""  # A/B: the Gram pass on K = 16 MFMAs
         self._convgram = os.environ.get("AVX_MST_NO_CONVGRAM", "") == ""  # A/B: the embedding conv carries the first block's Gram pass as its epilogue
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
+        self._dwmx = os.environ.get("AVX_MST_NO_DW_MFMA", "") == ""  # A/B: depthwise 3x3 convs on the matrix pipe (round 3)
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
         self._ctx = {}
 
@@ -417,16 +440,22 @@ class _AvxOps:
         return out
 
     def ffn_fused(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1p: torch.Tensor, taps: torch.Tensor, w2p: torch.Tensor,
-                  eps: float = 1e-5) -> torch.Tensor:
-        """x + FeedForward(LayerNorm(x)) on (b, h, w, c) float16 in ONE kernel, the 4c hidden tile in LDS (csrc/mst_fused.hip)."""
+                  eps: float = 1e-5, dwpack: torch.Tensor = None) -> torch.Tensor:
+        """x + FeedForward(LayerNorm(x)) on (b, h, w, c) float16 in ONE kernel, the 4c hidden tile in LDS (csrc/mst_fused.hip).
+        dwpack (pack_dw_mfma): the depthwise conv runs on the matrix pipe (avx_mst_ffn_fused_mx); else taps ([9][4c]) on the vector unit."""
         from .._lib import lib
 
         b, h, w, c = x.shape
         x = x.contiguous()
         out = torch.empty_like(x)
         ctx = self.ctx(x.device)
-        ctx._check(lib.avx_mst_ffn_fused(ctx._h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w1p.data_ptr(), taps.data_ptr(), w2p.data_ptr(),
-                                         out.data_ptr(), b, h, w, c, torch.cuda.current_stream(x.device).cuda_stream))
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        if dwpack is not None:
+            ctx._check(lib.avx_mst_ffn_fused_mx(ctx._h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w1p.data_ptr(), dwpack.data_ptr(), w2p.data_ptr(),
+                                                out.data_ptr(), b, h, w, c, st))
+        else:
+            ctx._check(lib.avx_mst_ffn_fused(ctx._h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w1p.data_ptr(), taps.data_ptr(), w2p.data_ptr(),
+                                             out.data_ptr(), b, h, w, c, st))
         return out
 
     def dw_gemm_add(self, hidden: torch.Tensor, w_c9: torch.Tensor, w2pack: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -703,6 +732,8 @@ class MSTPlusPlus(torch.nn.Module):
             w1q = self._prep(p + ".w1.frag16", lambda: pack_fragments16(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous()))
             w2q = self._prep(p + ".w2.frag16", lambda: pack_fragments16(w2))
             key = p + ".fn.net.2.weight"
+            if _AVX._dwmx:
+                return _AVX.ffn_fused(x, g32, b32, w1q, None, w2q, dwpack=self._prep(key + ".dwmx", lambda: pack_dw_mfma(self._w(key, (0,)))))
             t9 = self._prep(key + ".t9h", lambda: self._w(key, (0,)).reshape(4 * c, 9).t().contiguous())  # [9][4c], tap-major, the model's own float16 values
             return _AVX.ffn_fused(x, g32, b32, w1q, t9, w2q)
         if _AVX.fused_ok(x):  # LayerNorm -> 1x1 conv -> GELU on the matrix cores, the hidden tensor is written once

@@ -398,6 +398,12 @@ int avx_mst_attn_tail_x(avx_ctx* ctx, const void* x, const void* wvpack16, const
  * tap-major [9][4C].  out must not alias x (tiles read their neighbours' rows). */
 int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
                       const void* w2pack, void* out, int B, int H, int W, int C, void* stream);
+/* The same with the depthwise 3x3 conv (MST_Plus_Plus.py:151) on the matrix pipe: a result tile of v_mfma_f32_16x16x32_f16 is 8 channels x
+ * 2 vertically adjacent output rows x 16 pixels, the K slots are 4 input rows x 3 column shifts of those 8 channels (three MFMAs per 256
+ * outputs).  dwpack: the depthwise weights as A fragments, [4C/8 octets][3 shifts][64 lanes][8] float16
+ * (ml/mst_plus_plus.py::pack_dw_mfma).  Same result up to the summation order of the nine taps (float32 accumulation in both). */
+int avx_mst_ffn_fused_mx(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* dwpack,
+                         const void* w2pack, void* out, int B, int H, int W, int C, void* stream);
 
 /* out = [add +] a @ W [+ a2 @ W2] for (rows x C) float16 tensors and C x C weights in fragment order (out may alias
  * add; a2 / W2 and add may be NULL): MS_MSA's `proj(attn @ v)` collapsed to one matrix per frame (:132-135)

@@ -12,7 +12,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 // KIND 0: 16x16x32, 1: 32x32x16, 2: 4x4x4 (16 blocks), 3: no MFMA (vector stream only).  NV packed FMAs follow every MFMA.
-template <int KIND, int NV>
+template <int KIND, int NV, int VOP = 0>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     extern __shared__ float lds[];
     constexpr int NACC = 4;
@@ -39,7 +39,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             if (KIND == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc16[m & 1]) : "v"(a), "v"(b));
             if (KIND == 2) asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+v"(acc4[m]) : "v"(a4), "v"(b4));
 #pragma unroll
-            for (int v = 0; v < NV; ++v) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[v % 8]) : "v"(p[(v + 1) % 8]), "v"(p[(v + 2) % 8]));
+            for (int v = 0; v < NV; ++v) {
+                if (VOP == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[v % 8]) : "v"(p[(v + 1) % 8]), "v"(p[(v + 2) % 8]));
+                if (VOP == 1) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(p[v % 8].x) : "v"(p[(v + 1) % 8].x), "v"(p[(v + 2) % 8].x));
+                if (VOP == 2) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(p[v % 8].x) : "v"(p[(v + 1) % 8].x), "v"(p[(v + 2) % 8].x));
+                if (VOP == 3) asm volatile("v_fma_mix_f32 %0, %1, %2, %0" : "+v"(p[v % 8].x) : "v"(p[(v + 1) % 8].x), "v"(p[(v + 2) % 8].x));
+                if (VOP == 4) asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(p[v % 8]) : "v"(p[(v + 1) % 8]), "v"(p[(v + 2) % 8]));
+                if (VOP == 5) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(p[v % 8].x) : "v"(p[(v + 1) % 8].x), "v"(p[(v + 2) % 8].x));
+                if (VOP == 6) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "+v"(p[v % 8].x) : "v"(p[(v + 1) % 8].x), "v"(p[(v + 2) % 8].x));
+                if (VOP == 7) asm volatile("v_pk_add_f32 %0, %1, %2" : "+v"(p[v % 8]) : "v"(p[(v + 1) % 8]), "v"(p[(v + 2) % 8]));
+                if (VOP == 8) asm volatile("v_mul_f32 %0, %1, %2" : "+v"(p[v % 8].x) : "v"(p[(v + 1) % 8].x), "v"(p[(v + 2) % 8].x));
+            }
         }
     }
     float s = 0;
@@ -94,6 +104,22 @@ int main() {
     ROW("mfma 32x32x16 f16", 1)
     ROW("mfma 4x4x4 16b f16", 2)
     ROW("no mfma (vector only)", 3)
+#define ROW2(name, KIND, VOP)                                                                                                                 \
+    for (int w : {2, 4}) {                                                                                                                    \
+        printf("%-34s w%d:", name, w);                                                                                                        \
+        printf("  nv2 %6.2f  nv4 %6.2f  nv8 %6.2f  nv16 %6.2f  nv24 %6.2f\n", run(k<KIND, 2, VOP>, d, w), run(k<KIND, 4, VOP>, d, w),         \
+               run(k<KIND, 8, VOP>, d, w), run(k<KIND, 16, VOP>, d, w), run(k<KIND, 24, VOP>, d, w));                                         \
+    }
+    printf("other vector instructions beside v_mfma_f32_16x16x32_f16 (KIND 0) and alone (KIND 3)\n");
+    ROW2("16x16x32 + v_fma_f32", 0, 1) ROW2("alone  v_fma_f32", 3, 1)
+    ROW2("16x16x32 + v_pk_fma_f16", 0, 2) ROW2("alone  v_pk_fma_f16", 3, 2)
+    ROW2("16x16x32 + v_fma_mix_f32", 0, 3) ROW2("alone  v_fma_mix_f32", 3, 3)
+    ROW2("16x16x32 + v_pk_mul_f32", 0, 4) ROW2("alone  v_pk_mul_f32", 3, 4)
+    ROW2("16x16x32 + v_med3_f32", 0, 5) ROW2("alone  v_med3_f32", 3, 5)
+    ROW2("16x16x32 + v_cvt_pk_f16_f32", 0, 6) ROW2("alone  v_cvt_pk_f16_f32", 3, 6)
+    ROW2("16x16x32 + v_pk_add_f32", 0, 7) ROW2("alone  v_pk_add_f32", 3, 7)
+    ROW2("16x16x32 + v_mul_f32", 0, 8) ROW2("alone  v_mul_f32", 3, 8)
+    ROW2("32x32x16 + v_fma_f32", 1, 1) ROW2("32x32x16 + v_pk_fma_f16", 1, 2)
     float hx[8] = {-10.f, -4.f, -1.f, 0.f, 1.f, 3.9f, 4.f, 10.f}, hy[16], *dx, *dy;
     hipMalloc(&dx, sizeof(hx)); hipMalloc(&dy, sizeof(hy));
     hipMemcpy(dx, hx, sizeof(hx), hipMemcpyHostToDevice);
