@@ -263,6 +263,8 @@ _SIGS = {
     "avx_mst_conv3x3_lds_gram": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "avx_mst_convt2x2_fuse_gram": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "avx_mst_attn_pack16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "avx_mst_attn_pack_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "avx_mst_attn_tail_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_attn_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_attn_tail_x": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_ffn_fused": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -26,6 +26,7 @@
 // by exactly this arithmetic; the forward pass is held to the reference's float32 output, tests/test_mstpp.py).
 #include <hip/hip_fp16.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "avx_internal.h"
@@ -83,11 +84,11 @@ struct TileWalk {
 // no other wave touches (its bytes are another octet's); (2b) after a barrier the second GEMM reads its B fragments from that map with the
 // same 16-byte reads the depthwise conv used to issue.  One ADDRESS register serves all of 2a (row pair, column shift and octet are
 // immediates), the taps need no LDS, and the vector unit is left with the GELUs.
-template <int C, int HPASS, int MINW, bool DWM>
+template <int C, int HPASS, int MINW, bool DWM, bool STAMP = false>
 __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, const uint4* __restrict__ w1pack /*[4C/32][C/16][64]*/, const __half* __restrict__ taps /*[9][4C]*/,
                                                           const uint4* __restrict__ w2pack /*[C/32][4C/16][64]*/, __half* __restrict__ out /*[B][H][W][C], != x*/, int B,
-                                                          int H, int W, const uint4* __restrict__ dwpack /*[4C/8][3][64], DWM only*/) {
+                                                          int H, int W, const uint4* __restrict__ dwpack /*[4C/8][3][64], DWM only*/, unsigned long long* __restrict__ stamps /*STAMP: [blocks][8 waves][8 segments] cycles*/) {
     constexpr int HID = 4 * C, NPASS = HID / HPASS, KS1 = C / 16, KS2 = HPASS / 16, NT = C / 32, YPITCH = C * 2 + 16, LNV = C / 16;
     constexpr int HPITCH = HPASS * 2 + 16, RPITCH = (HS * HPITCH + 255) / 256 * 256, NCT = HPASS / 32;  // channel tiles of 32 per pass
     static_assert(C == 32 || C == 64 || C == 128, "31-, 62- or 124-channel blocks (stored 32 / 64 / 128 wide)");
@@ -98,6 +99,17 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     __half* tapl = reinterpret_cast<__half*>(ht + (size_t)HS * RPITCH);  // [9][HID]
     float* gl = reinterpret_cast<float*>(tapl + 9 * HID);            // [C] gamma, [C] beta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    // STAMP (diagnostic instantiation, AVX_FFN_STAMPS=1): cycles this wave spends per segment -- 0 top barrier, 1 phase 1, 2 barrier, 3 phase 2a (or the
+    // whole vector-unit phase 2), 4 barrier, 5 phase 2b, 6 epilogue, 7 LayerNorm + fetch
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            seg[k] += now - tlast;
+            tlast = now;
+        }
+    };
+    if constexpr (STAMP) tlast = __builtin_readcyclecounter();
     if constexpr (!DWM)
         for (int i = tid; i < 9 * HID; i += kFT) tapl[i] = taps[i];
     for (int i = tid; i < C; i += kFT) { gl[i] = gamma[i]; gl[C + i] = beta[i]; }
@@ -189,6 +201,15 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             for (int s = 0; s < KS2; ++s) w2f[n * KS2 + s] = __builtin_bit_cast(half8_t, w2pack[((size_t)n * (HID / 16) + pass * KS2 + s) * 64 + lane]);
     };
     if constexpr (NPASS == 1) load_w2(0);
+    // the first GEMM's A fragments of this wave's channel tile (wave % NCT of the pass): requested at the END of the previous pass's phase 1, so
+    // the next phase 1 never waits for them (they were loaded at its top before: an L2 round trip per pass in front of the MFMAs)
+    half8_t w1f[KS1];
+    auto load_w1 = [&](int pass) {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) w1f[s] = __builtin_bit_cast(half8_t, w1pack[((size_t)(pass * NCT + wave % NCT) * KS1 + s) * 64 + lane]);
+    };
+    constexpr bool W1AHEAD = DWM && C == 64 && NPASS > 1;  // C = 32 / 128: the fragments' registers are needed in between (they would spill): loaded at the top of phase 1
+    if constexpr (W1AHEAD) load_w1(0);
     // phase 1 items of this wave (pixel groups wave / NCT + j * 8 / NCT): where a lane's pixel sits in the hidden tile and in the image
     constexpr int NITEM = (NGRP + 8 / NCT - 1) / (8 / NCT);
     int p1_g[NITEM], p1_dst[NITEM], p1_dy[NITEM], p1_dx[NITEM];
@@ -215,7 +236,9 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             for (int v = 0; v < 16; ++v) D[n][v] = 0.f;
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; ++pass) {
+            stamp(pass == 0 ? 7 : 5);
             __syncthreads();  // yt complete (pass 0) / ht no longer read by the previous pass's phase 2
+            stamp(0);
             half8_t af[DWM ? HPASS / 64 : 1][3];  // DWM: this wave's depthwise weight fragments of the pass (in flight during phase 1)
             if constexpr (DWM) {
 #pragma unroll
@@ -226,9 +249,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             // ---- phase 1: hidden = GELU(W1 y) for hidden channels [HPASS pass + 32 ct, + 32), ct = wave % NCT, pixel groups wave / NCT, + 8 / NCT, ... ----
             {
                 const int ct = wave % NCT;
-                half8_t w1f[KS1];
-#pragma unroll
-                for (int s = 0; s < KS1; ++s) w1f[s] = __builtin_bit_cast(half8_t, w1pack[((size_t)(pass * NCT + ct) * KS1 + s) * 64 + lane]);
+                if constexpr (!W1AHEAD) load_w1(pass);
 #pragma unroll
                 for (int j = 0; j < NITEM; ++j) {
                     if (p1_g[j] < 0) continue;  // wave-uniform
@@ -258,7 +279,9 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                     }
                 }
             }
+            stamp(1);
             __syncthreads();  // ht complete
+            stamp(2);
             if (PREFETCH && pass == NPASS - 1 && next < total) fetch(tile_of(next));  // next tile's raw rows: in flight during phase 2
             if constexpr (NPASS > 1) load_w2(pass);
             if constexpr (DWM) {
@@ -267,19 +290,30 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 const int n16 = lane & 15, q = lane >> 4;
                 unsigned char* rbase = ht + (size_t)q * RPITCH + (size_t)n16 * HPITCH + 16 * wave;                               // + 2p RPITCH + i HPITCH + 128 o2
                 unsigned char* wbase = ht + (size_t)(q >> 1) * RPITCH + (size_t)n16 * HPITCH + 16 * wave + 8 * (q & 1);        // + 2p RPITCH + 128 o2
+                // The map is read and written in place, so the compiler keeps every LDS read behind the previous unit's store (it cannot tell the bytes apart):
+                // the reads of unit u + 1 are therefore issued by hand right behind unit u's MFMAs, in front of its GELU and store -- one LDS round trip per unit less on the wave's clock.
+                constexpr int NU = NOCT * (TS / 2);
+                uint4 bq[3];
+                auto rd = [&](int u) {
+                    const int o2 = u / (TS / 2), pr = u % (TS / 2);
 #pragma unroll
-                for (int o2 = 0; o2 < NOCT; ++o2) {
+                    for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 128 * o2);
+                };
+                rd(0);
 #pragma unroll
-                    for (int pr = 0; pr < TS / 2; ++pr) {
-                        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < NU; ++u) {
+                    const int o2 = u / (TS / 2), pr = u % (TS / 2);
+                    float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 128 * o2)), acc, 0, 0, 0);
-                        const float2_t g0 = gelu_fast2(float2_t{acc[0], acc[1]}), g1 = gelu_fast2(float2_t{acc[2], acc[3]});
-                        *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 128 * o2) = uint2{pack_f16(g0.x, g0.y), pack_f16(g1.x, g1.y)};
-                    }
+                    for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
+                    if (u + 1 < NU) rd(u + 1);  // the MFMAs have taken their operands: the same registers receive the next unit's while this one's GELU runs
+                    const float2_t g0 = gelu_fast2(float2_t{acc[0], acc[1]}), g1 = gelu_fast2(float2_t{acc[2], acc[3]});
+                    *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 128 * o2) = uint2{pack_f16(g0.x, g0.y), pack_f16(g1.x, g1.y)};
                 }
+                stamp(3);
                 __syncthreads();  // the GELU'd depthwise map is complete
+                stamp(4);
+                if constexpr (W1AHEAD) load_w1(pass + 1 < NPASS ? pass + 1 : 0);  // dead since phase 1; requested here (not there: 8 live registers through phase 2a spill) -- phase 2b and the barrier cover the trip
                 // ---- phase 2b: second GEMM, this wave's 32 output pixels (rows 2 wave, 2 wave + 1), B fragments from the map ----
                 const int r = 2 * wave + (p >> 4), c = p & 15;
                 const unsigned char* zb = ht + (size_t)r * RPITCH + (size_t)c * HPITCH + 16 * h;
@@ -322,6 +356,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 }
             }
         }
+        stamp(5);
         // ---- epilogue: + x (the block's residual, :184), float16, 32 contiguous bytes per lane and output tile ----
         {
             const int yo = t.y0 + 2 * wave + (p >> 4), xo = t.x0 + (p & 15);
@@ -343,11 +378,17 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 }
             }
         }
+        stamp(6);
         if (next >= total) break;
         tile = next;
         t = tile_of(tile);
         if (!PREFETCH) fetch(t);
         layernorm();  // yt is free: every wave is past the last pass's first barrier, after which nobody reads it
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && stamps)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) stamps[((size_t)blockIdx.x * 8 + wave) * 8 + k] = seg[k];
     }
 }
 
@@ -601,6 +642,302 @@ int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpa
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), lds, s, (const __half*)v, (const __half*)x, (const uint4*)mpack,
                        (const __half*)taps1, (const __half*)taps2, bias, (__half*)out, B, H, W, (const uint4*)wvpack);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+
+// ---- attention tail with BOTH depthwise convs and the projection on the matrix pipe (round 3) ----------------------------------------------
+// out = dw2(gelu(dw1(v))) + v @ M + bias + x with v = float16(x W_v^T) formed on the tile's halo (MS_MSA :96, :104-106, :132-137; MSAB :183), as
+// k_mst_attn_tail above, but the vector unit is left with the GELU and the final sums:
+//   * a depthwise 3x3 conv is three v_mfma_f32_16x16x32_f16 per "unit" = 8 channels (an octet: one 16-byte LDS read) x 2 vertically adjacent
+//     output rows x 16 pixels: the K slots are the 4 input rows the row pair needs x 3 column shifts, the weight fragment is diagonal in the
+//     channels (pack_dw_mfma; see k_mst_ffn_fused);
+//   * v @ M lands in the SAME accumulator: its fragment is block diagonal in the two rows -- slot q of step t carries row q & 1, input
+//     channels 16 t + 8 (q >> 1) ... + 7, and lane (m = 8 s + c, q) of the weight holds M[.][8 o + c] when (q & 1) == s (avx_mst_attn_pack_mx);
+//     pos_emb + projection meet in float32 without the float16 rounding of pos_emb's result;
+//   * tiles are 14 pixels wide: the first conv's output (needed one pixel beyond the tile on every side) is then exactly 16 wide -- one MFMA
+//     column block, no GELU on columns nobody reads -- and v is 18 wide; TR rows tall (v: TR + 4, mid: TR + 2 rows);
+//   * a unit's result (8 bytes per lane) goes to an LDS image of the output tile; after a barrier all threads add the residual to 16-byte pieces
+//     of it and store whole 64-byte pixels (14 consecutive pixels per row: 896 contiguous bytes at C = 32).
+// Wave w owns octet w % NOCT (its eight weight fragments stay in registers for the whole launch) and every (8 / NOCT)-th row pair.
+template <int C, int TR, int MINW, bool STAMP = false>
+__global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __restrict__ x /*[B][H][W][C]*/, const uint4* __restrict__ wvpack /*[C/32][C/16][64]*/,
+                                                                const uint4* __restrict__ mpack /*[C/8][C/16][64]*/, const uint4* __restrict__ dw1 /*[C/8][3][64]*/,
+                                                                const uint4* __restrict__ dw2 /*[C/8][3][64]*/, const float* __restrict__ bias /*[C] or NULL*/,
+                                                                __half* __restrict__ out, int B, int H, int W, unsigned long long* __restrict__ stamps /*STAMP: [blocks][8][8]*/) {
+    constexpr int TW = 14, VW = 18, VR = TR + 4, MR = TR + 2, NOCT = C / 8, NK = C / 16, NT = C / 32, NS = C / 16;
+    constexpr int PP = C * 2 + 16, RP = (VW * PP + 255) / 256 * 256, OP = TW * C * 2;  // pixel / row pitch of the v and mid maps; row pitch of the output image
+    constexpr int NFILL = (VR * VW * NOCT + kFT - 1) / kFT;
+    constexpr int OPW = NOCT >= 8 ? NOCT / 8 : 1, RSPLIT = NOCT >= 8 ? 1 : 8 / NOCT;  // octets per wave; waves that share an octet split its row pairs
+    static_assert(C == 32 || C == 64, "31- or 62-channel blocks");
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* vt = smem;                             // [VR][RP]: v on the halo region (zeros outside the image)
+    unsigned char* mt = vt + (size_t)VR * RP;             // [VR][RP]: first the x tile, then mid = gelu(dw1(v)) on [MR][16 px]
+    unsigned char* ot = mt + (size_t)VR * RP;             // [TR][TW][C] float16: pos_emb + projection + bias of the tile
+    uint4* wvl = reinterpret_cast<uint4*>(ot + (size_t)TR * TW * C * 2);  // [NT * NS][64]: W_v's fragments (a global load inside the tile loop would drain the prefetches: in-order counter)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5, n16 = lane & 15, q = lane >> 4;
+    // STAMP (AVX_TAIL_STAMPS=1): cycles per segment and wave -- 0 fill + barrier, 1 phase A, 2 barrier, 3 phase B, 4 barrier, 5 phase C, 6 barrier, 7 epilogue
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int kk) {
+        if constexpr (STAMP) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            seg[kk] += now - tlast;
+            tlast = now;
+        }
+    };
+    if constexpr (STAMP) tlast = __builtin_readcyclecounter();
+    const int tx = (W + TW - 1) / TW, ty = (H + TR - 1) / TR;
+    const long total = (long)B * ty * tx;
+    for (int i = tid; i < NT * NS * 64; i += kFT) wvl[i] = wvpack[i];
+    const int o0 = NOCT >= 8 ? wave : wave % NOCT, rp0 = NOCT >= 8 ? 0 : wave / NOCT;
+    half8_t a1[OPW][3], a2[OPW][3], am[OPW][NK];
+    float bs[OPW][4];
+#pragma unroll
+    for (int k = 0; k < OPW; ++k) {
+        const int o = o0 + 8 * k;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a1[k][i] = __builtin_bit_cast(half8_t, dw1[((size_t)o * 3 + i) * 64 + lane]);
+            a2[k][i] = __builtin_bit_cast(half8_t, dw2[((size_t)o * 3 + i) * 64 + lane]);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < NK; ++t2) am[k][t2] = __builtin_bit_cast(half8_t, mpack[((size_t)o * NK + t2) * 64 + lane]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[k][j] = bias ? bias[8 * o + 4 * (q & 1) + j] : 0.f;
+    }
+    // The fragments above stay in registers for the whole launch.  Used once here: the compiler's wait for their loads then sits in front of the
+    // tile loop -- left to its first use INSIDE the loop, the in-order load counter would drain every tile's prefetches at that point.
+#pragma unroll
+    for (int k = 0; k < OPW; ++k) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(a1[k][i]), "v"(a2[k][i]));
+#pragma unroll
+        for (int t2 = 0; t2 < NK; ++t2) asm volatile("" ::"v"(am[k][t2]));
+        asm volatile("" ::"v"(bs[k][0]), "v"(bs[k][1]), "v"(bs[k][2]), "v"(bs[k][3]));
+    }
+    // lane-constant LDS addresses: everything else (row pair, column shift, K step, second octet) is an immediate
+    const unsigned char* rbB = vt + (size_t)q * RP + (size_t)n16 * PP + 16 * o0;                              // first conv's B operand: + 2 rp RP + i PP
+    unsigned char* wbB = mt + (size_t)(q >> 1) * RP + (size_t)n16 * PP + 16 * o0 + 8 * (q & 1);              // mid: + 2 rp RP
+    const unsigned char* rbC = mt + (size_t)q * RP + (size_t)n16 * PP + 16 * o0;                              // second conv's B operand
+    const unsigned char* rbG = vt + (size_t)(2 + (q & 1)) * RP + (size_t)(n16 + 2) * PP + 16 * (q >> 1);      // projection's B operand: + 2 rp RP + 32 t
+    unsigned char* wbC = ot + (size_t)(q >> 1) * OP + (size_t)n16 * C * 2 + 16 * o0 + 8 * (q & 1);            // output image: + 2 rp OP
+
+    uint4 pre[NFILL];
+    int f_lds[NFILL];
+    unsigned f_rel[NFILL];
+#pragma unroll
+    for (int k = 0; k < NFILL; ++k) {
+        const int it = tid + k * kFT, itc = it < VR * VW * NOCT ? it : 0, qq = itc / NOCT, part16 = itc % NOCT;
+        f_lds[k] = it < VR * VW * NOCT ? (qq / VW) * RP + (qq % VW) * PP + 16 * part16 : -1;
+        f_rel[k] = (unsigned)(((qq / VW) * W + qq % VW) * C + 8 * part16) * 2u;
+    }
+    auto fetch = [&](const Tile& t) {
+        if (t.y0 >= 2 && t.y0 + VR - 2 <= H && t.x0 >= 2 && t.x0 + VW - 2 <= W) {  // halo inside the frame: scalar origin + fixed lane offsets
+            const char* origin = reinterpret_cast<const char*>(x + ((t.b * H + t.y0 - 2) * (size_t)W + t.x0 - 2) * C);
+#pragma unroll
+            for (int k = 0; k < NFILL; ++k) {
+                unsigned o = f_rel[k];
+                asm volatile("" : "+v"(o));
+                pre[k] = *reinterpret_cast<const uint4*>(origin + o);
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            const int fl = f_lds[k] < 0 ? 0 : f_lds[k], row = fl / RP, col = (fl - row * RP) / PP, f_off = (fl - row * RP - col * PP) / 2;
+            const int yy = t.y0 + row - 2, xx = t.x0 + col - 2;
+            const bool ok = f_lds[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            uint4 r = *reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + f_off);
+            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
+            pre[k] = r;
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile >= total) return;
+    TileWalk walk, ahead;
+    walk.init(tile, gridDim.x, tx, ty);
+    ahead = walk;
+    ahead.advance();
+    auto tile_at = [&](const TileWalk& wk) { return Tile{wk.xi * TW, wk.yi * TR, wk.b}; };
+    Tile t = tile_at(walk);
+    fetch(t);
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k)
+            if (f_lds[k] >= 0) *reinterpret_cast<uint4*>(mt + f_lds[k]) = pre[k];
+        const long next = tile + gridDim.x;
+        if (next < total) fetch(tile_at(ahead));  // the next tile's halo: in flight for the whole tile (HBM latency is of the order of a tile's work)
+        __syncthreads();  // the x tile is complete; the previous tile's output image has been read
+        stamp(0);
+        // ---- phase A: v = float16(x W_v^T) on the halo region: 32-pixel groups x 32-channel tiles over the waves ----
+        {
+            constexpr int NG = (VR * VW + 31) / 32;
+            for (int task = wave; task < NG * NT; task += kFT / 64) {
+                const int g = task / NT, nt = task % NT;
+                const int qq = 32 * g + p, qc = qq < VR * VW ? qq : VR * VW - 1;
+                const int lo = (qc / VW) * RP + (qc % VW) * PP;
+                float16_t d;
+#pragma unroll
+                for (int vv = 0; vv < 16; ++vv) d[vv] = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2)
+                    d = mfma16(__builtin_bit_cast(half8_t, wvl[(nt * NS + s2) * 64 + lane]), __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(mt + lo + 32 * s2 + 16 * h)), d);
+                if (qq < VR * VW) {
+                    half8_t w0, w1;
+#pragma unroll
+                    for (int vv = 0; vv < 8; ++vv) { w0[vv] = (_Float16)d[vv]; w1[vv] = (_Float16)d[8 + vv]; }
+                    reinterpret_cast<uint4*>(vt + lo + 64 * nt + 32 * h)[0] = __builtin_bit_cast(uint4, w0);
+                    reinterpret_cast<uint4*>(vt + lo + 64 * nt + 32 * h)[1] = __builtin_bit_cast(uint4, w1);
+                }
+            }
+        }
+        stamp(1);
+        __syncthreads();  // v complete; the x tile is dead: its region becomes mid
+        stamp(2);
+        // ---- phase B: mid = gelu(dw1(v)) on MR rows x 16 columns, zero outside the image (the second conv's padding applies to THIS map) ----
+        {
+            const bool mid_inside = t.y0 >= 1 && t.y0 + MR - 1 <= H && t.x0 >= 1 && t.x0 + 15 <= W;  // scalar
+            // units of this wave: (octet k, row pair rp0 + j RSPLIT).  Reads and stores go to the same LDS array, so the compiler serialises a unit's reads behind
+            // the previous unit's store: unit u + 1's B operands are requested by hand right behind unit u's MFMAs, in front of its GELU.
+            constexpr int NJ = (MR / 2 + RSPLIT - 1) / RSPLIT, NU = OPW * NJ;
+            uint4 bq[3];
+            auto rd = [&](int u) {
+                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT, rpc = rp < MR / 2 ? rp : MR / 2 - 1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbB + (size_t)(2 * rpc) * RP + i * PP + 128 * k);
+            };
+            rd(0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT;
+                if (rp >= MR / 2) continue;  // wave-uniform (only ever the last unit)
+                float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[k][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
+                if (u + 1 < NU) rd(u + 1);  // behind the MFMAs, in front of the GELU
+                const float2_t g0 = gelu_fast2(float2_t{acc[0], acc[1]}), g1 = gelu_fast2(float2_t{acc[2], acc[3]});
+                uint2 ov = uint2{pack_f16(g0.x, g0.y), pack_f16(g1.x, g1.y)};
+                if (!mid_inside) {
+                    const int yy = t.y0 - 1 + 2 * rp + (q >> 1), xx = t.x0 - 1 + n16;
+                    const unsigned keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
+                    ov.x &= keep; ov.y &= keep;
+                }
+                *reinterpret_cast<uint2*>(wbB + (size_t)(2 * rp) * RP + 128 * k) = ov;
+            }
+        }
+        stamp(3);
+        __syncthreads();  // mid complete
+        stamp(4);
+        // the residual's pieces of x (this thread's items of the epilogue): requested now, in flight during phase C
+        constexpr int NEPI = (TR * TW * NOCT + kFT - 1) / kFT;
+        uint4 xres[NEPI];
+        size_t e_off[NEPI];
+#pragma unroll
+        for (int k = 0; k < NEPI; ++k) {
+            const int it = tid + k * kFT, row = it / (TW * NOCT), rem = it - row * (TW * NOCT), px = rem / NOCT, part = rem - px * NOCT;
+            const int yo = t.y0 + row, xo = t.x0 + px;
+            const bool live = it < TR * TW * NOCT && yo < H && xo < W;
+            e_off[k] = live ? ((t.b * H + yo) * (size_t)W + xo) * C + 8 * part : ~(size_t)0;
+            xres[k] = live ? *reinterpret_cast<const uint4*>(x + e_off[k]) : uint4{0, 0, 0, 0};
+        }
+        // ---- phase C: dw2(mid) + v @ M + bias for this wave's units -> the output image ----
+        {
+            constexpr int NJ = (TR / 2 + RSPLIT - 1) / RSPLIT, NU = OPW * NJ;  // TR / 2 is a multiple of RSPLIT: every unit is live
+            static_assert((TR / 2) % RSPLIT == 0, "row pairs split evenly over the waves of an octet");
+            uint4 bq[3], bg[NK];
+            auto rd = [&](int u) {
+                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbC + (size_t)(2 * rp) * RP + i * PP + 128 * k);
+#pragma unroll
+                for (int t2 = 0; t2 < NK; ++t2) bg[t2] = *reinterpret_cast<const uint4*>(rbG + (size_t)(2 * rp) * RP + 32 * t2);
+            };
+            rd(0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT;
+                float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[k][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
+#pragma unroll
+                for (int t2 = 0; t2 < NK; ++t2) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[k][t2], __builtin_bit_cast(half8_t, bg[t2]), acc, 0, 0, 0);
+                if (u + 1 < NU) rd(u + 1);  // behind the MFMAs, in front of the stores (which the compiler will not let a later read pass)
+                if (n16 < TW)
+                    *reinterpret_cast<uint2*>(wbC + (size_t)(2 * rp) * OP + 128 * k) = uint2{pack_f16(acc[0] + bs[k][0], acc[1] + bs[k][1]), pack_f16(acc[2] + bs[k][2], acc[3] + bs[k][3])};
+            }
+        }
+        stamp(5);
+        __syncthreads();  // the output image is complete; mid and v are dead
+        stamp(6);
+        // ---- epilogue: + x (the block's residual, :183), whole pixels, 16-byte pieces (x was requested before phase C) ----
+        {
+#pragma unroll
+            for (int k = 0; k < NEPI; ++k) {
+                if (e_off[k] == ~(size_t)0) continue;
+                const int it = tid + k * kFT, row = it / (TW * NOCT), rem = it - row * (TW * NOCT), px = rem / NOCT, part = rem - px * NOCT;
+                const uint4 xa = xres[k];
+                const uint4 oa = *reinterpret_cast<const uint4*>(ot + (size_t)row * OP + (size_t)px * C * 2 + 16 * part);
+                const unsigned xw[4] = {xa.x, xa.y, xa.z, xa.w}, ow[4] = {oa.x, oa.y, oa.z, oa.w};
+                unsigned rw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // float16 + float16 in float32, one rounding (v_fma_mix_f32: a * 1.0 + b takes both as they are)
+                    constexpr unsigned kOnes = 0x3c003c00u;
+                    float s0, s1;
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,1]" : "=v"(s0) : "v"(ow[j]), "v"(kOnes), "v"(xw[j]));
+                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,1,1]" : "=v"(s1) : "v"(ow[j]), "v"(kOnes), "v"(xw[j]));
+                    rw[j] = pack_f16(s0, s1);
+                }
+                *reinterpret_cast<uint4*>(out + e_off[k]) = uint4{rw[0], rw[1], rw[2], rw[3]};
+            }
+        }
+        stamp(7);
+        if (next >= total) break;
+        tile = next;
+        walk = ahead;
+        ahead.advance();
+        t = tile_at(walk);
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && stamps)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) stamps[((size_t)blockIdx.x * 8 + wave) * 8 + kk] = seg[kk];
+    }
+}
+
+template <int C, int TR, int MINW>
+int launch_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack, const void* mpack, const void* dw1, const void* dw2, const float* bias, void* out, int B, int H, int W,
+                        hipStream_t s) {
+    constexpr int PP = C * 2 + 16, RP = (18 * PP + 255) / 256 * 256;
+    const size_t lds = (size_t)2 * (TR + 4) * RP + (size_t)TR * 14 * C * 2 + (size_t)(C / 32) * (C / 16) * 1024;
+    const long total = (long)B * ((H + TR - 1) / TR) * ((W + 13) / 14);
+    const long cap = (long)ctx->num_cus * (MINW / 2);
+    const unsigned blocks = (unsigned)(total < cap ? total : cap);
+    if (getenv("AVX_TAIL_STAMPS")) {  // diagnostic: per-segment cycles of every wave, summed and printed
+        auto ks = k_mst_attn_tail_mx<C, TR, MINW, true>;
+        unsigned long long* d_st = nullptr;
+        const size_t n = (size_t)blocks * 64;
+        AVX_HIP(ctx, hipMalloc((void**)&d_st, n * sizeof(unsigned long long)));
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ks, dim3(blocks), dim3(kFT), lds, s, (const __half*)x, (const uint4*)wvpack, (const uint4*)mpack, (const uint4*)dw1, (const uint4*)dw2, bias, (__half*)out, B, H, W, d_st);
+        AVX_HIP(ctx, hipStreamSynchronize(s));
+        unsigned long long* h_st = (unsigned long long*)malloc(n * sizeof(unsigned long long));
+        AVX_HIP(ctx, hipMemcpy(h_st, d_st, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double tot[8] = {0}, all = 0;
+        for (size_t i = 0; i < n; ++i) { tot[i & 7] += (double)h_st[i]; all += (double)h_st[i]; }
+        const char* nm[8] = {"fill+bar0", "phaseA", "bar1", "phaseB", "bar2", "phaseC", "bar3", "epilogue"};
+        fprintf(stderr, "[tail stamps C=%d] %u blocks, %ld tiles, mean cycles per wave %.0f:", C, blocks, total, all / (blocks * 8.0));
+        for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, "  %s %.1f%%", nm[k2], 100 * tot[k2] / all);
+        fprintf(stderr, "\n");
+        free(h_st);
+        (void)hipFree(d_st);
+        return AVX_OK;
+    }
+    auto k = k_mst_attn_tail_mx<C, TR, MINW>;
+    AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(kFT), lds, s, (const __half*)x, (const uint4*)wvpack, (const uint4*)mpack, (const uint4*)dw1,
+                       (const uint4*)dw2, bias, (__half*)out, B, H, W, (unsigned long long*)nullptr);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
@@ -1095,10 +1432,31 @@ static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, con
         auto k = k_mst_ffn_fused<CV, HP, MW, DW>;                                                                                                \
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
         hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid,      \
-                           (const uint4*)w2pack, (__half*)out, B, H, W, (const uint4*)dwpack);                                                   \
+                           (const uint4*)w2pack, (__half*)out, B, H, W, (const uint4*)dwpack, (unsigned long long*)nullptr);                     \
     }
 #define AVX_FFN(CV, HP, MW) { if (dwpack) AVX_FFN1(CV, HP, MW, true) else AVX_FFN1(CV, HP, MW, false) }
-    if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2) else if (C == 64) AVX_FFN(64, 128, 2) else AVX_FFN(128, 64, 2)
+    if (C == 32 && small && dwpack && getenv("AVX_FFN_STAMPS")) {  // diagnostic: per-segment cycles of every wave, summed and printed
+        auto k = k_mst_ffn_fused<32, 64, 4, true, true>;
+        unsigned long long* d_st = nullptr;
+        const size_t n = (size_t)grid.x * 64;
+        AVX_HIP(ctx, hipMalloc((void**)&d_st, n * sizeof(unsigned long long)));
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid, (const uint4*)w2pack, (__half*)out, B, H, W,
+                           (const uint4*)dwpack, d_st);
+        AVX_HIP(ctx, hipStreamSynchronize(s));
+        unsigned long long* h_st = (unsigned long long*)malloc(n * sizeof(unsigned long long));
+        AVX_HIP(ctx, hipMemcpy(h_st, d_st, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double tot[8] = {0}, w0[8] = {0}, w7[8] = {0};
+        for (size_t i = 0; i < n; ++i) { tot[i & 7] += (double)h_st[i]; if (((i >> 3) & 7) == 0) w0[i & 7] += (double)h_st[i]; if (((i >> 3) & 7) == 7) w7[i & 7] += (double)h_st[i]; }
+        double all = 0;
+        for (int k2 = 0; k2 < 8; ++k2) all += tot[k2];
+        fprintf(stderr, "[ffn stamps] %u blocks, mean cycles per wave %.0f; share per segment (all waves | wave 0 | wave 7): ", grid.x, all / (grid.x * 8.0));
+        const char* nm[8] = {"bar1", "phase1", "bar2", "phase2a", "bar3", "phase2b", "epilogue", "ln+fetch"};
+        for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, "%s %.1f%% | %.1f%% | %.1f%%  ", nm[k2], 100 * tot[k2] / all, 100 * w0[k2] * 8 / all, 100 * w7[k2] * 8 / all);
+        fprintf(stderr, "\n");
+        free(h_st);
+        (void)hipFree(d_st);
+    } else if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2) else if (C == 64) AVX_FFN(64, 128, 2) else AVX_FFN(128, 64, 2)
 #undef AVX_FFN
 #undef AVX_FFN1
     AVX_HIP(ctx, hipGetLastError());
@@ -1133,6 +1491,22 @@ extern "C" int avx_mst_attn_tail_x(avx_ctx* ctx, const void* x, const void* wvpa
     hipStream_t s = avx_pick_stream(ctx, stream);
     if (C == 32) return launch_attn_tail<32, 4>(ctx, x, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s, wvpack16);
     return launch_attn_tail<64, 2>(ctx, x, x, mpack16, taps1_9xc, taps2_9xc, bias, out, B, H, W, s, wvpack16);
+}
+
+// The tail with both depthwise convs and the projection on the matrix pipe (k_mst_attn_tail_mx): dw1pack / dw2pack = pos_emb's two depthwise
+// weights as pack_dw_mfma fragments, mpack_mx = avx_mst_attn_pack_mx's output.  out != x.
+extern "C" int avx_mst_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack16, const void* mpack_mx, const void* dw1pack, const void* dw2pack,
+                                    const float* bias, void* out, int B, int H, int W, int C, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wvpack16 && mpack_mx && dw1pack && dw2pack && out && B > 0 && H > 0 && W > 0, "avx_mst_attn_tail_mx: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_attn_tail_mx: C=%d (32 or 64)", C);
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wvpack16 | (uintptr_t)mpack_mx | (uintptr_t)out | (uintptr_t)dw1pack | (uintptr_t)dw2pack)) & 15u) == 0,
+                "avx_mst_attn_tail_mx: pointers must be 16-byte aligned");
+    AVX_REQUIRE(ctx, x != out, "avx_mst_attn_tail_mx: tiles read their neighbours' rows of x: the output cannot be x");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    if (C == 32) return launch_attn_tail_mx<32, 16, 4>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);
+    return launch_attn_tail_mx<64, 16, 2>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);
 }
 
 extern "C" int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, void* out, int B, int H, int W, int C, void* stream) {

@@ -488,18 +488,26 @@ __global__ __launch_bounds__(256) void k_mst_attn_pack(const float* __restrict__
     __syncthreads();
     {  // every block repeats the (tiny) softmax above and then packs its own 256 entries of M
         const int idx = blockIdx.x * 256 + tid;
-        int k, n;
+        int k = 0, n = 0;
         if (layout == 0) {  // v_mfma_f32_32x32x8_f16 fragments of k_mst_rowgemm_add
             const int e = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % KS, t = (idx >> 8) / KS;
             const int hh = lane >> 5, m = lane & 31;
             k = hh * (C / 2) + 4 * s + e;                                    // input channel (row of M)
             n = 32 * t + 16 * ((m & 7) >> 2) + 4 * (m >> 3) + (m & 3);       // output channel (column of M)
-        } else {  // v_mfma_f32_32x32x16_f16 fragments of k_mst_attn_tail (csrc/mst_fused.hip): lane half hh carries input channels
+        } else if (layout == 1) {  // v_mfma_f32_32x32x16_f16 fragments of k_mst_attn_tail (csrc/mst_fused.hip): lane half hh carries input channels
                   // [hh C/2, (hh + 1) C/2) in steps of 8, and a result lane (pixel, hd) ends up with output channels hd C/2 + 16 t + v
             const int e = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) % (C / 16), t = (idx >> 9) / (C / 16);
             const int hh = lane >> 5, m = lane & 31;
             k = hh * (C / 2) + 8 * s + e;
             n = ((m >> 2) & 1) * (C / 2) + 16 * t + (m & 3) + 4 * (m >> 3);
+        }
+        if (layout == 2) {  // block-diagonal v_mfma_f32_16x16x32_f16 fragments of k_mst_attn_tail_mx (csrc/mst_fused.hip): [C/8 octets][C/16 steps][64][8]; result row
+                            // m = 8 s + c is output channel 8 o + c at tile row s, K slot q of step t2 carries row q & 1 and input channels 16 t2 + 8 (q >> 1) + e
+            const int e = idx & 7, lane = (idx >> 3) & 63, t2 = (idx >> 9) % (C / 16), o = (idx >> 9) / (C / 16);
+            const int m = lane & 15, q2 = lane >> 4;
+            if ((q2 & 1) != (m >> 3)) { mpack[idx] = __float2half(0.f); return; }
+            k = 16 * t2 + 8 * (q2 >> 1) + e;
+            n = 8 * o + (m & 7);
         }
         const int hd = k >> 5, j = k & 31;
         float acc = 0.f;
@@ -1099,7 +1107,7 @@ static int attn_pack_impl(avx_ctx* ctx, const float* gram, const float* nq, cons
     AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_attn_pack: C=%d (32, 64 or 128)", C);
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
-    hipLaunchKernelGGL(k_mst_attn_pack, dim3((unsigned)(C * C / 256)), dim3(256), 0, s, gram, nq, nk, rescale, wproj_t, C, (__half*)mpack, layout);
+    hipLaunchKernelGGL(k_mst_attn_pack, dim3((unsigned)((layout == 2 ? 4 : 1) * C * C / 256)), dim3(256), 0, s, gram, nq, nk, rescale, wproj_t, C, (__half*)mpack, layout);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }
@@ -1112,6 +1120,11 @@ int avx_mst_attn_pack(avx_ctx* ctx, const float* gram, const float* nq, const fl
 int avx_mst_attn_pack16(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
                         void* stream) {
     return attn_pack_impl(ctx, gram, nq, nk, rescale, wproj_t, C, mpack, 1, stream);
+}
+
+int avx_mst_attn_pack_mx(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
+                         void* stream) {
+    return attn_pack_impl(ctx, gram, nq, nk, rescale, wproj_t, C, mpack, 2, stream);
 }
 
 int avx_mst_conv3x3_add(avx_ctx* ctx, const void* x, const void* wpack, const void* add, void* out, int B, int H, int W, int C, void* stream) {

@@ -398,6 +398,31 @@ class _AvxOps:
                                            torch.cuda.current_stream(gram.device).cuda_stream))
         return out
 
+    def attn_pack_mx(self, gram: torch.Tensor, nq: torch.Tensor, nk: torch.Tensor, rescale: torch.Tensor, wproj_t: torch.Tensor) -> torch.Tensor:
+        """attn_pack as the block-diagonal 16x16x32 fragments avx_mst_attn_tail_mx takes (csrc/mst_mfma.hip::k_mst_attn_pack, layout 2)."""
+        from .._lib import lib
+
+        c = nq.numel()
+        ctx = self.ctx(gram.device)
+        out = torch.empty((c // 8, c // 16, 64, 8), dtype=torch.float16, device=gram.device)
+        ctx._check(lib.avx_mst_attn_pack_mx(ctx._h, gram.data_ptr(), nq.data_ptr(), nk.data_ptr(), rescale.data_ptr(), wproj_t.data_ptr(), c, out.data_ptr(),
+                                            torch.cuda.current_stream(gram.device).cuda_stream))
+        return out
+
+    def attn_tail_mx(self, x: torch.Tensor, wvpack16: torch.Tensor, mpack_mx: torch.Tensor, dw1: torch.Tensor, dw2: torch.Tensor, bias: torch.Tensor,
+                     out: torch.Tensor = None) -> torch.Tensor:
+        """pos_emb(v) + v @ M + bias + x with v = float16(x @ W_v) formed inside the kernel and both depthwise convs on the matrix pipe, on one
+        (h, w, c) float16 frame (csrc/mst_fused.hip::k_mst_attn_tail_mx)."""
+        from .._lib import lib
+
+        h, w, c = x.shape
+        assert x.is_contiguous()
+        out = torch.empty_like(x) if out is None else out
+        ctx = self.ctx(x.device)
+        ctx._check(lib.avx_mst_attn_tail_mx(ctx._h, x.data_ptr(), wvpack16.data_ptr(), mpack_mx.data_ptr(), dw1.data_ptr(), dw2.data_ptr(), bias.data_ptr(),
+                                            out.data_ptr(), 1, h, w, c, torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+
     def attn_tail(self, v: torch.Tensor, x: torch.Tensor, mpack16: torch.Tensor, taps1: torch.Tensor, taps2: torch.Tensor, bias: torch.Tensor,
                   out: torch.Tensor = None) -> torch.Tensor:
         """pos_emb(v) + v @ M + bias + x on one (h, w, c) float16 frame in one pass (csrc/mst_fused.hip::k_mst_attn_tail)."""
@@ -664,6 +689,13 @@ class MSTPlusPlus(torch.nn.Module):
                 t2 = self._prep(k2 + ".t9h", lambda: self._w(k2, (0,)).reshape(c, 9).t().contiguous())
                 xc = x.contiguous()
                 out = torch.empty_like(xc)
+                if tailx and _AVX._dwmx:  # both depthwise convs and the projection on the matrix pipe
+                    wv16 = self._prep(p + ".wv.frag16", lambda: pack_fragments16(wqkv[:, 2 * c :].contiguous()))
+                    d1 = self._prep(k1 + ".dwmx", lambda: pack_dw_mfma(self._w(k1, (0,))))
+                    d2 = self._prep(k2 + ".dwmx", lambda: pack_dw_mfma(self._w(k2, (0,))))
+                    for i in range(b):
+                        _AVX.attn_tail_mx(xc[i], wv16, _AVX.attn_pack_mx(gram[i], nq[i], nk[i], resc, wpt), d1, d2, bias32, out[i])
+                    return out
                 if tailx:
                     wv16 = self._prep(p + ".wv.frag16", lambda: pack_fragments16(wqkv[:, 2 * c :].contiguous()))
                     for i in range(b):

@@ -389,6 +389,18 @@ int avx_mst_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mp
  * HBM and avx_mst_qkv_gram may be called with v_out = NULL.  out != x. */
 int avx_mst_attn_tail_x(avx_ctx* ctx, const void* x, const void* wvpack16, const void* mpack16, const void* taps1_9xc, const void* taps2_9xc,
                         const float* bias, void* out, int B, int H, int W, int C, void* stream);
+/* The tail with BOTH depthwise convs of pos_emb and the projection on the matrix pipe (csrc/mst_fused.hip::k_mst_attn_tail_mx; round 3): a
+ * v_mfma_f32_16x16x32_f16 result tile is 8 channels x 2 vertically adjacent rows x 16 pixels, a depthwise 3x3 conv is three MFMAs per tile
+ * (dw1pack / dw2pack: ml/mst_plus_plus.py::pack_dw_mfma fragments of MS_MSA.pos_emb's two weights, :104-106), and v @ M accumulates into the
+ * same registers through block-diagonal fragments (mpack_mx: avx_mst_attn_pack_mx).  v = float16(x W_v^T) is formed on the tile's halo as in
+ * avx_mst_attn_tail_x.  C = 32 or 64; out != x. */
+int avx_mst_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack16, const void* mpack_mx, const void* dw1pack, const void* dw2pack,
+                         const float* bias, void* out, int B, int H, int W, int C, void* stream);
+/* avx_mst_attn_pack16's matrix M in the fragment order avx_mst_attn_tail_mx takes: [C/8][C/16][64][8] float16 (4 C^2 entries, half of them
+ * the zeros of the block-diagonal form). */
+int avx_mst_attn_pack_mx(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
+                         void* stream);
+
 
 /* The whole second half of an MSAB block in one kernel (MST_Plus_Plus.py:57-65 PreNorm, :141-158 FeedForward, :184 residual):
  * out = x + W2 gelu(dw3x3(gelu(W1 layernorm(x)))) on a (B, H, W, C) float16 tensor, C = 32 or 64 (31-channel groups stored
