@@ -65,6 +65,39 @@ __device__ __forceinline__ float2_t gelu_poly2(float2_t x) {
     return x * __builtin_elementwise_fma(xc, r, c2(0.5f));
 }
 
+// NP pairs at once, STEP-major: every Horner step is issued for all pairs before the next one, so a wave has NP independent instructions between
+// an instruction and its consumer (pair-major code -- one whole chain after the other -- leaves the vector unit waiting out each result's latency
+// whenever fewer than ~4 waves share the SIMD, and the compiler does not interleave the chains by itself).  The asm barriers pin the order.
+template <int NP>
+__device__ __forceinline__ void gelu_multi(float2_t (&x)[NP]) {
+#ifdef AVX_GELU_SIGMOID
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = gelu_sig2(x[i]);
+#else
+    constexpr float R[8] = {0x1.9860cap-2f, -0x1.0e9c60p-4f, 0x1.3a08cap-7f, -0x1.0bd734p-10f, 0x1.4005e4p-14f, -0x1.f322cap-19f, 0x1.c24602p-24f, -0x1.61225cp-30f};
+    auto c2 = [](float v) { return float2_t{v, v}; };
+    float2_t xc[NP], t[NP], r[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) xc[i] = float2_t{__builtin_amdgcn_fmed3f(x[i].x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[i].y, -4.0f, 4.0f)};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) t[i] = xc[i] * xc[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = __builtin_elementwise_fma(t[i], c2(R[7]), c2(R[6]));
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            r[i] = __builtin_elementwise_fma(r[i], t[i], c2(R[k]));
+            asm volatile("" : "+v"(r[i]));  // keeps the step-major order through the scheduler
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = __builtin_elementwise_fma(xc[i], r[i], c2(0.5f));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = x[i] * r[i];
+#endif
+}
+
 __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
 #ifdef AVX_GELU_SIGMOID
     return gelu_sig2(x);

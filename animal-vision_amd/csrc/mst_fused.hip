@@ -265,13 +265,19 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                             const int yy = t.y0 + p1_dy[j], xx = t.x0 + p1_dx[j];
                             keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
                         }
-                        half8_t o0, o1;
+                        // GELU of the 16 results, GP1 pairs at a time step-major (gelu_multi): as many as the registers allow without spilling
+                        constexpr int GP1 = C == 64 ? 4 : 1;  // C = 32 / 128: no register to spare (more than one pair in flight spills)
+                        unsigned pk[8];
 #pragma unroll
-                        for (int v = 0; v < 16; v += 2) {
-                            const float2_t gv = gelu_fast2(float2_t{d[v], d[v + 1]});
-                            if (v < 8) { o0[v] = (_Float16)gv.x; o0[v + 1] = (_Float16)gv.y; } else { o1[v - 8] = (_Float16)gv.x; o1[v - 7] = (_Float16)gv.y; }
+                        for (int v0 = 0; v0 < 8; v0 += GP1) {
+                            float2_t gq[GP1];
+#pragma unroll
+                            for (int v = 0; v < GP1; ++v) gq[v] = float2_t{d[2 * (v0 + v)], d[2 * (v0 + v) + 1]};
+                            gelu_multi<GP1>(gq);
+#pragma unroll
+                            for (int v = 0; v < GP1; ++v) pk[v0 + v] = pack_f16(gq[v].x, gq[v].y);
                         }
-                        uint4 u0 = __builtin_bit_cast(uint4, o0), u1 = __builtin_bit_cast(uint4, o1);
+                        uint4 u0 = uint4{pk[0], pk[1], pk[2], pk[3]}, u1 = uint4{pk[4], pk[5], pk[6], pk[7]};
                         if (!halo_inside) { u0.x &= keep; u0.y &= keep; u0.z &= keep; u0.w &= keep; u1.x &= keep; u1.y &= keep; u1.z &= keep; u1.w &= keep; }
                         unsigned char* dst = ht + p1_dst[j] + 64 * ct;
                         reinterpret_cast<uint4*>(dst)[0] = u0;
@@ -299,16 +305,19 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
 #pragma unroll
                     for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 128 * o2);
                 };
-                rd(0);
+                constexpr bool AHEAD = C != 128;  // C = 128: the read-ahead's registers spill
+                if constexpr (AHEAD) rd(0);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int o2 = u / (TS / 2), pr = u % (TS / 2);
+                    if constexpr (!AHEAD) rd(u);
                     float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
-                    if (u + 1 < NU) rd(u + 1);  // the MFMAs have taken their operands: the same registers receive the next unit's while this one's GELU runs
-                    const float2_t g0 = gelu_fast2(float2_t{acc[0], acc[1]}), g1 = gelu_fast2(float2_t{acc[2], acc[3]});
-                    *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 128 * o2) = uint2{pack_f16(g0.x, g0.y), pack_f16(g1.x, g1.y)};
+                    if (AHEAD && u + 1 < NU) rd(u + 1);  // the MFMAs have taken their operands: the same registers receive the next unit's while this one's GELU runs
+                    float2_t gp[2] = {float2_t{acc[0], acc[1]}, float2_t{acc[2], acc[3]}};
+                    if constexpr (C == 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
+                    *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 128 * o2) = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
                 }
                 stamp(3);
                 __syncthreads();  // the GELU'd depthwise map is complete
@@ -658,26 +667,29 @@ int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpa
 //     pos_emb + projection meet in float32 without the float16 rounding of pos_emb's result;
 //   * tiles are 14 pixels wide: the first conv's output (needed one pixel beyond the tile on every side) is then exactly 16 wide -- one MFMA
 //     column block, no GELU on columns nobody reads -- and v is 18 wide; TR rows tall (v: TR + 4, mid: TR + 2 rows);
-//   * a unit's result (8 bytes per lane) goes to an LDS image of the output tile; after a barrier all threads add the residual to 16-byte pieces
-//     of it and store whole 64-byte pixels (14 consecutive pixels per row: 896 contiguous bytes at C = 32).
-// Wave w owns octet w % NOCT (its eight weight fragments stay in registers for the whole launch) and every (8 / NOCT)-th row pair.
+//   * depthwise convs do not mix channels, so after v is complete a wave needs NOBODY ELSE: wave w owns octet w % NOCT (and, where two waves
+//     share an octet, half of the tile's rows: the one mid row pair both halves need is computed by both), runs conv1 -> GELU -> mid (its own
+//     bytes of the LDS map) -> conv2 + projection for its units back to back and stores its 8 bytes per lane and pixel straight to memory with
+//     the residual (requested before the first unit) added: two barriers per tile (v complete; v free), no output staging;
+//   * v is formed from x as it arrives: a lane's prefetched half row of its halo pixel IS its B operand (W_v packed in that K order,
+//     pack_fragments16(halfrow=True)); the x tile never sits in LDS.
 template <int C, int TR, int MINW, bool STAMP = false>
-__global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __restrict__ x /*[B][H][W][C]*/, const uint4* __restrict__ wvpack /*[C/32][C/16][64]*/,
+__global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __restrict__ x /*[B][H][W][C]*/, const uint4* __restrict__ wvpack /*[C/32][C/16][64], half-row K order*/,
                                                                 const uint4* __restrict__ mpack /*[C/8][C/16][64]*/, const uint4* __restrict__ dw1 /*[C/8][3][64]*/,
                                                                 const uint4* __restrict__ dw2 /*[C/8][3][64]*/, const float* __restrict__ bias /*[C] or NULL*/,
                                                                 __half* __restrict__ out, int B, int H, int W, unsigned long long* __restrict__ stamps /*STAMP: [blocks][8][8]*/) {
-    constexpr int TW = 14, VW = 18, VR = TR + 4, MR = TR + 2, NOCT = C / 8, NK = C / 16, NT = C / 32, NS = C / 16;
-    constexpr int PP = C * 2 + 16, RP = (VW * PP + 255) / 256 * 256, OP = TW * C * 2;  // pixel / row pitch of the v and mid maps; row pitch of the output image
-    constexpr int NFILL = (VR * VW * NOCT + kFT - 1) / kFT;
-    constexpr int OPW = NOCT >= 8 ? NOCT / 8 : 1, RSPLIT = NOCT >= 8 ? 1 : 8 / NOCT;  // octets per wave; waves that share an octet split its row pairs
+    constexpr int TW = 14, VW = 18, VR = TR + 4, MR = TR + 2, NOCT = C / 8, NK = C / 16, NT = C / 32, NS = C / 16, LNV = C / 16;
+    constexpr int PP = C * 2 + 16, RP = (VW * PP + 255) / 256 * 256, MP = 16 * PP;  // pixel pitch; row pitch of v (18 px) and of mid (16 px): multiples of 256 bytes
+    constexpr int NG = (VR * VW + 31) / 32, NGW = (NG + 7) / 8;                     // 32-pixel groups of the halo region; per wave
+    constexpr int WPO = 8 / NOCT, NOUT = (TR / 2) / WPO, NMID = NOUT + 1;           // waves per octet; output / mid row pairs per wave
     static_assert(C == 32 || C == 64, "31- or 62-channel blocks");
+    static_assert(MP % 256 == 0 && (TR / 2) % WPO == 0, "pitches / row split");
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* vt = smem;                             // [VR][RP]: v on the halo region (zeros outside the image)
-    unsigned char* mt = vt + (size_t)VR * RP;             // [VR][RP]: first the x tile, then mid = gelu(dw1(v)) on [MR][16 px]
-    unsigned char* ot = mt + (size_t)VR * RP;             // [TR][TW][C] float16: pos_emb + projection + bias of the tile
-    uint4* wvl = reinterpret_cast<uint4*>(ot + (size_t)TR * TW * C * 2);  // [NT * NS][64]: W_v's fragments (a global load inside the tile loop would drain the prefetches: in-order counter)
+    unsigned char* vt = smem;                                            // [VR][RP]: v on the halo region (zeros outside the image)
+    unsigned char* mt = vt + (size_t)VR * RP;                            // [MR][MP]: mid = gelu(dw1(v)), 16 columns; an octet's bytes belong to its wave(s)
+    uint4* wvl = reinterpret_cast<uint4*>(mt + (size_t)MR * MP);         // [NT * NS][64]: W_v's fragments (also absorbs the reads of the two unused columns past the last mid row)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5, n16 = lane & 15, q = lane >> 4;
-    // STAMP (AVX_TAIL_STAMPS=1): cycles per segment and wave -- 0 fill + barrier, 1 phase A, 2 barrier, 3 phase B, 4 barrier, 5 phase C, 6 barrier, 7 epilogue
+    // STAMP (AVX_TAIL_STAMPS=1): cycles per segment and wave -- 0 v from x (incl. waiting for the prefetch), 1 barrier, 2 conv1 + GELU, 3 conv2 + projection + stores, 4 barrier
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     auto stamp = [&](int kk) {
         if constexpr (STAMP) {
@@ -690,68 +702,68 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
     const int tx = (W + TW - 1) / TW, ty = (H + TR - 1) / TR;
     const long total = (long)B * ty * tx;
     for (int i = tid; i < NT * NS * 64; i += kFT) wvl[i] = wvpack[i];
-    const int o0 = NOCT >= 8 ? wave : wave % NOCT, rp0 = NOCT >= 8 ? 0 : wave / NOCT;
-    half8_t a1[OPW][3], a2[OPW][3], am[OPW][NK];
-    float bs[OPW][4];
+    const int o = wave % NOCT, rpo = (wave / NOCT) * NOUT;  // this wave's octet and first row pair
+    half8_t a1[3], a2[3], am[NK];
+    float bs[4];
 #pragma unroll
-    for (int k = 0; k < OPW; ++k) {
-        const int o = o0 + 8 * k;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            a1[k][i] = __builtin_bit_cast(half8_t, dw1[((size_t)o * 3 + i) * 64 + lane]);
-            a2[k][i] = __builtin_bit_cast(half8_t, dw2[((size_t)o * 3 + i) * 64 + lane]);
-        }
-#pragma unroll
-        for (int t2 = 0; t2 < NK; ++t2) am[k][t2] = __builtin_bit_cast(half8_t, mpack[((size_t)o * NK + t2) * 64 + lane]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bs[k][j] = bias ? bias[8 * o + 4 * (q & 1) + j] : 0.f;
+    for (int i = 0; i < 3; ++i) {
+        a1[i] = __builtin_bit_cast(half8_t, dw1[((size_t)o * 3 + i) * 64 + lane]);
+        a2[i] = __builtin_bit_cast(half8_t, dw2[((size_t)o * 3 + i) * 64 + lane]);
     }
+#pragma unroll
+    for (int t2 = 0; t2 < NK; ++t2) am[t2] = __builtin_bit_cast(half8_t, mpack[((size_t)o * NK + t2) * 64 + lane]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] = bias ? bias[8 * o + 4 * (q & 1) + j] : 0.f;
     // The fragments above stay in registers for the whole launch.  Used once here: the compiler's wait for their loads then sits in front of the
-    // tile loop -- left to its first use INSIDE the loop, the in-order load counter would drain every tile's prefetches at that point.
+    // tile loop -- left to their first use INSIDE the loop, the in-order load counter would drain every tile's prefetches at that point.
 #pragma unroll
-    for (int k = 0; k < OPW; ++k) {
+    for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(a1[i]), "v"(a2[i]));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(a1[k][i]), "v"(a2[k][i]));
+    for (int t2 = 0; t2 < NK; ++t2) asm volatile("" ::"v"(am[t2]));
+    asm volatile("" ::"v"(bs[0]), "v"(bs[1]), "v"(bs[2]), "v"(bs[3]));
+    // lane-constant LDS addresses: row pair, column shift and K step are immediates
+    const unsigned char* rbB = vt + (size_t)q * RP + (size_t)n16 * PP + 16 * o;                              // first conv's B operand: + 2 rp RP + i PP
+    unsigned char* wbB = mt + (size_t)(q >> 1) * MP + (size_t)n16 * PP + 16 * o + 8 * (q & 1);              // mid: + 2 rp MP
+    const unsigned char* rbC = mt + (size_t)q * MP + (size_t)n16 * PP + 16 * o;                              // second conv's B operand: + 2 rp MP + i PP
+    const unsigned char* rbG = vt + (size_t)(2 + (q & 1)) * RP + (size_t)(n16 + 2) * PP + 16 * (q >> 1);    // projection's B operand: + 2 rp RP + 32 t
+    // this wave's halo pixel groups (wave, wave + 8): where a lane's pixel sits in the frame (relative to the halo origin) and in the v map
+    unsigned f_rel[NGW];
+    int v_dst[NGW], p_row[NGW], p_col[NGW];
 #pragma unroll
-        for (int t2 = 0; t2 < NK; ++t2) asm volatile("" ::"v"(am[k][t2]));
-        asm volatile("" ::"v"(bs[k][0]), "v"(bs[k][1]), "v"(bs[k][2]), "v"(bs[k][3]));
+    for (int gi = 0; gi < NGW; ++gi) {
+        const int g = wave + 8 * gi, qq = 32 * g + p, qc = qq < VR * VW ? qq : VR * VW - 1;
+        p_row[gi] = qc / VW; p_col[gi] = qc % VW;
+        f_rel[gi] = (unsigned)((p_row[gi] * W + p_col[gi]) * C + h * (C / 2)) * 2u;
+        v_dst[gi] = (g < NG && qq < VR * VW) ? p_row[gi] * RP + p_col[gi] * PP + 32 * h : -1;
     }
-    // lane-constant LDS addresses: everything else (row pair, column shift, K step, second octet) is an immediate
-    const unsigned char* rbB = vt + (size_t)q * RP + (size_t)n16 * PP + 16 * o0;                              // first conv's B operand: + 2 rp RP + i PP
-    unsigned char* wbB = mt + (size_t)(q >> 1) * RP + (size_t)n16 * PP + 16 * o0 + 8 * (q & 1);              // mid: + 2 rp RP
-    const unsigned char* rbC = mt + (size_t)q * RP + (size_t)n16 * PP + 16 * o0;                              // second conv's B operand
-    const unsigned char* rbG = vt + (size_t)(2 + (q & 1)) * RP + (size_t)(n16 + 2) * PP + 16 * (q >> 1);      // projection's B operand: + 2 rp RP + 32 t
-    unsigned char* wbC = ot + (size_t)(q >> 1) * OP + (size_t)n16 * C * 2 + 16 * o0 + 8 * (q & 1);            // output image: + 2 rp OP
-
-    uint4 pre[NFILL];
-    int f_lds[NFILL];
-    unsigned f_rel[NFILL];
-#pragma unroll
-    for (int k = 0; k < NFILL; ++k) {
-        const int it = tid + k * kFT, itc = it < VR * VW * NOCT ? it : 0, qq = itc / NOCT, part16 = itc % NOCT;
-        f_lds[k] = it < VR * VW * NOCT ? (qq / VW) * RP + (qq % VW) * PP + 16 * part16 : -1;
-        f_rel[k] = (unsigned)(((qq / VW) * W + qq % VW) * C + 8 * part16) * 2u;
-    }
+    uint4 pre[NGW][LNV];  // a lane's half row of its halo pixels: fetched a tile ahead, consumed as MFMA operands
     auto fetch = [&](const Tile& t) {
         if (t.y0 >= 2 && t.y0 + VR - 2 <= H && t.x0 >= 2 && t.x0 + VW - 2 <= W) {  // halo inside the frame: scalar origin + fixed lane offsets
             const char* origin = reinterpret_cast<const char*>(x + ((t.b * H + t.y0 - 2) * (size_t)W + t.x0 - 2) * C);
 #pragma unroll
-            for (int k = 0; k < NFILL; ++k) {
-                unsigned o = f_rel[k];
-                asm volatile("" : "+v"(o));
-                pre[k] = *reinterpret_cast<const uint4*>(origin + o);
+            for (int gi = 0; gi < NGW; ++gi) {
+                if (wave + 8 * gi >= NG) break;
+                unsigned of = f_rel[gi];
+                asm volatile("" : "+v"(of));
+                const uint4* src = reinterpret_cast<const uint4*>(origin + of);
+#pragma unroll
+                for (int v = 0; v < LNV; ++v) pre[gi][v] = src[v];
             }
             return;
         }
 #pragma unroll
-        for (int k = 0; k < NFILL; ++k) {
-            const int fl = f_lds[k] < 0 ? 0 : f_lds[k], row = fl / RP, col = (fl - row * RP) / PP, f_off = (fl - row * RP - col * PP) / 2;
-            const int yy = t.y0 + row - 2, xx = t.x0 + col - 2;
-            const bool ok = f_lds[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        for (int gi = 0; gi < NGW; ++gi) {
+            if (wave + 8 * gi >= NG) break;
+            const int yy = t.y0 - 2 + p_row[gi], xx = t.x0 - 2 + p_col[gi];
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;  // zeros outside the image: v = 0 there (to_v has no bias), the convs' padding
             const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            uint4 r = *reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + f_off);
-            r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
-            pre[k] = r;
+            const uint4* src = reinterpret_cast<const uint4*>(x + ((t.b * H + yc) * (size_t)W + xc) * C + h * (C / 2));
+#pragma unroll
+            for (int v = 0; v < LNV; ++v) {
+                uint4 r = src[v];
+                r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u;
+                pre[gi][v] = r;
+            }
         }
     };
     long tile = blockIdx.x;
@@ -763,141 +775,126 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
     auto tile_at = [&](const TileWalk& wk) { return Tile{wk.xi * TW, wk.yi * TR, wk.b}; };
     Tile t = tile_at(walk);
     fetch(t);
+    __syncthreads();  // W_v's fragments are in LDS
     for (;;) {
+        // ---- phase A: v = float16(x W_v^T) for this wave's halo pixel groups, straight from the prefetched rows ----
 #pragma unroll
-        for (int k = 0; k < NFILL; ++k)
-            if (f_lds[k] >= 0) *reinterpret_cast<uint4*>(mt + f_lds[k]) = pre[k];
-        const long next = tile + gridDim.x;
-        if (next < total) fetch(tile_at(ahead));  // the next tile's halo: in flight for the whole tile (HBM latency is of the order of a tile's work)
-        __syncthreads();  // the x tile is complete; the previous tile's output image has been read
-        stamp(0);
-        // ---- phase A: v = float16(x W_v^T) on the halo region: 32-pixel groups x 32-channel tiles over the waves ----
-        {
-            constexpr int NG = (VR * VW + 31) / 32;
-            for (int task = wave; task < NG * NT; task += kFT / 64) {
-                const int g = task / NT, nt = task % NT;
-                const int qq = 32 * g + p, qc = qq < VR * VW ? qq : VR * VW - 1;
-                const int lo = (qc / VW) * RP + (qc % VW) * PP;
+        for (int gi = 0; gi < NGW; ++gi) {
+            if (wave + 8 * gi >= NG) break;  // wave-uniform
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
                 float16_t d;
 #pragma unroll
                 for (int vv = 0; vv < 16; ++vv) d[vv] = 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2)
-                    d = mfma16(__builtin_bit_cast(half8_t, wvl[(nt * NS + s2) * 64 + lane]), __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(mt + lo + 32 * s2 + 16 * h)), d);
-                if (qq < VR * VW) {
+                for (int s2 = 0; s2 < NS; ++s2) d = mfma16(__builtin_bit_cast(half8_t, wvl[(nt * NS + s2) * 64 + lane]), __builtin_bit_cast(half8_t, pre[gi][s2]), d);
+                if (v_dst[gi] >= 0) {
                     half8_t w0, w1;
 #pragma unroll
                     for (int vv = 0; vv < 8; ++vv) { w0[vv] = (_Float16)d[vv]; w1[vv] = (_Float16)d[8 + vv]; }
-                    reinterpret_cast<uint4*>(vt + lo + 64 * nt + 32 * h)[0] = __builtin_bit_cast(uint4, w0);
-                    reinterpret_cast<uint4*>(vt + lo + 64 * nt + 32 * h)[1] = __builtin_bit_cast(uint4, w1);
+                    reinterpret_cast<uint4*>(vt + v_dst[gi] + 64 * nt)[0] = __builtin_bit_cast(uint4, w0);
+                    reinterpret_cast<uint4*>(vt + v_dst[gi] + 64 * nt)[1] = __builtin_bit_cast(uint4, w1);
                 }
             }
         }
+        stamp(0);
+        __syncthreads();  // v complete
         stamp(1);
-        __syncthreads();  // v complete; the x tile is dead: its region becomes mid
-        stamp(2);
-        // ---- phase B: mid = gelu(dw1(v)) on MR rows x 16 columns, zero outside the image (the second conv's padding applies to THIS map) ----
+        const long next = tile + gridDim.x;
+        if (next < total) fetch(tile_at(ahead));  // the next tile's halo rows: in flight while this wave works through its units
+        // the residual's pieces of x for this wave's output units (8 bytes per lane and unit): requested now, added at the stores
+        uint2 xr[NOUT];
+        size_t e_off[NOUT];
+#pragma unroll
+        for (int u = 0; u < NOUT; ++u) {
+            const int yo = t.y0 + 2 * (rpo + u) + (q >> 1), xo = t.x0 + n16;
+            const bool live = n16 < TW && yo < H && xo < W;
+            e_off[u] = live ? ((t.b * H + yo) * (size_t)W + xo) * C + 8 * o + 4 * (q & 1) : ~(size_t)0;
+            xr[u] = live ? *reinterpret_cast<const uint2*>(x + e_off[u]) : uint2{0, 0};
+        }
+        // ---- conv1 + GELU -> mid, this wave's octet, mid row pairs rpo ... rpo + NOUT (zero outside the image: the second conv's padding applies to THIS map) ----
         {
             const bool mid_inside = t.y0 >= 1 && t.y0 + MR - 1 <= H && t.x0 >= 1 && t.x0 + 15 <= W;  // scalar
-            // units of this wave: (octet k, row pair rp0 + j RSPLIT).  Reads and stores go to the same LDS array, so the compiler serialises a unit's reads behind
-            // the previous unit's store: unit u + 1's B operands are requested by hand right behind unit u's MFMAs, in front of its GELU.
-            constexpr int NJ = (MR / 2 + RSPLIT - 1) / RSPLIT, NU = OPW * NJ;
-            uint4 bq[3];
+            // units UPB at a time (two where the registers allow: four GELU pairs then advance together, gelu_multi); NMID is odd: the last step carries one unit
+            constexpr int UPB = C >= 64 ? 2 : 1;
+            uint4 bq[UPB][3];
             auto rd = [&](int u) {
-                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT, rpc = rp < MR / 2 ? rp : MR / 2 - 1;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbB + (size_t)(2 * rpc) * RP + i * PP + 128 * k);
+                for (int k = 0; k < UPB; ++k) {
+                    if (u + k >= NMID) break;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) bq[k][i] = *reinterpret_cast<const uint4*>(rbB + (size_t)(2 * (rpo + u + k)) * RP + i * PP);
+                }
             };
-            rd(0);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT;
-                if (rp >= MR / 2) continue;  // wave-uniform (only ever the last unit)
-                float4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[k][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
-                if (u + 1 < NU) rd(u + 1);  // behind the MFMAs, in front of the GELU
-                const float2_t g0 = gelu_fast2(float2_t{acc[0], acc[1]}), g1 = gelu_fast2(float2_t{acc[2], acc[3]});
-                uint2 ov = uint2{pack_f16(g0.x, g0.y), pack_f16(g1.x, g1.y)};
+            auto put = [&](int u, float2_t ga, float2_t gb) {
+                uint2 ov = uint2{pack_f16(ga.x, ga.y), pack_f16(gb.x, gb.y)};
                 if (!mid_inside) {
-                    const int yy = t.y0 - 1 + 2 * rp + (q >> 1), xx = t.x0 - 1 + n16;
+                    const int yy = t.y0 - 1 + 2 * (rpo + u) + (q >> 1), xx = t.x0 - 1 + n16;
                     const unsigned keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
                     ov.x &= keep; ov.y &= keep;
                 }
-                *reinterpret_cast<uint2*>(wbB + (size_t)(2 * rp) * RP + 128 * k) = ov;
-            }
-        }
-        stamp(3);
-        __syncthreads();  // mid complete
-        stamp(4);
-        // the residual's pieces of x (this thread's items of the epilogue): requested now, in flight during phase C
-        constexpr int NEPI = (TR * TW * NOCT + kFT - 1) / kFT;
-        uint4 xres[NEPI];
-        size_t e_off[NEPI];
-#pragma unroll
-        for (int k = 0; k < NEPI; ++k) {
-            const int it = tid + k * kFT, row = it / (TW * NOCT), rem = it - row * (TW * NOCT), px = rem / NOCT, part = rem - px * NOCT;
-            const int yo = t.y0 + row, xo = t.x0 + px;
-            const bool live = it < TR * TW * NOCT && yo < H && xo < W;
-            e_off[k] = live ? ((t.b * H + yo) * (size_t)W + xo) * C + 8 * part : ~(size_t)0;
-            xres[k] = live ? *reinterpret_cast<const uint4*>(x + e_off[k]) : uint4{0, 0, 0, 0};
-        }
-        // ---- phase C: dw2(mid) + v @ M + bias for this wave's units -> the output image ----
-        {
-            constexpr int NJ = (TR / 2 + RSPLIT - 1) / RSPLIT, NU = OPW * NJ;  // TR / 2 is a multiple of RSPLIT: every unit is live
-            static_assert((TR / 2) % RSPLIT == 0, "row pairs split evenly over the waves of an octet");
-            uint4 bq[3], bg[NK];
-            auto rd = [&](int u) {
-                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbC + (size_t)(2 * rp) * RP + i * PP + 128 * k);
-#pragma unroll
-                for (int t2 = 0; t2 < NK; ++t2) bg[t2] = *reinterpret_cast<const uint4*>(rbG + (size_t)(2 * rp) * RP + 32 * t2);
+                *reinterpret_cast<uint2*>(wbB + (size_t)(2 * (rpo + u)) * MP) = ov;
             };
             rd(0);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int k = u / NJ, rp = rp0 + (u % NJ) * RSPLIT;
+            for (int u = 0; u < NMID; u += UPB) {
+                const bool two = UPB == 2 && u + 1 < NMID;  // compile time after unrolling
+                float4_t acc[2] = {float4_t{0.f, 0.f, 0.f, 0.f}, float4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int k = 0; k < UPB; ++k) {
+                    if (u + k >= NMID) break;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], __builtin_bit_cast(half8_t, bq[k][i]), acc[k], 0, 0, 0);
+                }
+                if (u + UPB < NMID) rd(u + UPB);  // behind the MFMAs, in front of the GELUs and the stores (which the compiler will not let a later read pass)
+                if (two) {
+                    float2_t gp[4] = {float2_t{acc[0][0], acc[0][1]}, float2_t{acc[0][2], acc[0][3]}, float2_t{acc[1][0], acc[1][1]}, float2_t{acc[1][2], acc[1][3]}};
+                    gelu_multi<4>(gp);
+                    put(u, gp[0], gp[1]);
+                    put(u + 1, gp[2], gp[3]);
+                } else {
+                    float2_t gp[2] = {float2_t{acc[0][0], acc[0][1]}, float2_t{acc[0][2], acc[0][3]}};
+                    if constexpr (C >= 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
+                    put(u, gp[0], gp[1]);
+                }
+            }
+        }
+        stamp(2);
+        // ---- conv2(mid) + v @ M + bias + x for this wave's output units, stored from registers ----
+        {
+            uint4 bq[3], bg[NK];
+            auto rd = [&](int u) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbC + (size_t)(2 * (rpo + u)) * MP + i * PP);
+#pragma unroll
+                for (int t2 = 0; t2 < NK; ++t2) bg[t2] = *reinterpret_cast<const uint4*>(rbG + (size_t)(2 * (rpo + u)) * RP + 32 * t2);
+            };
+            rd(0);
+#pragma unroll
+            for (int u = 0; u < NOUT; ++u) {
                 float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[k][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
+                for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
 #pragma unroll
-                for (int t2 = 0; t2 < NK; ++t2) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[k][t2], __builtin_bit_cast(half8_t, bg[t2]), acc, 0, 0, 0);
-                if (u + 1 < NU) rd(u + 1);  // behind the MFMAs, in front of the stores (which the compiler will not let a later read pass)
-                if (n16 < TW)
-                    *reinterpret_cast<uint2*>(wbC + (size_t)(2 * rp) * OP + 128 * k) = uint2{pack_f16(acc[0] + bs[k][0], acc[1] + bs[k][1]), pack_f16(acc[2] + bs[k][2], acc[3] + bs[k][3])};
-            }
-        }
-        stamp(5);
-        __syncthreads();  // the output image is complete; mid and v are dead
-        stamp(6);
-        // ---- epilogue: + x (the block's residual, :183), whole pixels, 16-byte pieces (x was requested before phase C) ----
-        {
-#pragma unroll
-            for (int k = 0; k < NEPI; ++k) {
-                if (e_off[k] == ~(size_t)0) continue;
-                const int it = tid + k * kFT, row = it / (TW * NOCT), rem = it - row * (TW * NOCT), px = rem / NOCT, part = rem - px * NOCT;
-                const uint4 xa = xres[k];
-                const uint4 oa = *reinterpret_cast<const uint4*>(ot + (size_t)row * OP + (size_t)px * C * 2 + 16 * part);
-                const unsigned xw[4] = {xa.x, xa.y, xa.z, xa.w}, ow[4] = {oa.x, oa.y, oa.z, oa.w};
-                unsigned rw[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {  // float16 + float16 in float32, one rounding (v_fma_mix_f32: a * 1.0 + b takes both as they are)
+                for (int t2 = 0; t2 < NK; ++t2) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[t2], __builtin_bit_cast(half8_t, bg[t2]), acc, 0, 0, 0);
+                if (u + 1 < NOUT) rd(u + 1);
+                if (e_off[u] != ~(size_t)0) {  // ((pos_emb + projection) + bias) + x: the float16 residual taken as it is (v_fma_mix_f32: x * 1.0 + sum)
                     constexpr unsigned kOnes = 0x3c003c00u;
-                    float s0, s1;
-                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,1]" : "=v"(s0) : "v"(ow[j]), "v"(kOnes), "v"(xw[j]));
-                    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,1,1]" : "=v"(s1) : "v"(ow[j]), "v"(kOnes), "v"(xw[j]));
-                    rw[j] = pack_f16(s0, s1);
+                    float s0 = acc[0] + bs[0], s1 = acc[1] + bs[1], s2 = acc[2] + bs[2], s3 = acc[3] + bs[3];
+                    fma_mix_lo(s0, xr[u].x, kOnes); fma_mix_hi(s1, xr[u].x, kOnes);
+                    fma_mix_lo(s2, xr[u].y, kOnes); fma_mix_hi(s3, xr[u].y, kOnes);
+                    *reinterpret_cast<uint2*>(out + e_off[u]) = uint2{pack_f16(s0, s1), pack_f16(s2, s3)};
                 }
-                *reinterpret_cast<uint4*>(out + e_off[k]) = uint4{rw[0], rw[1], rw[2], rw[3]};
             }
         }
-        stamp(7);
+        stamp(3);
         if (next >= total) break;
         tile = next;
         walk = ahead;
         ahead.advance();
         t = tile_at(walk);
+        __syncthreads();  // every wave is done reading v: the next tile's may be written
+        stamp(4);
     }
     if constexpr (STAMP) {
         if (lane == 0 && stamps)
@@ -910,7 +907,7 @@ template <int C, int TR, int MINW>
 int launch_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack, const void* mpack, const void* dw1, const void* dw2, const float* bias, void* out, int B, int H, int W,
                         hipStream_t s) {
     constexpr int PP = C * 2 + 16, RP = (18 * PP + 255) / 256 * 256;
-    const size_t lds = (size_t)2 * (TR + 4) * RP + (size_t)TR * 14 * C * 2 + (size_t)(C / 32) * (C / 16) * 1024;
+    const size_t lds = (size_t)(TR + 4) * RP + (size_t)(TR + 2) * 16 * PP + (size_t)(C / 32) * (C / 16) * 1024;
     const long total = (long)B * ((H + TR - 1) / TR) * ((W + 13) / 14);
     const long cap = (long)ctx->num_cus * (MINW / 2);
     const unsigned blocks = (unsigned)(total < cap ? total : cap);
@@ -926,7 +923,7 @@ int launch_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack, const v
         AVX_HIP(ctx, hipMemcpy(h_st, d_st, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double tot[8] = {0}, all = 0;
         for (size_t i = 0; i < n; ++i) { tot[i & 7] += (double)h_st[i]; all += (double)h_st[i]; }
-        const char* nm[8] = {"fill+bar0", "phaseA", "bar1", "phaseB", "bar2", "phaseC", "bar3", "epilogue"};
+        const char* nm[8] = {"v from x", "bar1", "conv1+gelu", "conv2+proj+store", "bar2", "-", "-", "-"};
         fprintf(stderr, "[tail stamps C=%d] %u blocks, %ld tiles, mean cycles per wave %.0f:", C, blocks, total, all / (blocks * 8.0));
         for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, "  %s %.1f%%", nm[k2], 100 * tot[k2] / all);
         fprintf(stderr, "\n");

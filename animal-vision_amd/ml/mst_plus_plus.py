@@ -84,7 +84,7 @@ def pack_fragments(w_kn: torch.Tensor, transposed: bool) -> torch.Tensor:
 _FRAG_INDEX: Dict[tuple, torch.Tensor] = {}
 
 
-def pack_fragments16(w_kn: torch.Tensor) -> torch.Tensor:
+def pack_fragments16(w_kn: torch.Tensor, halfrow: bool = False) -> torch.Tensor:
     """(K x N) float16 weight of `y = x @ w` as the A operand of v_mfma_f32_32x32x16_f16 ("channels x pixels" results,
     csrc/mst_fused.hip): [N/32][K/16][64 lanes][8]; lane (m = lane % 32, h = lane // 32), element j of step s carries input
     channel 16 s + 8 h + j (natural K order) of output channel 32 t + perm(m), perm(m) = 16 ((m % 8) // 4) + 4 (m // 8) + m % 4 --
@@ -92,7 +92,7 @@ def pack_fragments16(w_kn: torch.Tensor) -> torch.Tensor:
     K, N = w_kn.shape
     assert K % 16 == 0 and N % 32 == 0
     dev = w_kn.device
-    key = (K, N, "k16", str(dev))
+    key = (K, N, "k16h" if halfrow else "k16", str(dev))
     idx = _FRAG_INDEX.get(key)
     if idx is None:
         lane = torch.arange(64, device=dev)
@@ -100,7 +100,10 @@ def pack_fragments16(w_kn: torch.Tensor) -> torch.Tensor:
         col = 16 * ((m % 8) // 4) + 4 * (m // 8) + m % 4
         s = torch.arange(K // 16, device=dev)
         j = torch.arange(8, device=dev)
-        k = (16 * s[:, None, None] + 8 * h[None, :, None] + j[None, None, :])[None]                    # (1, K/16, 64, 8)
+        if halfrow:  # step s of lane half h carries input channel h K/2 + 8 s + j: the order in which a lane holds its contiguous half row of x (operands straight from global memory)
+            k = (8 * s[:, None, None] + (K // 2) * h[None, :, None] + j[None, None, :])[None]
+        else:
+            k = (16 * s[:, None, None] + 8 * h[None, :, None] + j[None, None, :])[None]                    # (1, K/16, 64, 8)
         n = 32 * torch.arange(N // 32, device=dev)[:, None, None, None] + col[None, None, :, None]      # (N/32, 1, 64, 1)
         idx = (k * N + n).contiguous()
         _FRAG_INDEX[key] = idx
@@ -690,7 +693,7 @@ class MSTPlusPlus(torch.nn.Module):
                 xc = x.contiguous()
                 out = torch.empty_like(xc)
                 if tailx and _AVX._dwmx:  # both depthwise convs and the projection on the matrix pipe
-                    wv16 = self._prep(p + ".wv.frag16", lambda: pack_fragments16(wqkv[:, 2 * c :].contiguous()))
+                    wv16 = self._prep(p + ".wv.frag16h", lambda: pack_fragments16(wqkv[:, 2 * c :].contiguous(), halfrow=True))
                     d1 = self._prep(k1 + ".dwmx", lambda: pack_dw_mfma(self._w(k1, (0,))))
                     d2 = self._prep(k2 + ".dwmx", lambda: pack_dw_mfma(self._w(k2, (0,))))
                     for i in range(b):

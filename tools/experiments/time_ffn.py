@@ -35,7 +35,8 @@ for c, div, pfx in ((32, 1, "body.0.encoder_layers.0.0"), (64, 2, "body.0.encode
         d1 = pack_dw_mfma(m._w(p + ".pos_emb.0.weight", (0,))); d2 = pack_dw_mfma(m._w(p + ".pos_emb.2.weight", (0,)))
         mp = _AVX.attn_pack_mx(gram, nq, nk, resc, wpt)
         o = torch.empty_like(x[0])
-        us3 = t(lambda: _AVX.attn_tail_mx(x[0], wv16, mp, d1, d2, b32, o))
+        wv16h = pack_fragments16(wqkv[:, 2 * c:].contiguous(), halfrow=True)
+        us3 = t(lambda: _AVX.attn_tail_mx(x[0], wv16h, mp, d1, d2, b32, o))
         t1 = m._w(p + ".pos_emb.0.weight", (0,)).reshape(c, 9).t().contiguous(); t2 = m._w(p + ".pos_emb.2.weight", (0,)).reshape(c, 9).t().contiguous()
         m16 = _AVX.attn_pack16(gram, nq, nk, resc, wpt)
         us4 = t(lambda: _AVX.attn_tail_x(x[0], wv16, m16, t1, t2, b32, o))
