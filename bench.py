@@ -22,9 +22,9 @@ synchronise with torch.distributed (RCCL on the box): barriers and the max-over-
 stream is sharded round-robin (frame i -> rank i mod N), no data-path collective ("weak" for the device-resident value).
 
 `roofline`: HBM-bound workloads = algorithmic bytes per launch / the launch's duration from HIP events on the
-kernel's own stream; the MST++ route (~110 launches per frame) reports its HBM side -- algorithmic bytes of one forward pass at the
-current fusion level / step time, `traffic` = PMC-measured bytes -- with the MFMA view (`mfma`) and the dominant kernel
-timed on its own (`dominant_kernel`) beside it.  `cpu_baseline` = the
+kernel's own stream; the MST++ route (98 launches per frame) reports SURVEY 8(d)'s quantity -- 703.4 kFLOP per pixel x pixels per step / step
+time against the dense float16 matrix peak (`bound: "mfma"`) -- with the byte view at the current fusion level (`hbm_at_fusion_level`, `traffic` =
+PMC-measured bytes), the vector unit's view (`valu`: the resource that binds) and the dominant kernel timed on its own (`dominant_kernel`) beside it.  `cpu_baseline` = the
 oracle (or, for the network, this repo's CPU float32 port of it) timed on this box's host cores on a bounded sample (rank 0)."""
 import argparse
 import json
@@ -52,7 +52,7 @@ WORKLOADS = {
     "honeybee_1080p": ("honeybee", 1080, 1920, 8),
     "honeybee_4k": ("honeybee", 2160, 3840, 4),
     "honeybee_mst_1080p": ("honeybee_mst", 1080, 1920, 2),
-    "honeybee_mst_4k": ("honeybee_mst", 2160, 3840, 2),
+    "honeybee_mst_4k": ("honeybee_mst", 2160, 3840, 4),  # 4 frames per step on 2 lanes: the default 20 steps time 80 4K frames (>= 64)
     # BASELINE config 5: standalone spectral integration of an fp16 NHWC cube, (N bands-out, B bands-in) = (12,31), (10,81)
     "spectral_4k_12x31": ("spectral:12x31", 2160, 3840, 8),
     "spectral_4k_10x81": ("spectral:10x81", 2160, 3840, 8),
@@ -63,14 +63,44 @@ WORKLOADS = {
     **{f"{m}_{r}": (f"uv:{m}", h, w, 4 if r == "1080p" else 2) for m in UV_MODULES for r, h, w in (("1080p", 1080, 1920), ("4k", 2160, 3840))},
 }
 HEADLINE = "honeybee_mst_4k"
-HEADLINE_LEGS = ("dog_1080p", "dog_4k", "honeybee_mst_1080p", "cat_1080p")
+HEADLINE_LEGS = ("dog_1080p", "dog_4k", "honeybee_mst_1080p", "cat_1080p",
+                 # BASELINE config 5 (standalone spectral integration) and the non-headline species, under the driver's clock
+                 "spectral_4k_12x31", "spectral_4k_10x81", "mantis_4k", "honeybee_4k", "hummingbird_1080p")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
 MFMA_FP16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, same guide
 MSTPP_FLOP_PER_PX = 703.4e3  # 2 x 351.7 kMAC/px (23.05 GMAC at 256x256)
+# The vector unit's side of one MST++ forward pass, per full-resolution pixel: what the network's arithmetic needs at the very least
+# once the GEMM-shaped work AND the depthwise convs (16,848 MACs / px) are on the matrix pipe.  Counted in wave64 issue slots per lane ("lane-instructions"):
+#   2,808 GELUs (15 blocks: 2 x 4C hidden + C pos_emb channels each, at the block's resolution) x 5 (ten packed float32 operations per PAIR, degree 5)
+#   + 1,404 float16 conversions of their results (one v_cvt_pk_f16_f32 per pair) + 312 LayerNorm elements x 5 (sum, centre, square, scale + shift, half a conversion)
+VALU_MIN_LANE_INSTR_PER_PX = 2808 * 5 + 1404 + 312 * 5
+VALU_PEAK_LANE_INSTR_PER_S = 1024 * 16 * 2.4e9  # 1,024 SIMDs x 16 lanes per clock (a wave64 instruction holds its SIMD for 4 cycles) x 2.4 GHz
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def host_info():
+    """What SURVEY 8(d) asks the CPU baseline to state: affinity, core count, CPU model, thread environment."""
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    info = {"cpu_model": model, "cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+            "thread_env": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS") if os.environ.get(k) is not None}}
+    try:
+        import torch
+
+        info["torch_num_threads"] = int(torch.get_num_threads())
+    except Exception:  # noqa: BLE001
+        pass
+    return info
 
 
 def parse_args(argv=None):
@@ -252,7 +282,7 @@ class Workload:
                 from animal_vision_amd.runtime import DeviceBuffer
 
                 torch.cuda.set_device(env.local_rank)
-                mst = self.mst = MSTPlusPlusPredictor(None, seed=0, half=True, device=f"cuda:{env.local_rank}")
+                mst = self.mst = MSTPlusPlusPredictor(None, seed=0, half=True, device=f"cuda:{env.local_rank}").prepare()  # derived weights built and waited for before the lanes start
                 t_in = self.t_in = torch.from_numpy(batch_arr).cuda()
                 t_out = self.t_out = torch.empty_like(t_in)
                 ctx.stream_destroy(stream)
@@ -315,7 +345,8 @@ class Workload:
             self.run_step()
         ev_ms = ctx.timer_stop(self.stream)  # HIP events on the launch stream; also fences it
         env.barrier(ctx)
-        elapsed = env.max_over_ranks(time.perf_counter() - t0)
+        self.elapsed_local = time.perf_counter() - t0
+        elapsed = env.max_over_ranks(self.elapsed_local)
         return elapsed, ev_ms
 
     def steps_for(self, seconds, probe=3):
@@ -354,9 +385,10 @@ class Workload:
             us = self.ctx.timer_stop(self.stream) * 1e3 / reps
             byts = 128.0 * Hp * Wp
             gbs = byts / (us * 1e-6) / 1e9
-            return {"kernel": "k_mst_ffn_fused<32> (LayerNorm -> 1x1 -> GELU -> dw3x3 -> GELU -> 1x1 -> + x, one launch)", "bound": "hbm", "us_per_launch": round(us, 1),
+            return {"kernel": "k_mst_ffn_fused<32> (LayerNorm -> 1x1 -> GELU -> dw3x3 on the matrix pipe -> GELU -> 1x1 -> + x, one launch)", "bound": "hbm", "us_per_launch": round(us, 1),
                     "algorithmic_bytes": int(byts), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "note": "VALU-bound (PMC: vector unit 90 % busy; 256 + 70 GELUs and 1,152 depthwise MACs per pixel), DESIGN 4.3"}
+                    "mfma_tflops": round(16.4e3 * Hp * Wp / (us * 1e-6) / 1e12, 1),
+                    "note": "bound by the vector unit (GELU arithmetic: 256 + 70 GELUs per pixel; the 1,152 depthwise MACs per pixel run on the matrix pipe since round 3), DESIGN 4.3"}
         except Exception as e:  # noqa: BLE001  (a diagnostic: never fail the bench line over it)
             log(f"dominant-kernel timing skipped: {type(e).__name__}: {e}")
             return None
@@ -399,11 +431,22 @@ class Workload:
             bpp = hbm_bytes_per_px()
             gbs = bpp * B * H * W / launch_s / 1e9
             tf = MSTPP_FLOP_PER_PX * B * H * W / launch_s / 1e12
-            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            vi = VALU_MIN_LANE_INSTR_PER_PX * B * H * W / launch_s
+            # the MST++ route's roofline is the dense float16 matrix peak: 703.4 kFLOP per pixel x pixels per step / step time against 2.5 PFLOP/s
+            # (reproducible from this line alone: flop_per_px x pixels_per_step / (us_per_launch x 1e-6) / 1e12).  Beside it: the byte view at the current
+            # fusion level (what the launches must move, ml/mst_plus_plus.py::hbm_bytes_per_px; `traffic` = PMC-measured bytes), the vector unit's view (the
+            # resource that binds: GELU arithmetic) and the dominant kernel timed on its own.
+            roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5), "traffic": None,
                     "kernel": "MST++ forward (fused MSAB kernels, fp16) + honeybee tail, whole step", "us_per_launch": round(launch_s * 1e6, 2),
-                    "algorithmic_bytes_per_px": round(bpp, 1),
-                    "mfma": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_FP16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 5),
-                             "note": "703 kFLOP/px (BASELINE.md) against the dense fp16 peak: the blocks are VALU-bound (GELU, depthwise convs), not MFMA-bound"}}
+                    "flop_per_px": MSTPP_FLOP_PER_PX, "pixels_per_step": B * H * W,
+                    "note": "703.4 kFLOP/px (BASELINE.md) against the dense fp16 peak; the blocks are bound by the vector unit (GELU), see `valu`",
+                    "hbm_at_fusion_level": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                            "algorithmic_bytes_per_px": round(bpp, 1),
+                                            "note": "bytes crossing THIS build's launch boundaries (falls whenever two kernels are fused): not SURVEY 8(d)'s quantity, kept for continuity with round 2"},
+                    "valu": {"bound": "valu", "achieved": round(vi / 1e12, 3), "peak": round(VALU_PEAK_LANE_INSTR_PER_S / 1e12, 3), "unit": "T lane-instructions/s",
+                             "frac": round(vi / VALU_PEAK_LANE_INSTR_PER_S, 4), "min_lane_instr_per_px": VALU_MIN_LANE_INSTR_PER_PX,
+                             "note": "minimal vector work of the network per pixel (2,808 GELUs x 5 + conversions + LayerNorm; the 16,848 depthwise MACs run on the matrix pipe) "
+                                     "x pixels / step time against 1,024 SIMDs x 16 lanes x 2.4 GHz; measured: see `valu_measured` (PMC SQ_INSTS_VALU, profiles/)"}}
             dom = self.dominant_kernel()
             if dom:
                 roof["dominant_kernel"] = dom
@@ -425,6 +468,9 @@ class Workload:
             elif pmc and self.mst is not None:  # measured per frame (one frame per step); a step is B independent frames
                 roof["traffic"] = int(pmc["hbm_bytes_per_launch"] * B / pmc["frames_per_launch"])
                 roof["traffic_note"] = pmc["note"] + f"; x{B} frames per step"
+                if "valu_wave_instr_per_frame" in pmc:  # PMC SQ_INSTS_VALU summed over one frame's launches (wave instructions; x 64 lanes)
+                    roof["valu"]["valu_measured"] = {"wave_instr_per_frame": pmc["valu_wave_instr_per_frame"], "lane_instr_per_px": round(pmc["valu_wave_instr_per_frame"] * 64.0 / (H * W), 1),
+                                                     "note": pmc.get("valu_note", "")}
         except (OSError, ValueError):
             pass
         return {"value": round(value, 1), "unit": "MP/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
@@ -475,7 +521,7 @@ class Workload:
                 if time.perf_counter() - t0 > seconds or n >= 16:
                     break
             t = time.perf_counter() - t0
-            return {"value": round(n * 512 * 512 / 1e6 / t, 3), "unit": "MP/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            return {"value": round(n * 512 * 512 / 1e6 / t, 3), "unit": "MP/s", "cores": int(torch.get_num_threads()), "kind": "port", **host_info(),
                     "sample": f"{n} x (MST++ float32 forward on the CPU, this repo's torch port, {torch.get_num_threads()} torch threads of {ncores} cores available + "
                               f"oracle honeybee tail) on a 512x512 crop of the frame"}
         fn, name = self.cpu_fn()
@@ -488,7 +534,7 @@ class Workload:
                 break
         t = time.perf_counter() - t0
         px = 960 * 540 if self.spectral else H * W
-        return {"value": round(n * px / 1e6 / t, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+        return {"value": round(n * px / 1e6 / t, 2), "unit": "MP/s", "cores": 1, "kind": "port", **host_info(),
                 "sample": (f"{n} frames {W}x{H} through {name}, 1 thread of {ncores} available" if not self.spectral
                            else f"{n} x {name}, BLAS threads as configured ({ncores} cores available)")}
 
@@ -588,8 +634,11 @@ def c4_stream(env, n_frames, seconds_cap=60.0):
     from animal_vision_amd.renderers import VideoRenderer
 
     H, W = 2160, 3840
-    out = {"frames": n_frames, "size": f"{W}x{H}", "scaling": "strong", "sharding": f"round-robin x{env.world}",
-           "note": "PCIe-inclusive whole-job rate: host frame -> pinned -> H2D -> kernels -> D2H -> host frame, per-rank 3 frames in flight; sink = none (frames dropped after D2H)"}
+    out = {"frames": n_frames, "size": f"{W}x{H}", "scaling": "strong", "sharding": f"round-robin x{env.world}", "split_compare": True,
+           "note": "main.py:60-72's loop, PCIe-inclusive whole-job rate: host frame -> pinned -> H2D -> kernels -> device split-compose (original | transformed, seam, two corner labels: "
+                   "renderers/video.py:198-245) -> D2H -> host frame, per-rank 3 frames in flight; sink = none (the composed frames are dropped after D2H: no codec). "
+                   "dog moves 2 x 25 MB per frame through host memory at ~1,000 frames/s per rank (host_copy_s: the slowest rank's seconds in pageable <-> pinned copies): N ranks "
+                   "want N x ~50 GB/s of host memcpy and will NOT scale to 8 ranks on one host -- the honeybee-MST++ stream (compute-bound, ~45 frames/s per rank) is the scaling leg"}
     torch.cuda.set_device(env.local_rank)
     for name in ("dog", "honeybee_mst"):
         kind = "noise" if name == "dog" else "structured"
@@ -603,12 +652,21 @@ def c4_stream(env, n_frames, seconds_cap=60.0):
             vr.open()
             env.barrier()
             t0 = time.perf_counter()
-            st = run_video(op, vr, rank=env.rank, world=env.world, depth=3, dist=env.dist)
+            st = run_video(op, vr, rank=env.rank, world=env.world, depth=3, dist=env.dist, split_compare=True)
             torch.cuda.synchronize()
             env.barrier()
             wall = env.max_over_ranks(time.perf_counter() - t0)
             vr.close()
-        out[name] = {"frames_per_s": round(st.frames / wall, 2), "MP_per_s": round(st.frames * H * W / 1e6 / wall, 1), "seconds": round(wall, 3), "frames": st.frames}
+        out[name] = {"frames_per_s": round(st.frames / wall, 2), "MP_per_s": round(st.frames * H * W / 1e6 / wall, 1), "seconds": round(wall, 3), "frames": st.frames,
+                     "host_copy_s": round(st.host_copy_seconds, 3)}
+        # strong-scaling efficiency against the one-GPU rate carried in profiles/ (the driver computes its own from the per-N lines; this is for reading one record alone)
+        try:
+            ref = json.load(open(os.path.join(ROOT, "profiles", "c4_stream_n1.json"))).get(name)
+            if ref and env.world > 1:
+                out[name]["efficiency_vs_n1"] = round(out[name]["frames_per_s"] / (env.world * ref["frames_per_s"]), 3)
+                out[name]["n1_frames_per_s"] = ref["frames_per_s"]
+        except (OSError, ValueError):
+            pass
         del op
     return out
 
@@ -637,6 +695,7 @@ def worker(args):
     wl = Workload(name, env, args.batch, args.frames)
     steps, warmup = args.steps, args.warmup
     elapsed, ev_ms = wl.time(steps, warmup, args.ramp_ms)
+    elapsed_local = wl.elapsed_local
     rep = wl.report(steps, warmup, elapsed, ev_ms)
     result = {
         "metric": "megapixels/sec per-frame pipeline",
@@ -645,6 +704,18 @@ def worker(args):
         "config": {"workload": rep["workload"], "name": name, "frames_per_step_per_gpu": wl.B, "fps": rep["fps"], "sharding": f"round-robin x{env.world}"},
         "roofline": rep["roofline"],
     }
+    if env.world > 1:  # what a SCALE record needs to be read on its own: every rank arrived, and how far apart the ranks ran
+        import torch
+
+        seen = torch.ones(1, dtype=torch.float64, device="cuda")
+        env.dist.all_reduce(seen)
+        mine = elapsed_local / steps * 1e3
+        lo = torch.tensor([mine], dtype=torch.float64, device="cuda")
+        hi = lo.clone()
+        env.dist.all_reduce(lo, op=env.dist.ReduceOp.MIN)
+        env.dist.all_reduce(hi, op=env.dist.ReduceOp.MAX)
+        result["ranks_seen"] = int(seen.item())
+        result["ms_per_step_ranks"] = {"min": round(float(lo.item()), 4), "max": round(float(hi.item()), 4)}
     lead = env.rank == 0 and env.world == 1
     if lead:
         ok, stats = wl.parity()
@@ -669,7 +740,7 @@ def worker(args):
                 r["parity_checked"] = ok
                 if stats:
                     r["parity_stats"] = stats
-                if not args.no_cpu_baseline and leg in ("dog_1080p", "cat_1080p"):
+                if not args.no_cpu_baseline and leg in ("dog_1080p", "cat_1080p", "spectral_4k_12x31"):
                     r["cpu_baseline"] = w2.cpu_baseline(min(args.cpu_seconds, 8.0))
                 if leg == "dog_4k" and not args.no_e2e:
                     r["e2e_pcie"] = w2.e2e_pcie()
