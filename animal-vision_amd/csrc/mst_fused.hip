@@ -298,6 +298,10 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 unsigned char* wbase = ht + (size_t)(q >> 1) * RPITCH + (size_t)n16 * HPITCH + 16 * wave + 8 * (q & 1);        // + 2p RPITCH + 128 o2
                 // The map is read and written in place, so the compiler keeps every LDS read behind the previous unit's store (it cannot tell the bytes apart):
                 // the reads of unit u + 1 are therefore issued by hand right behind unit u's MFMAs, in front of its GELU and store -- one LDS round trip per unit less on the wave's clock.
+                // Software pipeline, one unit deep (the wave issues in order, and the compiler keeps every LDS read behind the previous store to the same array):
+                //   unit u's three MFMAs | the reads of unit u + 1 (into the operand registers the MFMAs have just consumed) | GELU + store of unit u - 1
+                // so an LDS round trip and the matrix pipe's latency both pass under the previous unit's GELU.  sched_barrier pins that order (left alone, the
+                // scheduler hoists unit u + 1's first MFMA up against its reads and the wave waits out the LDS latency once per unit).
                 constexpr int NU = NOCT * (TS / 2);
                 uint4 bq[3];
                 auto rd = [&](int u) {
@@ -305,19 +309,42 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
 #pragma unroll
                     for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 128 * o2);
                 };
-                constexpr bool AHEAD = C != 128;  // C = 128: the read-ahead's registers spill
-                if constexpr (AHEAD) rd(0);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
+                auto finish = [&](int u, float4_t a) {
                     const int o2 = u / (TS / 2), pr = u % (TS / 2);
-                    if constexpr (!AHEAD) rd(u);
-                    float4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
-                    if (AHEAD && u + 1 < NU) rd(u + 1);  // the MFMAs have taken their operands: the same registers receive the next unit's while this one's GELU runs
-                    float2_t gp[2] = {float2_t{acc[0], acc[1]}, float2_t{acc[2], acc[3]}};
+                    float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
                     if constexpr (C == 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
                     *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 128 * o2) = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
+                };
+#ifndef AVX_FFN_PIPE_ALL
+#define AVX_FFN_PIPE_ALL 0
+#endif
+                constexpr bool PIPE = C == 64 || AVX_FFN_PIPE_ALL;  // C = 32 / 128: not a register to spare (the lagging accumulator spills); measured, same-box A/B
+                if constexpr (PIPE) {
+                    rd(0);
+                    float4_t prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int o2 = u / (TS / 2);
+                        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
+                        if (u + 1 < NU) rd(u + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (u > 0) finish(u - 1, prev);
+                        __builtin_amdgcn_sched_barrier(0);
+                        prev = acc;
+                    }
+                    finish(NU - 1, prev);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int o2 = u / (TS / 2);
+                        rd(u);
+                        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
+                        finish(u, acc);
+                    }
                 }
                 stamp(3);
                 __syncthreads();  // the GELU'd depthwise map is complete
@@ -815,19 +842,16 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
         // ---- conv1 + GELU -> mid, this wave's octet, mid row pairs rpo ... rpo + NOUT (zero outside the image: the second conv's padding applies to THIS map) ----
         {
             const bool mid_inside = t.y0 >= 1 && t.y0 + MR - 1 <= H && t.x0 >= 1 && t.x0 + 15 <= W;  // scalar
-            // units UPB at a time (two where the registers allow: four GELU pairs then advance together, gelu_multi); NMID is odd: the last step carries one unit
-            constexpr int UPB = C >= 64 ? 2 : 1;
-            uint4 bq[UPB][3];
+            // software pipeline, one unit deep (as k_mst_ffn_fused's phase 2a): unit u's MFMAs | reads of unit u + 1 | GELU + store of unit u - 1
+            uint4 bq[3];
             auto rd = [&](int u) {
 #pragma unroll
-                for (int k = 0; k < UPB; ++k) {
-                    if (u + k >= NMID) break;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) bq[k][i] = *reinterpret_cast<const uint4*>(rbB + (size_t)(2 * (rpo + u + k)) * RP + i * PP);
-                }
+                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbB + (size_t)(2 * (rpo + u)) * RP + i * PP);
             };
-            auto put = [&](int u, float2_t ga, float2_t gb) {
-                uint2 ov = uint2{pack_f16(ga.x, ga.y), pack_f16(gb.x, gb.y)};
+            auto finish = [&](int u, float4_t a) {
+                float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
+                if constexpr (C >= 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
+                uint2 ov = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
                 if (!mid_inside) {
                     const int yy = t.y0 - 1 + 2 * (rpo + u) + (q >> 1), xx = t.x0 - 1 + n16;
                     const unsigned keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
@@ -836,28 +860,19 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
                 *reinterpret_cast<uint2*>(wbB + (size_t)(2 * (rpo + u)) * MP) = ov;
             };
             rd(0);
+            float4_t prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < NMID; u += UPB) {
-                const bool two = UPB == 2 && u + 1 < NMID;  // compile time after unrolling
-                float4_t acc[2] = {float4_t{0.f, 0.f, 0.f, 0.f}, float4_t{0.f, 0.f, 0.f, 0.f}};
+            for (int u = 0; u < NMID; ++u) {
+                float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < UPB; ++k) {
-                    if (u + k >= NMID) break;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], __builtin_bit_cast(half8_t, bq[k][i]), acc[k], 0, 0, 0);
-                }
-                if (u + UPB < NMID) rd(u + UPB);  // behind the MFMAs, in front of the GELUs and the stores (which the compiler will not let a later read pass)
-                if (two) {
-                    float2_t gp[4] = {float2_t{acc[0][0], acc[0][1]}, float2_t{acc[0][2], acc[0][3]}, float2_t{acc[1][0], acc[1][1]}, float2_t{acc[1][2], acc[1][3]}};
-                    gelu_multi<4>(gp);
-                    put(u, gp[0], gp[1]);
-                    put(u + 1, gp[2], gp[3]);
-                } else {
-                    float2_t gp[2] = {float2_t{acc[0][0], acc[0][1]}, float2_t{acc[0][2], acc[0][3]}};
-                    if constexpr (C >= 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
-                    put(u, gp[0], gp[1]);
-                }
+                for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
+                if (u + 1 < NMID) rd(u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u > 0) finish(u - 1, prev);
+                __builtin_amdgcn_sched_barrier(0);
+                prev = acc;
             }
+            finish(NMID - 1, prev);
         }
         stamp(2);
         // ---- conv2(mid) + v @ M + bias + x for this wave's output units, stored from registers ----
@@ -1432,14 +1447,19 @@ static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, con
                            (const uint4*)w2pack, (__half*)out, B, H, W, (const uint4*)dwpack, (unsigned long long*)nullptr);                     \
     }
 #define AVX_FFN(CV, HP, MW) { if (dwpack) AVX_FFN1(CV, HP, MW, true) else AVX_FFN1(CV, HP, MW, false) }
-    if (C == 32 && small && dwpack && getenv("AVX_FFN_STAMPS")) {  // diagnostic: per-segment cycles of every wave, summed and printed
-        auto k = k_mst_ffn_fused<32, 64, 4, true, true>;
+    if (dwpack && getenv("AVX_FFN_STAMPS") && ((C == 32 && small) || C == 64 || C == 128)) {  // diagnostic: per-segment cycles of every wave, summed and printed
         unsigned long long* d_st = nullptr;
         const size_t n = (size_t)grid.x * 64;
         AVX_HIP(ctx, hipMalloc((void**)&d_st, n * sizeof(unsigned long long)));
-        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid, (const uint4*)w2pack, (__half*)out, B, H, W,
-                           (const uint4*)dwpack, d_st);
+#define AVX_FFN_ST(CV, HP, MW)                                                                                                                   \
+    {                                                                                                                                            \
+        auto k = k_mst_ffn_fused<CV, HP, MW, true, true>;                                                                                        \
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
+        hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid,      \
+                           (const uint4*)w2pack, (__half*)out, B, H, W, (const uint4*)dwpack, d_st);                                             \
+    }
+        if (C == 32) AVX_FFN_ST(32, 64, 4) else if (C == 64) AVX_FFN_ST(64, 128, 2) else AVX_FFN_ST(128, 64, 2)
+#undef AVX_FFN_ST
         AVX_HIP(ctx, hipStreamSynchronize(s));
         unsigned long long* h_st = (unsigned long long*)malloc(n * sizeof(unsigned long long));
         AVX_HIP(ctx, hipMemcpy(h_st, d_st, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1447,7 +1467,7 @@ static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, con
         for (size_t i = 0; i < n; ++i) { tot[i & 7] += (double)h_st[i]; if (((i >> 3) & 7) == 0) w0[i & 7] += (double)h_st[i]; if (((i >> 3) & 7) == 7) w7[i & 7] += (double)h_st[i]; }
         double all = 0;
         for (int k2 = 0; k2 < 8; ++k2) all += tot[k2];
-        fprintf(stderr, "[ffn stamps] %u blocks, mean cycles per wave %.0f; share per segment (all waves | wave 0 | wave 7): ", grid.x, all / (grid.x * 8.0));
+        fprintf(stderr, "[ffn stamps C=%d] %u blocks, mean cycles per wave %.0f; share per segment (all waves | wave 0 | wave 7): ", C, grid.x, all / (grid.x * 8.0));
         const char* nm[8] = {"bar1", "phase1", "bar2", "phase2a", "bar3", "phase2b", "epilogue", "ln+fetch"};
         for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, "%s %.1f%% | %.1f%% | %.1f%%  ", nm[k2], 100 * tot[k2] / all, 100 * w0[k2] * 8 / all, 100 * w7[k2] * 8 / all);
         fprintf(stderr, "\n");
