@@ -84,20 +84,28 @@ struct TileWalk {
 // no other wave touches (its bytes are another octet's); (2b) after a barrier the second GEMM reads its B fragments from that map with the
 // same 16-byte reads the depthwise conv used to issue.  One ADDRESS register serves all of 2a (row pair, column shift and octet are
 // immediates), the taps need no LDS, and the vector unit is left with the GELUs.
-template <int C, int HPASS, int MINW, bool DWM, bool STAMP = false>
-__global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
+// NW: waves per workgroup.  8 everywhere in round 2; 16 (one 1024-thread workgroup per CU, 128 registers per lane) for the 62-channel blocks since round 3: their
+// 143 KB of LDS admit one workgroup per CU, and at 8 waves the vector unit saw 2 waves per SIMD -- half of what it needs to issue back to back.  With 16 waves a pass's
+// 16 octets map one to a wave in phase 2a, the 44 phase 1 items are 3 + 3 + 3 + 2 per channel tile, and in phase 2b a wave owns a row pair x ONE 32-channel output tile.
+template <int C, int HPASS, int MINW, bool DWM, bool STAMP = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* __restrict__ x /*[B][H][W][C]*/, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, const uint4* __restrict__ w1pack /*[4C/32][C/16][64]*/, const __half* __restrict__ taps /*[9][4C]*/,
                                                           const uint4* __restrict__ w2pack /*[C/32][4C/16][64]*/, __half* __restrict__ out /*[B][H][W][C], != x*/, int B,
                                                           int H, int W, const uint4* __restrict__ dwpack /*[4C/8][3][64], DWM only*/, unsigned long long* __restrict__ stamps /*STAMP: [blocks][8 waves][8 segments] cycles*/) {
     constexpr int HID = 4 * C, NPASS = HID / HPASS, KS1 = C / 16, KS2 = HPASS / 16, NT = C / 32, YPITCH = C * 2 + 16, LNV = C / 16;
     constexpr int HPITCH = HPASS * 2 + 16, RPITCH = (HS * HPITCH + 255) / 256 * 256, NCT = HPASS / 32;  // channel tiles of 32 per pass
     static_assert(C == 32 || C == 64 || C == 128, "31-, 62- or 124-channel blocks (stored 32 / 64 / 128 wide)");
+    constexpr int NTHR = 64 * NW, NGW = (NGRP + NW - 1) / NW;  // threads; halo pixel groups per wave
+    constexpr int NTW = NT / (NW / 8), NOCTW = HPASS / (8 * NW);  // 32-channel output tiles per wave (phase 2b / epilogue); octets per wave and pass (phase 2a)
+    static_assert((NW == 8 || NW == 16) && NT % (NW / 8) == 0 && (!DWM || HPASS % (8 * NW) == 0) && (DWM || NW == 8), "wave split");
     constexpr bool PREFETCH = C <= 64;  // the next tile's raw rows wait in registers during phase 2 (C = 128: 64 registers that the accumulators need)
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* yt = smem;                                       // [NGRP * 32][YPITCH]  LayerNorm'd rows, float16
     unsigned char* ht = yt + (size_t)NGRP * 32 * YPITCH;             // [HS rows][RPITCH]: [HS px][HPITCH]  hidden map of the halo region, float16
-    __half* tapl = reinterpret_cast<__half*>(ht + (size_t)HS * RPITCH);  // [9][HID]
-    float* gl = reinterpret_cast<float*>(tapl + 9 * HID);            // [C] gamma, [C] beta
+    __half* tapl = reinterpret_cast<__half*>(ht + (size_t)HS * RPITCH);  // [9][HID] (not with DWM: no table, no space)
+    float* gl = reinterpret_cast<float*>(tapl + (DWM ? 0 : 9 * HID));  // [C] gamma, [C] beta
+    constexpr bool W2LDS = NW == 16;  // 128 registers per lane: the second GEMM's fragments of a pass wait in LDS (16 KB), not in 32 registers through phase 2a
+    uint4* w2l = reinterpret_cast<uint4*>(gl + 2 * C);               // W2LDS: [NT][KS2][64] this pass's W2 fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
     // STAMP (diagnostic instantiation, AVX_FFN_STAMPS=1): cycles this wave spends per segment -- 0 top barrier, 1 phase 1, 2 barrier, 3 phase 2a (or the
     // whole vector-unit phase 2), 4 barrier, 5 phase 2b, 6 epilogue, 7 LayerNorm + fetch
@@ -111,27 +119,27 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     };
     if constexpr (STAMP) tlast = __builtin_readcyclecounter();
     if constexpr (!DWM)
-        for (int i = tid; i < 9 * HID; i += kFT) tapl[i] = taps[i];
-    for (int i = tid; i < C; i += kFT) { gl[i] = gamma[i]; gl[C + i] = beta[i]; }
+        for (int i = tid; i < 9 * HID; i += NTHR) tapl[i] = taps[i];
+    for (int i = tid; i < C; i += NTHR) { gl[i] = gamma[i]; gl[C + i] = beta[i]; }
     const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
     const long total = (long)B * ty * tx;
     auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };  // (TileWalk measured 2 % slower in THIS kernel: the divisions run on the scalar unit beside a saturated vector unit)
     const float cnt = (float)(NT * 31);
 
     // ---- phase 0, split: fetch the raw rows of this wave's halo pixel groups (wave w: groups w and w + 8) ----
-    uint4 raw[2][LNV];
-    unsigned f_rel[2];  // this lane's halo pixel (group wave + 8 gi), as a byte offset from the halo origin (y0 - 1, x0 - 1): scalar base + lane offset when the halo lies inside the frame
+    uint4 raw[NGW][LNV];
+    unsigned f_rel[NGW];  // this lane's halo pixel (group wave + 8 gi), as a byte offset from the halo origin (y0 - 1, x0 - 1): scalar base + lane offset when the halo lies inside the frame
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-        const int q = 32 * (wave + 8 * gi) + p, qq = q < NHALO ? q : NHALO - 1;
+    for (int gi = 0; gi < NGW; ++gi) {
+        const int q = 32 * (wave + NW * gi) + p, qq = q < NHALO ? q : NHALO - 1;
         f_rel[gi] = (unsigned)(((qq / HS) * W + qq % HS) * C + h * (C / 2)) * 2u;
     }
     auto fetch = [&](const Tile& t) {
         if (t.y0 >= 1 && t.y0 + HS - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W) {  // all but the frame's border tiles: no clamping, no 64-bit lane arithmetic
             const char* origin = reinterpret_cast<const char*>(x + ((t.b * H + t.y0 - 1) * (size_t)W + t.x0 - 1) * C);
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                if (wave + 8 * gi >= NGRP) break;
+            for (int gi = 0; gi < NGW; ++gi) {
+                if (wave + NW * gi >= NGRP) break;
                 unsigned o = f_rel[gi];
                 asm volatile("" : "+v"(o));  // keeps the zero-extension here (hoisted out of the tile loop it becomes a 64-bit lane address)
                 const uint4* src = reinterpret_cast<const uint4*>(origin + o);
@@ -141,8 +149,8 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             return;
         }
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int g = wave + 8 * gi;
+        for (int gi = 0; gi < NGW; ++gi) {
+            const int g = wave + NW * gi;
             if (g >= NGRP) break;
             const int q = 32 * g + p, qq = q < NHALO ? q : NHALO - 1;
             int yy = t.y0 - 1 + qq / HS, xx = t.x0 - 1 + qq % HS;
@@ -155,8 +163,8 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     };
     auto layernorm = [&]() {  // lane (p, h) holds channels [h * C/2, (h + 1) * C/2) of halo pixel 32 g + p
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int g = wave + 8 * gi;
+        for (int gi = 0; gi < NGW; ++gi) {
+            const int g = wave + NW * gi;
             if (g >= NGRP) break;
             // float16 values enter through v_fma_mix_f32 (x * 1.0 + c): the sum and the centring cost one instruction per element, no conversions
             constexpr unsigned kOnes = 0x3c003c00u;
@@ -193,14 +201,15 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
         }
     };
 
-    half8_t w2f[NT * KS2];  // the second GEMM's A fragments of one pass: resident for the whole launch when there is one pass
+    const int n0 = (wave / 8) * NTW, w8 = wave % 8;  // this wave's first output tile and its row pair (phase 2b, epilogue)
+    half8_t w2f[W2LDS ? 1 : NTW * KS2];  // the second GEMM's A fragments of one pass (this wave's output tiles): resident for the whole launch when there is one pass
     auto load_w2 = [&](int pass) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int s = 0; s < KS2; ++s) w2f[n * KS2 + s] = __builtin_bit_cast(half8_t, w2pack[((size_t)n * (HID / 16) + pass * KS2 + s) * 64 + lane]);
+            for (int s = 0; s < KS2; ++s) w2f[n * KS2 + s] = __builtin_bit_cast(half8_t, w2pack[((size_t)(n0 + n) * (HID / 16) + pass * KS2 + s) * 64 + lane]);
     };
-    if constexpr (NPASS == 1) load_w2(0);
+    if constexpr (NPASS == 1 && !W2LDS) load_w2(0);
     // the first GEMM's A fragments of this wave's channel tile (wave % NCT of the pass): requested at the END of the previous pass's phase 1, so
     // the next phase 1 never waits for them (they were loaded at its top before: an L2 round trip per pass in front of the MFMAs)
     half8_t w1f[KS1];
@@ -208,14 +217,14 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
 #pragma unroll
         for (int s = 0; s < KS1; ++s) w1f[s] = __builtin_bit_cast(half8_t, w1pack[((size_t)(pass * NCT + wave % NCT) * KS1 + s) * 64 + lane]);
     };
-    constexpr bool W1AHEAD = DWM && C == 64 && NPASS > 1;  // C = 32 / 128: the fragments' registers are needed in between (they would spill): loaded at the top of phase 1
+    constexpr bool W1AHEAD = DWM && C == 64 && NPASS > 1 && NW == 8;  // C = 32 / 128: the fragments' registers are needed in between (they would spill): loaded at the top of phase 1
     if constexpr (W1AHEAD) load_w1(0);
     // phase 1 items of this wave (pixel groups wave / NCT + j * 8 / NCT): where a lane's pixel sits in the hidden tile and in the image
-    constexpr int NITEM = (NGRP + 8 / NCT - 1) / (8 / NCT);
+    constexpr int NITEM = (NGRP + NW / NCT - 1) / (NW / NCT);
     int p1_g[NITEM], p1_dst[NITEM], p1_dy[NITEM], p1_dx[NITEM];
 #pragma unroll
     for (int j = 0; j < NITEM; ++j) {
-        const int g = wave / NCT + j * (8 / NCT), q = 32 * g + p, qc = q < NHALO ? q : 0;
+        const int g = wave / NCT + j * (NW / NCT), q = 32 * g + p, qc = q < NHALO ? q : 0;
         p1_g[j] = g < NGRP ? g : -1;
         p1_dst[j] = (g < NGRP && q < NHALO) ? (qc / HS) * RPITCH + (qc % HS) * HPITCH + 32 * h : -1;
         p1_dy[j] = qc / HS - 1; p1_dx[j] = qc % HS - 1;
@@ -229,9 +238,9 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     for (;;) {
         const long next = tile + gridDim.x;
         const bool halo_inside = t.y0 >= 1 && t.y0 + HS - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W;  // scalar
-        float16_t D[NT];
+        float16_t D[NTW];
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NTW; ++n)
 #pragma unroll
             for (int v = 0; v < 16; ++v) D[n][v] = 0.f;
 #pragma unroll 1
@@ -239,12 +248,14 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             stamp(pass == 0 ? 7 : 5);
             __syncthreads();  // yt complete (pass 0) / ht no longer read by the previous pass's phase 2
             stamp(0);
-            half8_t af[DWM ? HPASS / 64 : 1][3];  // DWM: this wave's depthwise weight fragments of the pass (in flight during phase 1)
+            if constexpr (W2LDS)  // every wave is past the previous pass's phase 2b: its fragments may be replaced
+                for (int i = tid; i < NT * KS2 * 64; i += NTHR) w2l[i] = w2pack[((size_t)(i / (KS2 * 64)) * (HID / 16) + pass * KS2 + (i / 64) % KS2) * 64 + (i & 63)];
+            half8_t af[DWM ? NOCTW : 1][3];  // DWM: this wave's depthwise weight fragments of the pass (in flight during phase 1)
             if constexpr (DWM) {
 #pragma unroll
-                for (int o2 = 0; o2 < HPASS / 64; ++o2)
+                for (int o2 = 0; o2 < NOCTW; ++o2)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) af[o2][i] = __builtin_bit_cast(half8_t, dwpack[((size_t)(pass * (HPASS / 8) + 8 * o2 + wave) * 3 + i) * 64 + lane]);
+                    for (int i = 0; i < 3; ++i) af[o2][i] = __builtin_bit_cast(half8_t, dwpack[((size_t)(pass * (HPASS / 8) + NW * o2 + wave) * 3 + i) * 64 + lane]);
             }
             // ---- phase 1: hidden = GELU(W1 y) for hidden channels [HPASS pass + 32 ct, + 32), ct = wave % NCT, pixel groups wave / NCT, + 8 / NCT, ... ----
             {
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                             keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
                         }
                         // GELU of the 16 results, GP1 pairs at a time step-major (gelu_multi): as many as the registers allow without spilling
-                        constexpr int GP1 = C == 64 ? 4 : 1;  // C = 32 / 128: no register to spare (more than one pair in flight spills)
+                        constexpr int GP1 = (C == 64 && NW == 8) ? 4 : 1;  // C = 32 / 128: no register to spare (more than one pair in flight spills)
                         unsigned pk[8];
 #pragma unroll
                         for (int v0 = 0; v0 < 8; v0 += GP1) {
@@ -289,10 +300,10 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
             __syncthreads();  // ht complete
             stamp(2);
             if (PREFETCH && pass == NPASS - 1 && next < total) fetch(tile_of(next));  // next tile's raw rows: in flight during phase 2
-            if constexpr (NPASS > 1) load_w2(pass);
+            if constexpr (NPASS > 1 && !W2LDS) load_w2(pass);
             if constexpr (DWM) {
                 // ---- phase 2a: depthwise 3x3 on the matrix pipe + GELU, in place in the hidden tile (see the kernel's head comment) ----
-                constexpr int NOCT = HPASS / 64;  // octets of this pass per wave
+                constexpr int NOCT = NOCTW;  // octets of this pass per wave
                 const int n16 = lane & 15, q = lane >> 4;
                 unsigned char* rbase = ht + (size_t)q * RPITCH + (size_t)n16 * HPITCH + 16 * wave;                               // + 2p RPITCH + i HPITCH + 128 o2
                 unsigned char* wbase = ht + (size_t)(q >> 1) * RPITCH + (size_t)n16 * HPITCH + 16 * wave + 8 * (q & 1);        // + 2p RPITCH + 128 o2
@@ -307,13 +318,13 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 auto rd = [&](int u) {
                     const int o2 = u / (TS / 2), pr = u % (TS / 2);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 128 * o2);
+                    for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 16 * NW * o2);
                 };
                 auto finish = [&](int u, float4_t a) {
                     const int o2 = u / (TS / 2), pr = u % (TS / 2);
                     float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
                     if constexpr (C == 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
-                    *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 128 * o2) = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
+                    *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 16 * NW * o2) = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
                 };
 #ifndef AVX_FFN_PIPE_ALL
 #define AVX_FFN_PIPE_ALL 0
@@ -351,13 +362,16 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
                 stamp(4);
                 if constexpr (W1AHEAD) load_w1(pass + 1 < NPASS ? pass + 1 : 0);  // dead since phase 1; requested here (not there: 8 live registers through phase 2a spill) -- phase 2b and the barrier cover the trip
                 // ---- phase 2b: second GEMM, this wave's 32 output pixels (rows 2 wave, 2 wave + 1), B fragments from the map ----
-                const int r = 2 * wave + (p >> 4), c = p & 15;
+                const int r = 2 * w8 + (p >> 4), c = p & 15;
                 const unsigned char* zb = ht + (size_t)r * RPITCH + (size_t)c * HPITCH + 16 * h;
 #pragma unroll
                 for (int s = 0; s < KS2; ++s) {
                     const half8_t bf = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(zb + 32 * s));
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) D[n] = mfma16(w2f[n * KS2 + s], bf, D[n]);
+                    for (int n = 0; n < NTW; ++n) {
+                        if constexpr (W2LDS) D[n] = mfma16(__builtin_bit_cast(half8_t, w2l[((n0 + n) * KS2 + s) * 64 + lane]), bf, D[n]);
+                        else D[n] = mfma16(w2f[n * KS2 + s], bf, D[n]);
+                    }
                 }
             } else
             // ---- phase 2: depthwise 3x3 + GELU + W2, this wave's 32 output pixels (rows 2 wave, 2 wave + 1) ----
@@ -395,11 +409,11 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
         stamp(5);
         // ---- epilogue: + x (the block's residual, :184), float16, 32 contiguous bytes per lane and output tile ----
         {
-            const int yo = t.y0 + 2 * wave + (p >> 4), xo = t.x0 + (p & 15);
+            const int yo = t.y0 + 2 * w8 + (p >> 4), xo = t.x0 + (p & 15);
             if (yo < H && xo < W) {
-                const size_t off = ((t.b * H + yo) * (size_t)W + xo) * C + 16 * h;
+                const size_t off = ((t.b * H + yo) * (size_t)W + xo) * C + 16 * h + 32 * n0;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
+                for (int n = 0; n < NTW; ++n) {
                     const uint4 xa = reinterpret_cast<const uint4*>(x + off + 32 * n)[0], xb = reinterpret_cast<const uint4*>(x + off + 32 * n)[1];
                     const unsigned xw[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
                     unsigned ow[8];
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_ffn_fused(const __half* __res
     if constexpr (STAMP) {
         if (lane == 0 && stamps)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) stamps[((size_t)blockIdx.x * 8 + wave) * 8 + k] = seg[k];
+            for (int k = 0; k < 8; ++k) stamps[((size_t)blockIdx.x * NW + wave) * 8 + k] = seg[k];
     }
 }
 
@@ -1437,43 +1451,47 @@ static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, con
     const bool small = C == 32 && !(hp && atoi(hp) == 128);
     const int hpass = (small || C == 128) ? 64 : 128, hpitch = hpass * 2 + 16, rpitch = (HS * hpitch + 255) / 256 * 256;
     const long cap = (long)ctx->num_cus * (small ? 2 : 1);
-    const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * rpitch + (size_t)9 * 4 * C * 2 + sizeof(float) * 2 * C;
+    const bool nw16 = C == 64 && dwpack && !(getenv("AVX_MST_FFN_NW") && atoi(getenv("AVX_MST_FFN_NW")) == 8);  // AVX_MST_FFN_NW=8: A/B, the round-2 split
+    const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * rpitch + (dwpack ? 0 : (size_t)9 * 4 * C * 2) + sizeof(float) * 2 * C + (nw16 ? (size_t)(C / 32) * (hpass / 16) * 1024 : 0);
     const dim3 grid((unsigned)(total < cap ? total : cap));
-#define AVX_FFN1(CV, HP, MW, DW)                                                                                                                 \
+#define AVX_FFN1(CV, HP, MW, DW, NWV)                                                                                                            \
     {                                                                                                                                            \
-        auto k = k_mst_ffn_fused<CV, HP, MW, DW>;                                                                                                \
+        auto k = k_mst_ffn_fused<CV, HP, MW, DW, false, NWV>;                                                                                    \
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
-        hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid,      \
+        hipLaunchKernelGGL(k, grid, dim3(64 * NWV), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid, \
                            (const uint4*)w2pack, (__half*)out, B, H, W, (const uint4*)dwpack, (unsigned long long*)nullptr);                     \
     }
-#define AVX_FFN(CV, HP, MW) { if (dwpack) AVX_FFN1(CV, HP, MW, true) else AVX_FFN1(CV, HP, MW, false) }
+#define AVX_FFN(CV, HP, MW) { if (dwpack) AVX_FFN1(CV, HP, MW, true, 8) else AVX_FFN1(CV, HP, MW, false, 8) }
     if (dwpack && getenv("AVX_FFN_STAMPS") && ((C == 32 && small) || C == 64 || C == 128)) {  // diagnostic: per-segment cycles of every wave, summed and printed
         unsigned long long* d_st = nullptr;
-        const size_t n = (size_t)grid.x * 64;
+        const int nwv = nw16 ? 16 : 8;
+        const size_t n = (size_t)grid.x * nwv * 8;
         AVX_HIP(ctx, hipMalloc((void**)&d_st, n * sizeof(unsigned long long)));
-#define AVX_FFN_ST(CV, HP, MW)                                                                                                                   \
+#define AVX_FFN_ST(CV, HP, MW, NWV)                                                                                                              \
     {                                                                                                                                            \
-        auto k = k_mst_ffn_fused<CV, HP, MW, true, true>;                                                                                        \
+        auto k = k_mst_ffn_fused<CV, HP, MW, true, true, NWV>;                                                                                   \
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
-        hipLaunchKernelGGL(k, grid, dim3(kFT), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid,      \
+        hipLaunchKernelGGL(k, grid, dim3(64 * NWV), lds, s, (const __half*)x, gamma, beta, eps, (const uint4*)w1pack, (const __half*)taps_9xhid, \
                            (const uint4*)w2pack, (__half*)out, B, H, W, (const uint4*)dwpack, d_st);                                             \
     }
-        if (C == 32) AVX_FFN_ST(32, 64, 4) else if (C == 64) AVX_FFN_ST(64, 128, 2) else AVX_FFN_ST(128, 64, 2)
+        if (C == 32) AVX_FFN_ST(32, 64, 4, 8) else if (nw16) AVX_FFN_ST(64, 128, 1, 16) else if (C == 64) AVX_FFN_ST(64, 128, 2, 8) else AVX_FFN_ST(128, 64, 2, 8)
 #undef AVX_FFN_ST
         AVX_HIP(ctx, hipStreamSynchronize(s));
         unsigned long long* h_st = (unsigned long long*)malloc(n * sizeof(unsigned long long));
         AVX_HIP(ctx, hipMemcpy(h_st, d_st, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double tot[8] = {0}, w0[8] = {0}, w7[8] = {0};
-        for (size_t i = 0; i < n; ++i) { tot[i & 7] += (double)h_st[i]; if (((i >> 3) & 7) == 0) w0[i & 7] += (double)h_st[i]; if (((i >> 3) & 7) == 7) w7[i & 7] += (double)h_st[i]; }
+        for (size_t i = 0; i < n; ++i) { tot[i & 7] += (double)h_st[i]; if (((i >> 3) % nwv) == 0) w0[i & 7] += (double)h_st[i]; if (((i >> 3) % nwv) == (size_t)nwv - 1) w7[i & 7] += (double)h_st[i]; }
         double all = 0;
         for (int k2 = 0; k2 < 8; ++k2) all += tot[k2];
-        fprintf(stderr, "[ffn stamps C=%d] %u blocks, mean cycles per wave %.0f; share per segment (all waves | wave 0 | wave 7): ", C, grid.x, all / (grid.x * 8.0));
+        fprintf(stderr, "[ffn stamps C=%d] %u blocks x %d waves, mean cycles per wave %.0f; share per segment (all waves | first wave | last wave): ", C, grid.x, nwv, all / (grid.x * (double)nwv));
         const char* nm[8] = {"bar1", "phase1", "bar2", "phase2a", "bar3", "phase2b", "epilogue", "ln+fetch"};
-        for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, "%s %.1f%% | %.1f%% | %.1f%%  ", nm[k2], 100 * tot[k2] / all, 100 * w0[k2] * 8 / all, 100 * w7[k2] * 8 / all);
+        for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, "%s %.1f%% | %.1f%% | %.1f%%  ", nm[k2], 100 * tot[k2] / all, 100 * w0[k2] * nwv / all, 100 * w7[k2] * nwv / all);
         fprintf(stderr, "\n");
         free(h_st);
         (void)hipFree(d_st);
-    } else if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2) else if (C == 64) AVX_FFN(64, 128, 2) else AVX_FFN(128, 64, 2)
+    } else if (C == 32 && small) AVX_FFN(32, 64, 4) else if (C == 32) AVX_FFN(32, 128, 2)
+    else if (nw16) AVX_FFN1(64, 128, 1, true, 16)
+    else if (C == 64) AVX_FFN(64, 128, 2) else AVX_FFN(128, 64, 2)
 #undef AVX_FFN
 #undef AVX_FFN1
     AVX_HIP(ctx, hipGetLastError());
