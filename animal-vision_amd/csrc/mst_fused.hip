@@ -714,17 +714,18 @@ int launch_attn_tail(avx_ctx* ctx, const void* v, const void* x, const void* mpa
 //     the residual (requested before the first unit) added: two barriers per tile (v complete; v free), no output staging;
 //   * v is formed from x as it arrives: a lane's prefetched half row of its halo pixel IS its B operand (W_v packed in that K order,
 //     pack_fragments16(halfrow=True)); the x tile never sits in LDS.
-template <int C, int TR, int MINW, bool STAMP = false>
-__global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __restrict__ x /*[B][H][W][C]*/, const uint4* __restrict__ wvpack /*[C/32][C/16][64], half-row K order*/,
+// NW: waves per workgroup (8; 16 for the 62-channel blocks, whose LDS footprint admits one workgroup per CU: two waves per octet as at C = 32, four waves per SIMD)
+template <int C, int TR, int MINW, bool STAMP = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half* __restrict__ x /*[B][H][W][C]*/, const uint4* __restrict__ wvpack /*[C/32][C/16][64], half-row K order*/,
                                                                 const uint4* __restrict__ mpack /*[C/8][C/16][64]*/, const uint4* __restrict__ dw1 /*[C/8][3][64]*/,
                                                                 const uint4* __restrict__ dw2 /*[C/8][3][64]*/, const float* __restrict__ bias /*[C] or NULL*/,
                                                                 __half* __restrict__ out, int B, int H, int W, unsigned long long* __restrict__ stamps /*STAMP: [blocks][8][8]*/) {
     constexpr int TW = 14, VW = 18, VR = TR + 4, MR = TR + 2, NOCT = C / 8, NK = C / 16, NT = C / 32, NS = C / 16, LNV = C / 16;
     constexpr int PP = C * 2 + 16, RP = (VW * PP + 255) / 256 * 256, MP = 16 * PP;  // pixel pitch; row pitch of v (18 px) and of mid (16 px): multiples of 256 bytes
-    constexpr int NG = (VR * VW + 31) / 32, NGW = (NG + 7) / 8;                     // 32-pixel groups of the halo region; per wave
-    constexpr int WPO = 8 / NOCT, NOUT = (TR / 2) / WPO, NMID = NOUT + 1;           // waves per octet; output / mid row pairs per wave
+    constexpr int NTHR = 64 * NW, NG = (VR * VW + 31) / 32, NGW = (NG + NW - 1) / NW;                     // 32-pixel groups of the halo region; per wave
+    constexpr int WPO = NW / NOCT, NOUT = (TR / 2) / WPO, NMID = NOUT + 1;           // waves per octet; output / mid row pairs per wave
     static_assert(C == 32 || C == 64, "31- or 62-channel blocks");
-    static_assert(MP % 256 == 0 && (TR / 2) % WPO == 0, "pitches / row split");
+    static_assert(MP % 256 == 0 && NW % NOCT == 0 && (TR / 2) % WPO == 0, "pitches / row split");
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* vt = smem;                                            // [VR][RP]: v on the halo region (zeros outside the image)
     unsigned char* mt = vt + (size_t)VR * RP;                            // [MR][MP]: mid = gelu(dw1(v)), 16 columns; an octet's bytes belong to its wave(s)
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
     if constexpr (STAMP) tlast = __builtin_readcyclecounter();
     const int tx = (W + TW - 1) / TW, ty = (H + TR - 1) / TR;
     const long total = (long)B * ty * tx;
-    for (int i = tid; i < NT * NS * 64; i += kFT) wvl[i] = wvpack[i];
+    for (int i = tid; i < NT * NS * 64; i += NTHR) wvl[i] = wvpack[i];
     const int o = wave % NOCT, rpo = (wave / NOCT) * NOUT;  // this wave's octet and first row pair
     half8_t a1[3], a2[3], am[NK];
     float bs[4];
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
     int v_dst[NGW], p_row[NGW], p_col[NGW];
 #pragma unroll
     for (int gi = 0; gi < NGW; ++gi) {
-        const int g = wave + 8 * gi, qq = 32 * g + p, qc = qq < VR * VW ? qq : VR * VW - 1;
+        const int g = wave + NW * gi, qq = 32 * g + p, qc = qq < VR * VW ? qq : VR * VW - 1;
         p_row[gi] = qc / VW; p_col[gi] = qc % VW;
         f_rel[gi] = (unsigned)((p_row[gi] * W + p_col[gi]) * C + h * (C / 2)) * 2u;
         v_dst[gi] = (g < NG && qq < VR * VW) ? p_row[gi] * RP + p_col[gi] * PP + 32 * h : -1;
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
             const char* origin = reinterpret_cast<const char*>(x + ((t.b * H + t.y0 - 2) * (size_t)W + t.x0 - 2) * C);
 #pragma unroll
             for (int gi = 0; gi < NGW; ++gi) {
-                if (wave + 8 * gi >= NG) break;
+                if (wave + NW * gi >= NG) break;
                 unsigned of = f_rel[gi];
                 asm volatile("" : "+v"(of));
                 const uint4* src = reinterpret_cast<const uint4*>(origin + of);
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
         }
 #pragma unroll
         for (int gi = 0; gi < NGW; ++gi) {
-            if (wave + 8 * gi >= NG) break;
+            if (wave + NW * gi >= NG) break;
             const int yy = t.y0 - 2 + p_row[gi], xx = t.x0 - 2 + p_col[gi];
             const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;  // zeros outside the image: v = 0 there (to_v has no bias), the convs' padding
             const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
         // ---- phase A: v = float16(x W_v^T) for this wave's halo pixel groups, straight from the prefetched rows ----
 #pragma unroll
         for (int gi = 0; gi < NGW; ++gi) {
-            if (wave + 8 * gi >= NG) break;  // wave-uniform
+            if (wave + NW * gi >= NG) break;  // wave-uniform
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float16_t d;
@@ -928,41 +929,41 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_attn_tail_mx(const __half* __
     if constexpr (STAMP) {
         if (lane == 0 && stamps)
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) stamps[((size_t)blockIdx.x * 8 + wave) * 8 + kk] = seg[kk];
+            for (int kk = 0; kk < 8; ++kk) stamps[((size_t)blockIdx.x * NW + wave) * 8 + kk] = seg[kk];
     }
 }
 
-template <int C, int TR, int MINW>
+template <int C, int TR, int MINW, int NW = 8>
 int launch_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack, const void* mpack, const void* dw1, const void* dw2, const float* bias, void* out, int B, int H, int W,
                         hipStream_t s) {
     constexpr int PP = C * 2 + 16, RP = (18 * PP + 255) / 256 * 256;
     const size_t lds = (size_t)(TR + 4) * RP + (size_t)(TR + 2) * 16 * PP + (size_t)(C / 32) * (C / 16) * 1024;
     const long total = (long)B * ((H + TR - 1) / TR) * ((W + 13) / 14);
-    const long cap = (long)ctx->num_cus * (MINW / 2);
+    const long cap = (long)ctx->num_cus * (NW == 16 ? 1 : MINW / 2);
     const unsigned blocks = (unsigned)(total < cap ? total : cap);
     if (getenv("AVX_TAIL_STAMPS")) {  // diagnostic: per-segment cycles of every wave, summed and printed
-        auto ks = k_mst_attn_tail_mx<C, TR, MINW, true>;
+        auto ks = k_mst_attn_tail_mx<C, TR, MINW, true, NW>;
         unsigned long long* d_st = nullptr;
-        const size_t n = (size_t)blocks * 64;
+        const size_t n = (size_t)blocks * NW * 8;
         AVX_HIP(ctx, hipMalloc((void**)&d_st, n * sizeof(unsigned long long)));
         AVX_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ks, dim3(blocks), dim3(kFT), lds, s, (const __half*)x, (const uint4*)wvpack, (const uint4*)mpack, (const uint4*)dw1, (const uint4*)dw2, bias, (__half*)out, B, H, W, d_st);
+        hipLaunchKernelGGL(ks, dim3(blocks), dim3(64 * NW), lds, s, (const __half*)x, (const uint4*)wvpack, (const uint4*)mpack, (const uint4*)dw1, (const uint4*)dw2, bias, (__half*)out, B, H, W, d_st);
         AVX_HIP(ctx, hipStreamSynchronize(s));
         unsigned long long* h_st = (unsigned long long*)malloc(n * sizeof(unsigned long long));
         AVX_HIP(ctx, hipMemcpy(h_st, d_st, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double tot[8] = {0}, all = 0;
         for (size_t i = 0; i < n; ++i) { tot[i & 7] += (double)h_st[i]; all += (double)h_st[i]; }
         const char* nm[8] = {"v from x", "bar1", "conv1+gelu", "conv2+proj+store", "bar2", "-", "-", "-"};
-        fprintf(stderr, "[tail stamps C=%d] %u blocks, %ld tiles, mean cycles per wave %.0f:", C, blocks, total, all / (blocks * 8.0));
+        fprintf(stderr, "[tail stamps C=%d] %u blocks, %ld tiles, mean cycles per wave %.0f:", C, blocks, total, all / (blocks * (double)NW));
         for (int k2 = 0; k2 < 8; ++k2) fprintf(stderr, "  %s %.1f%%", nm[k2], 100 * tot[k2] / all);
         fprintf(stderr, "\n");
         free(h_st);
         (void)hipFree(d_st);
         return AVX_OK;
     }
-    auto k = k_mst_attn_tail_mx<C, TR, MINW>;
+    auto k = k_mst_attn_tail_mx<C, TR, MINW, false, NW>;
     AVX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(kFT), lds, s, (const __half*)x, (const uint4*)wvpack, (const uint4*)mpack, (const uint4*)dw1,
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * NW), lds, s, (const __half*)x, (const uint4*)wvpack, (const uint4*)mpack, (const uint4*)dw1,
                        (const uint4*)dw2, bias, (__half*)out, B, H, W, (unsigned long long*)nullptr);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
@@ -1541,6 +1542,8 @@ extern "C" int avx_mst_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvp
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     if (C == 32) return launch_attn_tail_mx<32, 16, 4>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);
+    // 16 waves per workgroup (AVX_MST_TAIL_NW=16) measured no faster than 8 at C = 64 (258 vs 257 us per 4K launch: the kernel is not bound by occupancy): 8 it stays
+    if (getenv("AVX_MST_TAIL_NW") && atoi(getenv("AVX_MST_TAIL_NW")) == 16) return launch_attn_tail_mx<64, 16, 1, 16>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);
     return launch_attn_tail_mx<64, 16, 2>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);
 }
 
