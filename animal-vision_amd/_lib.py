@@ -65,6 +65,9 @@ class HoneybeeDesc(ctypes.Structure):
         ("custom_matrix", ctypes.c_float * 9),
         ("mixed_alpha", ctypes.c_float),
         ("out_float", ctypes.c_int32),
+        ("catches", ctypes.c_void_p),
+        ("catch_partials", ctypes.c_void_p),
+        ("n_catch_partials", ctypes.c_int32),
     ]
 
 
@@ -268,6 +271,7 @@ _SIGS = {
     "avx_mst_attn_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_attn_tail_x": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_ffn_fused": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "avx_mst_conv3x3_lds_spectral": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fp, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp]),
     "avx_mst_ffn_fused_mx": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_dw_gemm_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_dwconv3x3_nhwc_add": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

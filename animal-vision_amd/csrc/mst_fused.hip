@@ -978,10 +978,20 @@ int launch_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack, const v
 // norms over all pixels, MS_MSA :118-129).  The lane that has just rounded its pixel's 16 channels to float16 holds them in the K = 16 operand order
 // of avx_mst_qkv_gram16 (channel 16 h + 8 s + j), so the pass runs here on registers -- four projection MFMAs, two Gram MFMAs per 32 pixels --
 // and the 531 MB re-read of the tensor (121 us per 4K launch) does not happen.  Per-workgroup partial sums, reduced by k_mst_qkv_final as there.
-template <int MINW, bool GRAM>
+// SPEC (round 3): the conv is conv_out + x (MST_Plus_Plus.py:289-292) and what follows is the spectral integration of the cube it would write
+// (honeybee.py:126-135: radiance = cube * illuminant, three cone catches = 31 -> 3 GEMV per pixel).  The lane that has just rounded its pixel's 16 bands to float16
+// holds half of that pixel's cube row: the catches are formed here -- the SAME float32 FMA chain over the bands 0 ... 31 as csrc/uv.hip::k_spectral_nhwc_h runs
+// (bands 0-15 in lane half 0, handed to lane half 1 for bands 16-31), so the planes are bit-identical to the two-kernel route -- written as three float32 planes
+// of the cropped frame, with the per-workgroup min / max / sum the von Kries step needs (Stat3 as in csrc/uv.hip).  The cube is never written: 531 MB less to
+// write and 531 MB less to read per 4K frame, one launch less.
+struct SpecStat3 { float mn, mx; double sum; };  // == csrc/uv.hip::Stat3
+template <int MINW, bool GRAM, bool SPEC = false>
 __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __restrict__ x /*[B][H][W][32]*/, const uint4* __restrict__ wpack /*[9][2][64]*/,
                                                                const __half* __restrict__ add /*or NULL*/, __half* __restrict__ out, int B, int H, int W,
-                                                               const uint4* __restrict__ wqk /*[2][2][64]: pack_qkv16's q and k tiles*/, float* __restrict__ partial /*[blocks][34][32]*/) {
+                                                               const uint4* __restrict__ wqk /*[2][2][64]: pack_qkv16's q and k tiles*/, float* __restrict__ partial /*[blocks][34][32]*/,
+                                                               const float* __restrict__ specw = nullptr /*SPEC: [32 bands][4]: the three catches' weights, band-major*/,
+                                                               float* __restrict__ planes = nullptr /*SPEC: [3][Hc * Wc]*/, SpecStat3* __restrict__ spart = nullptr /*SPEC: [blocks][3]*/,
+                                                               int crop_t = 0, int crop_l = 0, int Hc = 0, int Wc = 0) {
     constexpr int C = 32, PP = C * 2 + 16, RP = (HS * PP + 255) / 256 * 256, NFILL = (HS * HS * 4 + kFT - 1) / kFT;
     __shared__ __align__(16) unsigned char xt[HS * RP];
     __shared__ uint4 wl[18 * 64];  // the 18 A fragments (9 taps x 2 K-steps): in registers they cost 72 VGPRs and a wave of occupancy
@@ -995,6 +1005,8 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
 #pragma unroll
         for (int v = 0; v < 16; ++v) G[v] = 0.f;
     }
+    float smn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, smx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    double ssum[3] = {0.0, 0.0, 0.0};
     const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
     const long total = (long)B * ty * tx;
     uint4 pre[NFILL];
@@ -1065,7 +1077,31 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
 #pragma unroll
                 for (int v = 0; v < 8; ++v) { o0[v] = (_Float16)(d[v] + (float)r0[v]); o1[v] = (_Float16)(d[8 + v] + (float)r1[v]); }
             }
-            if (live) {
+            if constexpr (SPEC) {
+                // catches of this pixel: acc_k = fma(band_b, w[b][k], acc_k) for b = 0 ... 31 in that order (uv.hip's chain), the first 16 bands in lane half 0
+                float a3[3] = {0.f, 0.f, 0.f};
+                auto chain = [&]() {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float v = (float)(j < 8 ? o0[j] : o1[j - 8]);
+                        const float* wb = specw + (16 * h + j) * 4;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) a3[k] = __builtin_fmaf(v, wb[k], a3[k]);
+                    }
+                };
+                if (h == 0) chain();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const float lo = __shfl_xor(a3[k], 32); a3[k] = h ? lo : a3[k]; }
+                if (h == 1) chain();
+                const int yc = yo - crop_t, xc = xo - crop_l;
+                if (h == 1 && live && yc >= 0 && yc < Hc && xc >= 0 && xc < Wc) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        planes[(size_t)k * Hc * Wc + (size_t)yc * Wc + xc] = a3[k];
+                        smn[k] = fminf(smn[k], a3[k]); smx[k] = fmaxf(smx[k], a3[k]); ssum[k] += (double)a3[k];
+                    }
+                }
+            } else if (live) {
                 reinterpret_cast<uint4*>(out + off)[0] = __builtin_bit_cast(uint4, o0);
                 reinterpret_cast<uint4*>(out + off)[1] = __builtin_bit_cast(uint4, o1);
             }
@@ -1098,6 +1134,26 @@ __global__ __launch_bounds__(kFT, MINW) void k_mst_conv3x3_lds(const __half* __r
         ahead.advance();
         t = walk.tile(TS);
         __syncthreads();  // everyone is done reading xt
+    }
+    if constexpr (SPEC) {  // this workgroup's statistics of the three planes (every workgroup writes its slot: k_finalize_stats reads them all)
+        __syncthreads();
+        float* redf = reinterpret_cast<float*>(xt);              // [8 waves][3][2]
+        double* redd = reinterpret_cast<double*>(xt + 256);      // [8 waves][3]
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float a = smn[k], b2 = smx[k];
+            double c2 = ssum[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b2 = fmaxf(b2, __shfl_xor(b2, o)); c2 += __shfl_xor(c2, o); }
+            if (lane == 0) { redf[(wave * 3 + k) * 2] = a; redf[(wave * 3 + k) * 2 + 1] = b2; redd[wave * 3 + k] = c2; }
+        }
+        __syncthreads();
+        if (tid < 3) {
+            float a = 3.4e38f, b2 = -3.4e38f;
+            double c2 = 0.0;
+            for (int w8 = 0; w8 < 8; ++w8) { a = fminf(a, redf[(w8 * 3 + tid) * 2]); b2 = fmaxf(b2, redf[(w8 * 3 + tid) * 2 + 1]); c2 += redd[w8 * 3 + tid]; }
+            spart[(size_t)blockIdx.x * 3 + tid] = SpecStat3{a, b2, c2};
+        }
     }
     if constexpr (GRAM) {  // this workgroup's partial: [34][32] = 32 Gram rows (i = k channel, j = q channel), sum q^2, sum k^2 (as k_mst_qkv16)
         static_assert(sizeof(xt) >= sizeof(float) * 4 * 34 * 32, "the halo tile's LDS holds four waves' results at a time");
@@ -1559,6 +1615,36 @@ extern "C" int avx_mst_conv3x3_lds(avx_ctx* ctx, const void* x, const void* wpac
     const long cap = (long)ctx->num_cus * 3;
     hipLaunchKernelGGL((k_mst_conv3x3_lds<6, false>), dim3((unsigned)(total < cap ? total : cap)), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (const __half*)add,
                        (__half*)out, B, H, W, (const uint4*)nullptr, (float*)nullptr);
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+
+// conv_out + x with the spectral integration as its epilogue (k_mst_conv3x3_lds<., false, true>): the 31-band cube is never written.  weights_host: 3 x 32 (K x bands,
+// illuminant folded in, band 31 = 0); planes_out: 3 x Hc x Wc float32 of the frame cropped at (crop_t, crop_l); partials_out: *n_partials x 3 records {float min, max; double sum}
+// (16 bytes each; at most 3 x CUs records) for avx_honeybee_u8 (source 2).  One frame per call.
+extern "C" int avx_mst_conv3x3_lds_spectral(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, int H, int W, int C, const float* weights_host, int crop_t,
+                                            int crop_l, int Hc, int Wc, float* planes_out, void* partials_out, int* n_partials, void* stream) {
+    if (!ctx) return AVX_ERR_INVALID;
+    AVX_REQUIRE(ctx, x && wpack16 && weights_host && planes_out && partials_out && n_partials && H > 0 && W > 0, "avx_mst_conv3x3_lds_spectral: NULL pointer or empty tensor");
+    AVX_REQUIRE(ctx, C == 32, "avx_mst_conv3x3_lds_spectral: C=%d (32: the 31-band cube as stored)", C);
+    AVX_REQUIRE(ctx, crop_t >= 0 && crop_l >= 0 && Hc > 0 && Wc > 0 && crop_t + Hc <= H && crop_l + Wc <= W, "avx_mst_conv3x3_lds_spectral: the crop window must lie inside the frame");
+    AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wpack16 | (uintptr_t)add | (uintptr_t)partials_out)) & 15u) == 0, "avx_mst_conv3x3_lds_spectral: pointers must be 16-byte aligned");
+    AVX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = avx_pick_stream(ctx, stream);
+    avx_ws* ws = avx_workspace(ctx, s);
+    if (!ws) return AVX_ERR_NOMEM;
+    float wT[32 * 4];  // band-major, padded to 4: wave-uniform scalar loads in the kernel
+    for (int b = 0; b < 32; ++b)
+        for (int k = 0; k < 4; ++k) wT[b * 4 + k] = k < 3 ? weights_host[(size_t)k * 32 + b] : 0.0f;
+    float* dwT = nullptr;
+    int rc = avx_const_upload(ctx, ws, 2, wT, sizeof(wT), s, (void**)&dwT);
+    if (rc) return rc;
+    const long total = (long)((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    const long cap = (long)ctx->num_cus * 2;  // 2 workgroups per CU: the epilogue's registers cost the third one's (as the Gram epilogue does)
+    const long blocks = total < cap ? total : cap;
+    *n_partials = (int)blocks;
+    hipLaunchKernelGGL((k_mst_conv3x3_lds<4, false, true>), dim3((unsigned)blocks), dim3(kFT), 0, s, (const __half*)x, (const uint4*)wpack16, (const __half*)add, (__half*)nullptr, 1, H, W,
+                       (const uint4*)nullptr, (float*)nullptr, (const float*)dwT, planes_out, (SpecStat3*)partials_out, crop_t, crop_l, Hc, Wc);
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;
 }

@@ -1311,7 +1311,7 @@ static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_
     double* pct = (double*)p;
     float* mat = nullptr;
     int rc = d->source == 0 ? avx_const_upload(ctx, ws, 0, d->rgb_matrix, sizeof(float) * 9, s, (void**)&mat)
-                            : avx_const_upload(ctx, ws, 0, d->weights_host, sizeof(float) * 3 * d->bands, s, (void**)&mat);
+             : d->source == 1 ? avx_const_upload(ctx, ws, 0, d->weights_host, sizeof(float) * 3 * d->bands, s, (void**)&mat) : AVX_OK;
     if (rc) return rc;
     const int R = d->blur_ksize / 2, mode = d->mapping;
     const int nj = mode == 2 ? 2 : (mode == 0 ? 3 : (mode == 3 ? 1 : 0));
@@ -1326,6 +1326,7 @@ static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_
             if (raw_f) raw = (float*)ws->d_scratch;
             if (sel_f) selp = (float*)ws->d_scratch + raw_f;
         }
+        if (d->source == 2) raw = const_cast<float*>(d->catches);  // the catches came with their statistics (csrc/mst_fused.hip: conv_out's epilogue)
     }
     const double q = mode == 3 ? 98.0 : 95.0;
     const float vi = (float)(n - 1) * ((float)q / 100.0f);  // NumPy evaluates the virtual index in float32 (run_percentiles)
@@ -1336,7 +1337,9 @@ static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_
     for (int f0 = 0; f0 < n_frames; f0 += kBeeMaxFrames) {
         const int F = n_frames - f0 < kBeeMaxFrames ? n_frames - f0 : kBeeMaxFrames;
         // 1) catches: statistics only (uint8 frames) or planes + statistics (HSI cubes), then the von Kries denominators
-        if (d->source == 0) {
+        if (d->source == 2) {
+            hipLaunchKernelGGL(k_finalize_stats, dim3(1), dim3(1024), 0, s, (const Stat3*)d->catch_partials, d->n_catch_partials, 3, n, d->adaptation, d->eps, stats);
+        } else if (d->source == 0) {
             hipLaunchKernelGGL(k_rgb_to_planes<3>, dim3(g, F), dim3(kT), 0, s, in_hwc + (size_t)f0 * n * 3, n, ctx->d_decode_lut, mat, 3, (float*)nullptr, partials);
         } else {
             const size_t esz = d->hsi_dtype == 0 ? 4 : 2;
@@ -1351,7 +1354,7 @@ static int honeybee_recompute(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_
                                    d->bands, mat, 3, raw + (size_t)f * 3 * n, partials + (size_t)f * g * 3);
             }
         }
-        hipLaunchKernelGGL(k_finalize_stats, dim3(F), dim3(1024), 0, s, partials, g, 3, n, d->adaptation, d->eps, stats);
+        if (d->source != 2) hipLaunchKernelGGL(k_finalize_stats, dim3(F), dim3(1024), 0, s, partials, g, 3, n, d->adaptation, d->eps, stats);
         BeeArgs a{};
         a.in = in_hwc ? in_hwc + (size_t)f0 * n * 3 : nullptr; a.raw = raw; a.H = H; a.W = W; a.lut = ctx->d_decode_lut; a.mat = mat; a.stats = stats;
         a.out = out_hwc + (size_t)f0 * n * 3;
@@ -1511,8 +1514,12 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, d && d->struct_size == sizeof(avx_honeybee_desc), "avx_honeybee_u8: desc is NULL or struct_size mismatch");
     AVX_REQUIRE(ctx, out_hwc && n_frames >= 0 && H > 0 && W > 0, "avx_honeybee_u8: bad arguments");
-    AVX_REQUIRE(ctx, d->source == 0 || d->source == 1, "avx_honeybee_u8: bad source");
-    AVX_REQUIRE(ctx, d->source == 1 ? (d->hsi && d->weights_host && d->bands > 0 && d->bands <= 129) : (in_hwc != nullptr), "avx_honeybee_u8: missing input");
+    AVX_REQUIRE(ctx, d->source >= 0 && d->source <= 2, "avx_honeybee_u8: bad source");
+    AVX_REQUIRE(ctx, d->source == 1 ? (d->hsi && d->weights_host && d->bands > 0 && d->bands <= 129) : d->source == 2 ? (d->catches && d->catch_partials && d->n_catch_partials > 0) : (in_hwc != nullptr),
+                "avx_honeybee_u8: missing input");
+    AVX_REQUIRE(ctx, d->source != 2 || (n_frames == 1 && d->mapping != 4 && !debug_planes && (d->blur_ksize == 0 || d->blur_ksize == 1 || d->blur_ksize == 3) &&
+                                        d->n_catch_partials <= ctx->num_cus * 8 && (((uintptr_t)d->catch_partials) & 15u) == 0),
+                "avx_honeybee_u8: source 2 (catches given) takes one frame, the tile schedule's mappings and blur sizes, and at most 8 statistics records per CU");
     AVX_REQUIRE(ctx, d->adaptation >= 0 && d->adaptation <= 2 && d->mapping >= 0 && d->mapping <= 4, "avx_honeybee_u8: bad adaptation/mapping");
     AVX_REQUIRE(ctx, d->blur_ksize == 0 || ((d->blur_ksize & 1) && d->blur_ksize <= AVX_MAX_KSIZE && d->blur_taps_host), "avx_honeybee_u8: bad blur");
     if (n_frames == 0) return AVX_OK;
@@ -1526,7 +1533,7 @@ int avx_honeybee_u8(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_hwc, int n
         // recomputing): the tile pipeline is bound by its arithmetic (three IEEE divisions, a square root and the 3 x 3 passes per pixel and
         // pass), not by bytes.  AVX_BEE_FUSED=0 pins the plane route below.
         const char* pin = getenv("AVX_BEE_FUSED");
-        const bool want = pin && *pin ? atoi(pin) != 0 : true;
+        const bool want = (pin && *pin ? atoi(pin) != 0 : true) || d->source == 2;
         if (want && d->mapping != 4 && !debug_planes && (d->blur_ksize == 0 || d->blur_ksize == 1 || d->blur_ksize == 3))
             return honeybee_recompute(ctx, in_hwc, out_hwc, n_frames, H, W, d, s0);
     }

@@ -184,6 +184,7 @@ class _AvxOps:
         self._convgram = os.environ.get("AVX_MST_NO_CONVGRAM", "") == ""  # A/B: the embedding conv carries the first block's Gram pass as its epilogue
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
         self._dwmx = os.environ.get("AVX_MST_NO_DW_MFMA", "") == ""  # A/B: depthwise 3x3 convs on the matrix pipe (round 3)
+        self._specfuse = os.environ.get("AVX_MST_NO_SPEC_FUSE", "") == ""  # A/B: the spectral integration as conv_out's epilogue (the cube is never written)
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
         self._ctx = {}
 
@@ -364,6 +365,31 @@ class _AvxOps:
             ctx._check(lib.avx_mst_conv3x3_lds_gram(ctx._h, x[i].data_ptr(), wpack16.data_ptr(), add[i].data_ptr() if add is not None else None, out[i].data_ptr(), h, w, c,
                                                     wqk16.data_ptr(), g[i].data_ptr(), nq[i].data_ptr(), nk[i].data_ptr(), st))
         return out, g, nq, nk
+
+    def conv3x3_lds_spectral(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor, weights, crop):
+        """conv3x3_lds with the spectral integration of its output as the epilogue (csrc/mst_fused.hip::k_mst_conv3x3_lds<., false, true>): the cube is never
+        written.  x / add: (1, h, w, 32) float16; weights: (3, 32) float32 NumPy (illuminant folded in); crop = (top, left, H, W) of the unpadded frame.
+        -> (planes (3, H, W) float32, partials (n, 3, 2) float64-sized records, n): what HoneybeeOp.run_device(catches=...) takes."""
+        import ctypes
+
+        import numpy as np
+
+        from .._lib import lib
+
+        b, h, w, c = x.shape
+        assert b == 1 and c == 32 and x.is_contiguous() and (add is None or add.is_contiguous())
+        t, l, H, W = crop
+        ctx = self.ctx(x.device)
+        planes = torch.empty((3, H, W), dtype=torch.float32, device=x.device)
+        ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+        partials = torch.empty((ncu * 3, 3, 2), dtype=torch.float64, device=x.device)  # 16-byte records {float min, max; double sum}: at most 3 workgroups per CU
+        wh = np.ascontiguousarray(weights, dtype=np.float32)
+        assert wh.shape == (3, 32)
+        n = ctypes.c_int(0)
+        ctx._check(lib.avx_mst_conv3x3_lds_spectral(ctx._h, x.data_ptr(), wpack16.data_ptr(), add.data_ptr() if add is not None else None, h, w, c,
+                                                    wh.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t, l, H, W, planes.data_ptr(), partials.data_ptr(), ctypes.byref(n),
+                                                    torch.cuda.current_stream(x.device).cuda_stream))
+        return planes, partials, int(n.value)
 
     def conv3x3_lds(self, x: torch.Tensor, wpack16: torch.Tensor, add: torch.Tensor = None) -> torch.Tensor:
         """conv3x3 through an LDS halo tile (csrc/mst_fused.hip::k_mst_conv3x3_lds): every input pixel is fetched once."""
@@ -871,18 +897,30 @@ class MSTPlusPlus(torch.nn.Module):
         return self._conv3(fea, p + ".mapping.weight", add=x)
 
     @torch.no_grad()
-    def forward_from_u8(self, frame: torch.Tensor, pads) -> torch.Tensor:
+    def forward_from_u8(self, frame: torch.Tensor, pads, spectral=None):
         """uint8 (H, W, 3) device frame -> (1, Hp, Wp, 32) cube on the reflect-padded frame (pads = (top, bottom, left, right), a
-        multiple of 8 in both directions afterwards): conv_in fused with the input preparation, then the body of forward_nhwc."""
+        multiple of 8 in both directions afterwards): conv_in fused with the input preparation, then the body of forward_nhwc.
+        spectral = (3, 32) float32 weights: the cube is not returned (nor written) but integrated in conv_out's epilogue ->
+        (planes (3, H, W) float32 of the UNPADDED frame, partials, n_partials) (see _AvxOps.conv3x3_lds_spectral)."""
         w27 = self._prep("conv_in.w27x32", lambda: self._w("conv_in.weight", (0,)).permute(2, 3, 1, 0).reshape(27, PAD).float().contiguous())
         x = _AVX.conv_in_u8(frame, pads, w27)
         assert x.shape[1] % 8 == 0 and x.shape[2] % 8 == 0, "pad the frame to a multiple of 8 (predict_torch.py pads to 16)"
-        return self._body(x)
+        if spectral is None:
+            return self._body(x)
+        H, W, _ = frame.shape
+        return self._body(x, spectral=(spectral, (pads[0], pads[2], H, W)))
 
-    def _body(self, x: torch.Tensor) -> torch.Tensor:
+    def can_fuse_spectral(self) -> bool:
+        return self.can_fuse_conv_in() and _AVX._conv_lds and _AVX._specfuse
+
+    def _body(self, x: torch.Tensor, spectral=None):
         hfe = x
         for s in range(self.stage):
             hfe = self._mst(hfe, f"body.{s}")
+        if spectral is not None:  # conv_out + x with the spectral integration as its epilogue
+            key = "conv_out.weight"
+            wq = self._prep(key + ".frag9k16", lambda: torch.stack([pack_fragments16(self._w(key, (0, 1))[:, :, t // 3, t % 3].t().contiguous()) for t in range(9)]).contiguous())
+            return _AVX.conv3x3_lds_spectral(hfe.contiguous(), wq, x.contiguous(), spectral[0], spectral[1])
         return self._conv3(hfe, "conv_out.weight", add=x)
 
     def can_fuse_conv_in(self) -> bool:
@@ -944,5 +982,7 @@ def hbm_bytes_per_px(stage: int = 3) -> float:
     else:
         convs += (t128 + t64) + (2 * t64 + t64)      # transposed conv 128 -> 64, fusion 1x1 over [up | skip]
         convs += (t64 + t32) + (2 * t32 + t32)       # transposed conv 64 -> 32, fusion 1x1
-    head = ((3 + t32) if _AVX._conv_in else (3 + 12) + (12 + t32)) + (3 * t32)   # uint8 frame -> conv_in output (one kernel, else float32 NCHW + conv); conv_out + x
+    # uint8 frame -> conv_in output (one kernel, else float32 NCHW + conv); conv_out + x (with the spectral integration as its epilogue the cube is
+    # not written: 12 bytes of catch planes per pixel instead of 64)
+    head = ((3 + t32) if _AVX._conv_in else (3 + 12) + (12 + t32)) + ((2 * t32 + 12) if (_AVX._specfuse and _AVX._conv_lds and _AVX._conv_in) else 3 * t32)
     return stage * (per_stage + convs) + head

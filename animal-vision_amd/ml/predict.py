@@ -104,6 +104,24 @@ class MSTPlusPlusPredictor:
         y = self.model.forward_nhwc(x.half() if self.half else x)
         return y[0, t : t + H, l : l + W, :].contiguous()
 
+    def honeybee_device(self, frame_dev, op32, d_out, stream_handle):
+        """uint8 (H, W, 3) device frame -> honeybee frame in d_out (a DeviceBuffer of H*W*3 bytes), everything enqueued on torch's current stream
+        (= stream_handle).  Where the fused kernels apply, the 31-band cube is never written: conv_out's epilogue integrates it into the three catch
+        planes (+ their statistics) that the honeybee tail starts from; else the cube is handed over by data_ptr.  op32: the HoneybeeOp padded to
+        32 bands (op.padded_clone(32)).  Returns the tensors that must stay alive until the stream has run (the caller records / keeps them)."""
+        torch = self.torch
+        H, W, _ = frame_dev.shape
+        t, b, l, r = pad_amounts(H, W, self.stride)
+        fuse = (self.half and frame_dev.dtype == torch.uint8 and self.stride % 8 == 0 and max(t, b) < H and max(l, r) < W and H > 1 and W > 1
+                and self.model.can_fuse_spectral() and op32.weights.shape == (3, 32))
+        if fuse:
+            planes, partials, n = self.model.forward_from_u8(frame_dev, (t, b, l, r), spectral=op32.weights)
+            op32.run_device(None, d_out, 1, H, W, catches=(planes.data_ptr(), partials.data_ptr(), n), stream=stream_handle)
+            return planes, partials
+        cube = self.predict_device_nhwc(frame_dev)
+        op32.run_device(None, d_out, 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=0, hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream_handle)
+        return (cube,)
+
     def predict_device(self, frame_dev):
         """uint8 (H,W,3) torch tensor on the device -> (31, H, W) contiguous tensor (fp16 when half)."""
         return self.predict_device_nhwc(frame_dev)[..., :31].permute(2, 0, 1).contiguous()
@@ -130,16 +148,16 @@ class MSTPlusPlusPredictor:
 
         H, W, _ = image.shape
         frame = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)
-        cube = self.predict_device_nhwc(frame)  # (H, W, 32): the layout the forward pass computes in, no transpose
         out = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         ctx = op._ctx()
         stream = torch.cuda.current_stream().cuda_stream
         op32 = self._padded_ops.get(id(op))
         if op32 is None:
-            op32 = self._padded_ops.setdefault(id(op), op.padded_clone(cube.shape[-1]))
-        op32.run_device(None, DeviceBuffer(ctx, out.data_ptr(), out.numel(), owned=False), 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=0,
-                        hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
-        return out.cpu().numpy()
+            op32 = self._padded_ops.setdefault(id(op), op.padded_clone(32))  # the cube is channels-last, 31 bands in a 32-wide group
+        keep = self.honeybee_device(frame, op32, DeviceBuffer(ctx, out.data_ptr(), out.numel(), owned=False), stream)
+        res = out.cpu().numpy()  # synchronises: `keep` may go
+        del keep
+        return res
 
 
 class MstHoneybeeStreamOp:
@@ -177,11 +195,10 @@ class MstHoneybeeStreamOp:
         if ext is None:
             ext = self._streams.setdefault(stream, torch.cuda.ExternalStream(stream, device=self.pred.device))
         with torch.cuda.stream(ext):
-            cube = self.pred.predict_device_nhwc(self._t_in[k])
             if self._op32 is None:
-                self._op32 = self._bee.padded_clone(cube.shape[-1])  # host-side tables only (uploaded per call through the workspace of `stream`)
-            self._op32.run_device(None, d_out, 1, H, W, hsi_ptr=cube.data_ptr(), hsi_layout=0, hsi_dtype=1 if cube.dtype == torch.float16 else 0, stream=stream)
-            cube.record_stream(ext)
+                self._op32 = self._bee.padded_clone(32)  # host-side tables only (uploaded per call through the workspace of `stream`)
+            for tns in self.pred.honeybee_device(self._t_in[k], self._op32, d_out, stream):
+                tns.record_stream(ext)
 
     def release_streams(self):
         """Called by pipeline.FramePipeline.close(): its slot streams are about to be destroyed, so the ExternalStream wrappers

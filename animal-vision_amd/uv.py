@@ -263,11 +263,15 @@ class HoneybeeOp:
         return op
 
     def run_device(self, d_in: Optional[DeviceBuffer], d_out: DeviceBuffer, n_frames: int, H: int, W: int, *, hsi_ptr: int = 0,
-                   hsi_layout: int = 1, hsi_dtype: int = 0, debug: Optional[DeviceBuffer] = None, stream=None):
-        """uint8 frames (or an HSI cube at hsi_ptr, e.g. the MST++ output tensor) -> uint8 frames, all on device."""
+                   hsi_layout: int = 1, hsi_dtype: int = 0, debug: Optional[DeviceBuffer] = None, stream=None, catches=None):
+        """uint8 frames (or an HSI cube at hsi_ptr, e.g. the MST++ output tensor; or catches = (planes_ptr, partials_ptr, n_partials): the three
+        catch planes already formed with their statistics, ml/mst_plus_plus.py::conv3x3_lds_spectral) -> uint8 frames, all on device."""
         ctx = self._ctx()
         d = self.desc
-        if hsi_ptr:
+        if catches is not None:
+            d.source, d.hsi = 2, None
+            d.catches, d.catch_partials, d.n_catch_partials = int(catches[0]), int(catches[1]), int(catches[2])
+        elif hsi_ptr:
             d.source, d.hsi, d.hsi_layout, d.hsi_dtype = 1, hsi_ptr, hsi_layout, hsi_dtype
         else:
             d.source, d.hsi = 0, None

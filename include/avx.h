@@ -152,7 +152,8 @@ enum { AVX_MAP_FALSECOLOR = 0, AVX_MAP_CUSTOM_MATRIX = 1, AVX_MAP_OPPONENT = 2, 
 typedef struct avx_honeybee_desc {
     uint32_t struct_size;
     int32_t source;            /* 0: uint8 RGB frames + rgb_matrix (analytic lobes x illuminant x cone curves folded
-                                  to 3x3, the route honeybee.py actually takes); 1: an HSI cube + weights_host  */
+                                  to 3x3, the route honeybee.py actually takes); 1: an HSI cube + weights_host;
+                                  2: the catches themselves + their statistics (one frame)                        */
     float rgb_matrix[9];       /* source 0: [U,B,G]_k = sum_j rgb_matrix[k][j] * linear_channel_j                  */
     const void* hsi;           /* source 1: device cube(s), N of them back to back                                */
     int32_t hsi_layout, hsi_dtype, bands;
@@ -166,6 +167,10 @@ typedef struct avx_honeybee_desc {
     float mixed_alpha;         /* falsecolor_uv_mixed alpha (honeybee.py:162 passes 0.45)                          */
     int32_t out_float;         /* 1: out_hwc is a float32 HxWx3 buffer receiving linear_to_srgb(clip(rgb_lin)) (the
                                   reference's output for float frames, honeybee.py:172-173) instead of uint8 codes */
+    const float* catches;      /* source 2: the three catch planes (device, 3 x H*W float32) already formed, e.g. by
+                                  avx_mst_conv3x3_lds_spectral (the spectral integration as conv_out's epilogue) ...  */
+    const void* catch_partials; /* ... with n_catch_partials x 3 records {float min, max; double sum} of them (device) */
+    int32_t n_catch_partials;
 } avx_honeybee_desc;
 
 /* debug_planes (optional, device, N x 3 x H*W floats): receives U,B,G after adaptation + blur. */
@@ -401,6 +406,13 @@ int avx_mst_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack16, cons
 int avx_mst_attn_pack_mx(avx_ctx* ctx, const float* gram, const float* nq, const float* nk, const float* rescale, const float* wproj_t, int C, void* mpack,
                          void* stream);
 
+
+/* MST_Plus_Plus.conv_out + x (:289-292) with the spectral integration that follows it in the honeybee route (honeybee.py:126-135) as its epilogue: the cube is
+ * never written.  x / add: (H, W, 32) float16; weights_host: 3 x 32 (illuminant folded in, band 31 zero); planes_out: 3 x Hc x Wc float32 of the frame cropped at
+ * (crop_t, crop_l) (the predict harness pads frames to multiples of 16, predict_torch.py:171-183); partials_out: up to 3 x CUs x 3 records of 16 bytes, *n_partials
+ * receives how many triples were written.  Feed both to avx_honeybee_u8 (source 2).  The planes equal avx_spectral_integrate's on the cube bit for bit. */
+int avx_mst_conv3x3_lds_spectral(avx_ctx* ctx, const void* x, const void* wpack16, const void* add, int H, int W, int C, const float* weights_host, int crop_t,
+                                 int crop_l, int Hc, int Wc, float* planes_out, void* partials_out, int* n_partials, void* stream);
 
 /* The whole second half of an MSAB block in one kernel (MST_Plus_Plus.py:57-65 PreNorm, :141-158 FeedForward, :184 residual):
  * out = x + W2 gelu(dw3x3(gelu(W1 layernorm(x)))) on a (B, H, W, C) float16 tensor, C = 32 or 64 (31-channel groups stored
