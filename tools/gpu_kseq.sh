@@ -11,7 +11,8 @@ f = glob.glob("gpurun_out/kseq/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 marker = "$2" or "conv_in_u8"
 marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-a, b = (marks[-3], marks[-2]) if len(marks) >= 3 else (max(0, len(rows) - 60), len(rows))
+# the last marks belong to bench.py's parity check (two forward passes since round 3) and follow the dominant-kernel loop: take a frame from the middle of the timed region
+a, b = (marks[len(marks) // 2], marks[len(marks) // 2 + 1]) if len(marks) >= 4 else (max(0, len(rows) - 60), len(rows))
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
 tot = 0
