@@ -723,9 +723,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
     constexpr int TW = 14, VW = 18, VR = TR + 4, MR = TR + 2, NOCT = C / 8, NK = C / 16, NT = C / 32, NS = C / 16, LNV = C / 16;
     constexpr int PP = C * 2 + 16, RP = (VW * PP + 255) / 256 * 256, MP = 16 * PP;  // pixel pitch; row pitch of v (18 px) and of mid (16 px): multiples of 256 bytes
     constexpr int NTHR = 64 * NW, NG = (VR * VW + 31) / 32, NGW = (NG + NW - 1) / NW;                     // 32-pixel groups of the halo region; per wave
-    constexpr int WPO = NW / NOCT, NOUT = (TR / 2) / WPO, NMID = NOUT + 1;           // waves per octet; output / mid row pairs per wave
-    static_assert(C == 32 || C == 64, "31- or 62-channel blocks");
-    static_assert(MP % 256 == 0 && NW % NOCT == 0 && (TR / 2) % WPO == 0, "pitches / row split");
+    constexpr int WPO = NOCT >= NW ? 1 : NW / NOCT, OPW = NOCT > NW ? NOCT / NW : 1;  // waves per octet; octets per wave (C = 128: two, taken one after the other, fragments loaded per octet)
+    constexpr int NOUT = (TR / 2) / WPO, NMID = NOUT + 1;                             // output / mid row pairs per wave and octet
+    static_assert(C == 32 || C == 64 || C == 128, "31-, 62- or 124-channel blocks");
+    static_assert(MP % 256 == 0 && (NW % NOCT == 0 || NOCT % NW == 0) && (TR / 2) % WPO == 0, "pitches / row split");
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* vt = smem;                                            // [VR][RP]: v on the halo region (zeros outside the image)
     unsigned char* mt = vt + (size_t)VR * RP;                            // [MR][MP]: mid = gelu(dw1(v)), 16 columns; an octet's bytes belong to its wave(s)
@@ -744,19 +745,22 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
     const int tx = (W + TW - 1) / TW, ty = (H + TR - 1) / TR;
     const long total = (long)B * ty * tx;
     for (int i = tid; i < NT * NS * 64; i += NTHR) wvl[i] = wvpack[i];
-    const int o = wave % NOCT, rpo = (wave / NOCT) * NOUT;  // this wave's octet and first row pair
+    const int o = wave % NOCT, rpo = (wave / NOCT) * NOUT;  // this wave's (first) octet and first row pair
     half8_t a1[3], a2[3], am[NK];
     float bs[4];
+    auto load_frags = [&](int oc) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        a1[i] = __builtin_bit_cast(half8_t, dw1[((size_t)o * 3 + i) * 64 + lane]);
-        a2[i] = __builtin_bit_cast(half8_t, dw2[((size_t)o * 3 + i) * 64 + lane]);
-    }
+        for (int i = 0; i < 3; ++i) {
+            a1[i] = __builtin_bit_cast(half8_t, dw1[((size_t)oc * 3 + i) * 64 + lane]);
+            a2[i] = __builtin_bit_cast(half8_t, dw2[((size_t)oc * 3 + i) * 64 + lane]);
+        }
 #pragma unroll
-    for (int t2 = 0; t2 < NK; ++t2) am[t2] = __builtin_bit_cast(half8_t, mpack[((size_t)o * NK + t2) * 64 + lane]);
+        for (int t2 = 0; t2 < NK; ++t2) am[t2] = __builtin_bit_cast(half8_t, mpack[((size_t)oc * NK + t2) * 64 + lane]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bs[j] = bias ? bias[8 * o + 4 * (q & 1) + j] : 0.f;
-    // The fragments above stay in registers for the whole launch.  Used once here: the compiler's wait for their loads then sits in front of the
+        for (int j = 0; j < 4; ++j) bs[j] = bias ? bias[8 * oc + 4 * (q & 1) + j] : 0.f;
+    };
+    load_frags(o);
+    // One octet per wave: the fragments above stay in registers for the whole launch.  Used once here: the compiler's wait for their loads then sits in front of the
     // tile loop -- left to their first use INSIDE the loop, the in-order load counter would drain every tile's prefetches at that point.
 #pragma unroll
     for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(a1[i]), "v"(a2[i]));
@@ -844,6 +848,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
         stamp(1);
         const long next = tile + gridDim.x;
         if (next < total) fetch(tile_at(ahead));  // the next tile's halo rows: in flight while this wave works through its units
+#pragma unroll
+        for (int kk = 0; kk < OPW; ++kk) {
+        const int oc = o + NW * kk, ob = 16 * NW * kk;  // this pass's octet; its byte offset from the lane-constant addresses (which carry octet o)
+        if constexpr (OPW > 1) load_frags(oc);
         // the residual's pieces of x for this wave's output units (8 bytes per lane and unit): requested now, added at the stores
         uint2 xr[NOUT];
         size_t e_off[NOUT];
@@ -851,7 +859,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
         for (int u = 0; u < NOUT; ++u) {
             const int yo = t.y0 + 2 * (rpo + u) + (q >> 1), xo = t.x0 + n16;
             const bool live = n16 < TW && yo < H && xo < W;
-            e_off[u] = live ? ((t.b * H + yo) * (size_t)W + xo) * C + 8 * o + 4 * (q & 1) : ~(size_t)0;
+            e_off[u] = live ? ((t.b * H + yo) * (size_t)W + xo) * C + 8 * oc + 4 * (q & 1) : ~(size_t)0;
             xr[u] = live ? *reinterpret_cast<const uint2*>(x + e_off[u]) : uint2{0, 0};
         }
         // ---- conv1 + GELU -> mid, this wave's octet, mid row pairs rpo ... rpo + NOUT (zero outside the image: the second conv's padding applies to THIS map) ----
@@ -861,7 +869,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
             uint4 bq[3];
             auto rd = [&](int u) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbB + (size_t)(2 * (rpo + u)) * RP + i * PP);
+                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbB + (size_t)(2 * (rpo + u)) * RP + i * PP + ob);
             };
             auto finish = [&](int u, float4_t a) {
                 float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
                     const unsigned keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
                     ov.x &= keep; ov.y &= keep;
                 }
-                *reinterpret_cast<uint2*>(wbB + (size_t)(2 * (rpo + u)) * MP) = ov;
+                *reinterpret_cast<uint2*>(wbB + (size_t)(2 * (rpo + u)) * MP + ob) = ov;
             };
             rd(0);
             float4_t prev = {0.f, 0.f, 0.f, 0.f};
@@ -895,7 +903,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
             uint4 bq[3], bg[NK];
             auto rd = [&](int u) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbC + (size_t)(2 * (rpo + u)) * MP + i * PP);
+                for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbC + (size_t)(2 * (rpo + u)) * MP + i * PP + ob);
 #pragma unroll
                 for (int t2 = 0; t2 < NK; ++t2) bg[t2] = *reinterpret_cast<const uint4*>(rbG + (size_t)(2 * (rpo + u)) * RP + 32 * t2);
             };
@@ -917,6 +925,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
                 }
             }
         }
+        }  // octets of this wave
         stamp(3);
         if (next >= total) break;
         tile = next;
@@ -1591,13 +1600,14 @@ extern "C" int avx_mst_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvp
                                     const float* bias, void* out, int B, int H, int W, int C, void* stream) {
     if (!ctx) return AVX_ERR_INVALID;
     AVX_REQUIRE(ctx, x && wvpack16 && mpack_mx && dw1pack && dw2pack && out && B > 0 && H > 0 && W > 0, "avx_mst_attn_tail_mx: NULL pointer or empty tensor");
-    AVX_REQUIRE(ctx, C == 32 || C == 64, "avx_mst_attn_tail_mx: C=%d (32 or 64)", C);
+    AVX_REQUIRE(ctx, C == 32 || C == 64 || C == 128, "avx_mst_attn_tail_mx: C=%d (32, 64 or 128)", C);
     AVX_REQUIRE(ctx, ((((uintptr_t)x | (uintptr_t)wvpack16 | (uintptr_t)mpack_mx | (uintptr_t)out | (uintptr_t)dw1pack | (uintptr_t)dw2pack)) & 15u) == 0,
                 "avx_mst_attn_tail_mx: pointers must be 16-byte aligned");
     AVX_REQUIRE(ctx, x != out, "avx_mst_attn_tail_mx: tiles read their neighbours' rows of x: the output cannot be x");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
     if (C == 32) return launch_attn_tail_mx<32, 16, 4>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);
+    if (C == 128) return launch_attn_tail_mx<128, 8, 2>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);  // 14 x 8 tiles: 137 KB of LDS, two octets per wave
     // 16 waves per workgroup (AVX_MST_TAIL_NW=16) measured no faster than 8 at C = 64 (258 vs 257 us per 4K launch: the kernel is not bound by occupancy): 8 it stays
     if (getenv("AVX_MST_TAIL_NW") && atoi(getenv("AVX_MST_TAIL_NW")) == 16) return launch_attn_tail_mx<64, 16, 1, 16>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);
     return launch_attn_tail_mx<64, 16, 2>(ctx, x, wvpack16, mpack_mx, dw1pack, dw2pack, bias, out, B, H, W, s);

@@ -696,7 +696,7 @@ class MSTPlusPlus(torch.nn.Module):
                                                          self._w(p + ".to_v.weight", (0, 1))], 0).t().contiguous())
         d = c // heads  # 32: 31 real channels + the zero padding
         if _AVX.fused_ok(x):  # one pass over x: q, k live only in MFMA accumulators, v is the only tensor written
-            tailx = _AVX._tail and _AVX._tailx and c in (32, 64)  # the tail forms v itself: this pass writes nothing but the Gram partials
+            tailx = _AVX._tail and _AVX._tailx and (c in (32, 64) or (c == 128 and _AVX._dwmx))  # the tail forms v itself: this pass writes nothing but the Gram partials
             if _AVX._qkv16:  # K = 16 MFMAs: a quarter of the matrix-core cycles (the K = 8 kernel is bound by them)
                 wpk = self._prep(p + ".qkv.frag16", lambda: pack_qkv16(wqkv))
             else:
@@ -712,7 +712,7 @@ class MSTPlusPlus(torch.nn.Module):
             wpt = self._prep(p + ".proj.t32", lambda: self._w(p + ".proj.weight", (0, 1)).t().float().contiguous())
             bias32 = self._prep(p + ".proj.bias32", lambda: self._w(p + ".proj.bias", (0,)).float().contiguous())
             vi = v.reshape(b, h, w, c) if v is not None else None
-            if _AVX._tail and c in (32, 64):  # v @ M + bias + pos_emb(v) + x in ONE pass over v and x (the block's `msa(x) + x`, :183)
+            if _AVX._tail and (c in (32, 64) or tailx):  # v @ M + bias + pos_emb(v) + x in ONE pass over v and x (the block's `msa(x) + x`, :183)
                 k1, k2 = p + ".pos_emb.0.weight", p + ".pos_emb.2.weight"
                 t1 = self._prep(k1 + ".t9h", lambda: self._w(k1, (0,)).reshape(c, 9).t().contiguous())  # [9][c] float16, tap-major
                 t2 = self._prep(k2 + ".t9h", lambda: self._w(k2, (0,)).reshape(c, 9).t().contiguous())
@@ -954,7 +954,7 @@ def hbm_bytes_per_px(stage: int = 3) -> float:
 
     def msab(c: int) -> float:
         t = 2.0 * c  # one activation tensor
-        if _AVX._tail and _AVX._tailx and c in (32, 64):
+        if _AVX._tail and _AVX._tailx and (c in (32, 64) or (c == 128 and _AVX._dwmx)):
             b = t                      # qkv + Gram: read x only (q, k never leave the matrix cores; v is formed in the tail)
             b += 2 * t                 # attention tail in one pass: read x, write x1 (v = x W_v^T on the tile's halo, in LDS)
             return b + ((2 * t) if (_AVX._ffn and c in _AVX.FFN_FUSED_C) else (t + 4 * t + ((4 * t + 2 * t) if _AVX._ffn2 else (4 * t + 4 * t + 4 * t + 2 * t))))

@@ -398,7 +398,7 @@ int avx_mst_attn_tail_x(avx_ctx* ctx, const void* x, const void* wvpack16, const
  * v_mfma_f32_16x16x32_f16 result tile is 8 channels x 2 vertically adjacent rows x 16 pixels, a depthwise 3x3 conv is three MFMAs per tile
  * (dw1pack / dw2pack: ml/mst_plus_plus.py::pack_dw_mfma fragments of MS_MSA.pos_emb's two weights, :104-106), and v @ M accumulates into the
  * same registers through block-diagonal fragments (mpack_mx: avx_mst_attn_pack_mx).  v = float16(x W_v^T) is formed on the tile's halo as in
- * avx_mst_attn_tail_x.  C = 32 or 64; out != x. */
+ * avx_mst_attn_tail_x.  C = 32, 64 or 128; out != x. */
 int avx_mst_attn_tail_mx(avx_ctx* ctx, const void* x, const void* wvpack16, const void* mpack_mx, const void* dw1pack, const void* dw2pack,
                          const float* bias, void* out, int B, int H, int W, int C, void* stream);
 /* avx_mst_attn_pack16's matrix M in the fragment order avx_mst_attn_tail_mx takes: [C/8][C/16][64][8] float16 (4 C^2 entries, half of them

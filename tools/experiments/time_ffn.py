@@ -24,7 +24,7 @@ for c, div, pfx in ((32, 1, "body.0.encoder_layers.0.0"), (64, 2, "body.0.encode
     us = t(lambda: m._ffn(x, pfx + ".blocks.0.1"))
     us2 = t(lambda: m._ms_msa(x, pfx + ".blocks.0.0", c // 32))
     line = f"C={c}: ffn {us:8.1f} us   msa (gram + pack + tail) {us2:8.1f} us"
-    if c in (32, 64):
+    if c in (32, 64, 128):
         from animal_vision_amd.ml.mst_plus_plus import pack_dw_mfma, pack_fragments16
         p = pfx + ".blocks.0.0"
         heads = c // 32
@@ -37,10 +37,16 @@ for c, div, pfx in ((32, 1, "body.0.encoder_layers.0.0"), (64, 2, "body.0.encode
         o = torch.empty_like(x[0])
         wv16h = pack_fragments16(wqkv[:, 2 * c:].contiguous(), halfrow=True)
         us3 = t(lambda: _AVX.attn_tail_mx(x[0], wv16h, mp, d1, d2, b32, o))
-        t1 = m._w(p + ".pos_emb.0.weight", (0,)).reshape(c, 9).t().contiguous(); t2 = m._w(p + ".pos_emb.2.weight", (0,)).reshape(c, 9).t().contiguous()
-        m16 = _AVX.attn_pack16(gram, nq, nk, resc, wpt)
-        us4 = t(lambda: _AVX.attn_tail_x(x[0], wv16, m16, t1, t2, b32, o))
+        us4 = float("nan")
+        if c != 128:
+            t1 = m._w(p + ".pos_emb.0.weight", (0,)).reshape(c, 9).t().contiguous(); t2 = m._w(p + ".pos_emb.2.weight", (0,)).reshape(c, 9).t().contiguous()
+            m16 = _AVX.attn_pack16(gram, nq, nk, resc, wpt)
+            us4 = t(lambda: _AVX.attn_tail_x(x[0], wv16, m16, t1, t2, b32, o))
         line += f"   tail_mx alone {us3:8.1f} us (round-2 tail {us4:8.1f})"
+        _AVX._dwmx = False
+        us6 = t(lambda: m._ms_msa(x, pfx + ".blocks.0.0", c // 32))
+        _AVX._dwmx = True
+        line += f"   msa round-2 {us6:8.1f}"
     _AVX._dwmx = False
     us5 = t(lambda: m._ffn(x, pfx + ".blocks.0.1"))
     _AVX._dwmx = True
