@@ -35,6 +35,9 @@
 namespace {
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
+#ifndef AVX_FFN32_GM2
+#define AVX_FFN32_GM2 1
+#endif
 constexpr int kFT = 512;              // 8 waves
 constexpr int TS = 16;                // output tile side
 constexpr int HS = TS + 2;            // halo tile side
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                             keep = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 0xffffffffu : 0u;
                         }
                         // GELU of the 16 results, GP1 pairs at a time step-major (gelu_multi): as many as the registers allow without spilling
-                        constexpr int GP1 = (C == 64 && NW == 8) ? 4 : 1;  // C = 32 / 128: no register to spare (more than one pair in flight spills)
+                        constexpr int GP1 = (C == 64 && NW == 8) ? 4 : (C == 32 ? 2 : 1);  // C = 32 / 128: no register to spare (more than one pair in flight spills)
                         unsigned pk[8];
 #pragma unroll
                         for (int v0 = 0; v0 < 8; v0 += GP1) {
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                 auto finish = [&](int u, float4_t a) {
                     const int o2 = u / (TS / 2), pr = u % (TS / 2);
                     float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
-                    if constexpr (C == 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
+                    if constexpr (C == 64 || (C == 32 && AVX_FFN32_GM2)) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
                     *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 16 * NW * o2) = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
                 };
 #ifndef AVX_FFN_PIPE_ALL
