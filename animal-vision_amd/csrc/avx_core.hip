@@ -40,6 +40,7 @@ static void avx_ws_release(avx_ws* w) {
     if (w->d_geom) (void)hipFree(w->d_geom);
     if (w->d_ew) (void)hipFree(w->d_ew);
     if (w->d_scan) (void)hipFree(w->d_scan);
+    if (w->d_periph) (void)hipFree(w->d_periph);
     if (w->bee_small) (void)hipFree(w->bee_small);
     for (int i = 0; i < w->n_geom_tabs; ++i)
         if (((w->geom_tabs[i].key >> 54) & 0xf) < 8) (void)hipFree(w->geom_tabs[i].dev);  // component >= 8: a scalar, not a pointer

@@ -35,6 +35,9 @@ struct avx_ws {
     float* d_scan = nullptr;         // mantis.hip: the blurred scanline plane of the current (H, W, rows, taps) -- frame-independent, kept across frames
     size_t scan_cap = 0;
     uint64_t scan_key = 0;
+    float* d_periph = nullptr;       // mantis.hip: the periphery blend weight 1 / (1 + exp(-softness (r - radius))) of the current (H, W, xx, yy, softness, radius): frame-independent too
+    size_t periph_cap = 0;
+    uint64_t periph_key = 0;
     void* d_ew = nullptr;            // per-block partial reductions of elementwise programs (ew.hip)
     size_t ew_cap = 0;
 };

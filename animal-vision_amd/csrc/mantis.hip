@@ -4,6 +4,7 @@
 // radix-select percentile, threshold encode).  Float contract: within 1e-4 relative of the reference; the
 // categorical `argmax` of :202 can differ where two band maps tie to within rounding.
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "dichromat_common.h"
@@ -193,7 +194,7 @@ __global__ void k_stack_minmax_final(const float2* partial, int nblocks, int K, 
 __global__ __launch_bounds__(kMT) void k_stack_safe_norm(float* __restrict__ S, size_t n, int K, const float2* __restrict__ mm) {
     for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < n * K; i += (size_t)gridDim.x * kMT) {
         const float2 m = mm[i % K];
-        S[i] = (m.y - m.x) < 1e-9f ? 0.f : (S[i] - m.x) / (m.y - m.x);
+        S[i] = stack_norm(S[i], m, 1.0f / (m.y - m.x));  // the same expression as the read-through form (stack_up.h): the two routes stay identical
     }
 }
 
@@ -206,19 +207,20 @@ template <int KT>
 __device__ __forceinline__ void barcode_pixel(const BarcodeArgs& a, size_t p, float (&sn)[KT], float den) {
     float sum = 0.f, best = -1.f;
     float hard[3] = {a.lut[0], a.lut[1], a.lut[2]};
+    const float rden = 1.0f / den;
 #pragma unroll
     for (int k = 0; k < KT; ++k)
         if (KT < KMAX || k < a.K) {
-            sn[k] = clip01f(sn[k] / den);
+            sn[k] = clip01f(div_by_r(sn[k], den, rden));
             sum += sn[k];
             if (sn[k] > best) { best = sn[k]; hard[0] = a.lut[3 * k]; hard[1] = a.lut[3 * k + 1]; hard[2] = a.lut[3 * k + 2]; }  // np.argmax: first maximum
         }
-    const float wden = sum + 1e-8f;
+    const float wden = sum + 1e-8f, rwden = 1.0f / wden;
     float soft[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < KT; ++k)
         if (KT < KMAX || k < a.K) {
-            const float w = sn[k] / wden;
+            const float w = div_by_r(sn[k], wden, rwden);
 #pragma unroll
             for (int c = 0; c < 3; ++c) soft[c] = fma_t(w, a.lut[3 * k + c], soft[c]);
         }
@@ -258,6 +260,23 @@ __global__ __launch_bounds__(kMT) void k_prep_render(const float* __restrict__ l
     }
 }
 
+// :226-242 the polarisation gain of one pixel from its Sobel pair.  cos(2 theta) and sin(2 theta) of theta = atan2(gy, gx) are taken algebraically,
+// (gx^2 - gy^2) / (gx^2 + gy^2) and 2 gx gy / (gx^2 + gy^2) (1, 0 for a zero gradient, where atan2 gives 0): the same functions of the gradient's direction to ~2 ulp
+// without atan2f + cosf + sinf (~100 of this stage's ~250 instructions per pixel; round 3).  cos2g / sin2g arrive as float32((1 - mix) * global).
+__device__ __forceinline__ float pol_gain_of(float gxv, float gyv, float cos2g, float sin2g, float mix, float lin_s, float lin_gamma, float circ_s) {
+    const float r2 = gxv * gxv + gyv * gyv;
+    float c2 = 1.0f, s2 = 0.0f;
+    if (r2 > 0.f) {
+        const float inv = 1.0f / r2;
+        c2 = (gxv * gxv - gyv * gyv) * inv;
+        s2 = (2.0f * gxv * gyv) * inv;
+    }
+    const float cm = cos2g + mix * c2, sm = sin2g + mix * s2;
+    const float al = powf(clip01f(0.5f * (cm + 1.0f)), lin_gamma);
+    const float ac = clip01f(0.5f * (sm + 1.0f));
+    return (1.0f + lin_s * al) + circ_s * ac;
+}
+
 struct PolArgs { const float* gx; const float* gy; size_t n; float cos2g, sin2g, mix, lin_s, lin_gamma, circ_s; float* gain;
                  const float* broad; int H, W; /* broad != NULL: the Sobel pair is computed here (geom.hip::k_sobel3's expressions), gx / gy unused */ };
 // :226-242
@@ -277,12 +296,7 @@ __global__ __launch_bounds__(kMT) void k_polgain(PolArgs a) {
             gxv = dd[0] + dd[1] * 2 + dd[2];
             gyv = ss[2] - ss[0];
         } else { gxv = a.gx[p]; gyv = a.gy[p]; }
-        const float theta = atan2f(gyv, gxv);
-        const float c2 = cosf(2.0f * theta), s2 = sinf(2.0f * theta);
-        const float cm = a.cos2g + a.mix * c2, sm = a.sin2g + a.mix * s2;  // cos2g/sin2g arrive as float32((1-mix)*global)
-        const float al = powf(clip01f(0.5f * (cm + 1.0f)), a.lin_gamma);
-        const float ac = clip01f(0.5f * (sm + 1.0f));
-        a.gain[p] = (1.0f + a.lin_s * al) + a.circ_s * ac;
+        a.gain[p] = pol_gain_of(gxv, gyv, a.cos2g, a.sin2g, a.mix, a.lin_s, a.lin_gamma, a.circ_s);
     }
 }
 
@@ -333,6 +347,240 @@ __global__ __launch_bounds__(kMT) void k_finish(FinishArgs a) {
         }
     }
 }
+
+// ---- the finishing stages fused around their three Gaussian blurs (round 3) -----------------------------------------------------------
+// :214-278 as launched until round 2: prep_render | blur | polgain | blur | unsharp_blend | blur | finish -- seven launches, 211 bytes per pixel of
+// plane round trips.  Here each blur carries its neighbours: the stage in front of it is its PROLOGUE (the value a tile load stores in LDS), the
+// stage behind it its EPILOGUE (applied to the column pass's result while the tile -- and with it the blur's own input at the same pixel -- is
+// still in LDS):
+//   MODE 1  pre-soften:  source = prep_render(baseline) (red kill, haze)                                    -> render planes
+//   MODE 2  unsharp:     source = render (or prep_render(baseline) when pre-soften is off); epilogue = the polarisation gain of :226-242 (Sobel
+//                        pair of `broad` + atan2 / cos / sin / pow, once per pixel), unsharp, barcode blend, scanline gain   -> P2 planes
+//   MODE 3  periphery:   source = P2; epilogue = radial sigmoid blend with the blurred copy + encode                         -> uint8 / float frame
+// A workgroup owns a 64 x 32 tile and passes its three planes through the same LDS tile one after the other; the per-pixel quantities of an
+// epilogue (gain; sigmoid weight; the three codes of an output pixel) stay in registers across the planes.  The blur is k_plane_blur_t's, term for
+// term (row pass = sequential FMA left to right, column pass = centre tap then fma(x[+j] + x[-j], k[r+j], s)), and every pointwise expression is
+// the unfused kernel's: the frames are identical to the seven-launch route (tests/test_mantis_gpu.py; AVX_MANTIS_FUSE=0 pins that route).
+// k_finish's blend weight t = 1 / (1 + exp(-softness (r - radius))), r = sqrt(xx^2 + yy^2) (:270-275), as a plane
+__global__ __launch_bounds__(kMT) void k_periph_plane(const float* __restrict__ xx, const float* __restrict__ yy, int H, int W, float softness, float radius, float* __restrict__ out) {
+    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < (size_t)H * W; p += (size_t)gridDim.x * kMT) {
+        const float xv = xx[p % W], yv = yy[p / W];
+        const float r = __fsqrt_rn(xv * xv + yv * yv);
+        out[p] = 1.0f / (1.0f + expf(-softness * (r - radius)));
+    }
+}
+
+struct FuseArgs {
+    int H, W;
+    float taps[2 * 5 + 1];
+    const float* lin;     // baseline (H x W x 3 linear) when the source is prep_render, else NULL
+    float red_keep, haze, haze_keep, tint[3];
+    const float* in;      // 3 planes (source when lin == NULL)
+    float* out;           // 3 planes (MODE 1, 2)
+    // MODE 2
+    const float* bar; const float* broad; const float* rows;
+    float cos2g, sin2g, mix, lin_s, lin_gamma, circ_s, amount, opacity, scan_gain;
+    // MODE 3
+    const float* tplane;  // the blend weight of every pixel (k_periph_plane)
+    const float* thr; const uint8_t* coarse; uint32_t lo_key; uint8_t* out_u8; float* out_f;
+};
+
+template <int R, int MODE, int TH>
+__global__ __launch_bounds__(kMT) void k_mantis_fused_blur(const FuseArgs a) {
+    constexpr int TW = 64, AH = TH + 2 * R, AW = TW + 2 * R, AWP = (AW + 3) & ~3, NT = 2 * R + 1, NIT = (TH / 4) * TW / kMT, NLD = (AH * AW + kMT - 1) / kMT;
+    static_assert((TH / 4) * TW % kMT == 0, "column-pass items per thread");
+    extern __shared__ __align__(16) float fsm[];
+    float* A = fsm;                    // [3][AH * AWP]  source tiles of the three planes (columns x0 - R ... at 0 ...)
+    float* Bm = fsm + 3 * AH * AWP;    // [3][AH * TW]   row pass
+    __shared__ float thr[MODE == 3 ? 256 : 1];
+    __shared__ uint8_t coarse[MODE == 3 ? kCoarseTableBytes : 1];
+    if constexpr (MODE == 3) {
+        for (int i = threadIdx.x; i < 256; i += kMT) thr[i] = a.thr[i];
+        for (int i = threadIdx.x; i < kCoarseTableBytes; i += kMT) coarse[i] = a.coarse[i];
+    }
+    float tp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) tp[j] = a.taps[j];
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const size_t n = (size_t)a.H * a.W;
+    const float tint[3] = {a.tint[0], a.tint[1], a.tint[2]};
+    // this thread's elements of a source tile: LDS slot (lane-constant) and position in the tile
+    int l_off[NLD], l_y[NLD], l_x[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int i = threadIdx.x + q * kMT, ii = i < AH * AW ? i : 0;
+        l_y[q] = ii / AW; l_x[q] = ii - l_y[q] * AW;
+        l_off[q] = i < AH * AW ? l_y[q] * AWP + l_x[q] : -1;
+    }
+    unsigned l_g[NLD];  // ... and in the frame, relative to the tile's first halo pixel (interior tiles: no reflection, one scalar base)
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) l_g[q] = (unsigned)(l_y[q] * a.W + l_x[q]);
+    for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
+        // interior: the tile and its halo lie inside the frame (uniform) -- no reflection, no bounds tests, one scalar origin; two instantiations of the body
+        const bool interior = x0 - R >= 0 && x0 + TW + R <= a.W && y0 - R >= 0 && y0 + TH + R <= a.H;
+        auto body = [&](auto int_tag) {
+        constexpr bool INT = decltype(int_tag)::value;
+        // ---- the three planes' source tiles: every load of the tile in flight together, the epilogue's per-pixel quantities computed under them ----
+        float ld[NLD][3];
+        const size_t origin = INT ? (size_t)(y0 - R) * a.W + (x0 - R) : 0;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            if (l_off[q] < 0) continue;
+            size_t p;
+            if constexpr (INT) p = origin + l_g[q];
+            else p = (size_t)reflect101(y0 - R + l_y[q], a.H) * a.W + reflect101(x0 - R + l_x[q], a.W);
+            if (a.lin) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ld[q][k] = a.lin[3 * p + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ld[q][k] = a.in[(size_t)k * n + p];
+            }
+        }
+        // per-pixel quantities of the epilogue: this thread's NIT items x 4 rows of the column pass
+        float pq[NIT][4];
+        uint32_t codes[NIT][4];
+        (void)pq; (void)codes;
+        if constexpr (MODE == 2 || MODE == 3) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * kMT, g = i / TW, xl = i - g * TW, x = x0 + xl;
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy) {
+                    const int y = y0 + 4 * g + yy;
+                    pq[it][yy] = 0.f; codes[it][yy] = 0;
+                    if (!INT && (y >= a.H || x >= a.W)) continue;
+                    if constexpr (MODE == 2) {  // k_polgain (the Sobel pair formed here)
+                        const int xm = INT ? x - 1 : reflect101(x - 1, a.W), xp = INT ? x + 1 : reflect101(x + 1, a.W);
+                        float dd[3], ss[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float* Rw = a.broad + (size_t)(INT ? y - 1 + k : reflect101(y - 1 + k, a.H)) * a.W;
+                            dd[k] = Rw[xp] - Rw[xm];
+                            ss[k] = Rw[xm] + Rw[x] * 2 + Rw[xp];
+                        }
+                        const float gxv = dd[0] + dd[1] * 2 + dd[2], gyv = ss[2] - ss[0];
+                        pq[it][yy] = pol_gain_of(gxv, gyv, a.cos2g, a.sin2g, a.mix, a.lin_s, a.lin_gamma, a.circ_s);
+                    } else {  // k_finish's radial sigmoid: a function of (x, y) only, read from the plane built once per geometry (k_periph_plane)
+                        pq[it][yy] = a.tplane[(size_t)y * a.W + x];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            if (l_off[q] < 0) continue;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v = ld[q][k];
+                if (a.lin) {  // k_prep_render
+                    if (k == 0) v = clip01f(v * a.red_keep);
+                    v = a.haze > 0.f ? a.haze_keep * v + a.haze * tint[k] : v;
+                }
+                A[k * (AH * AWP) + l_off[q]] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * AH * (TW / 4); i += kMT) {  // row pass (k_plane_blur_t), the three planes
+            const int k = i / (AH * (TW / 4)), i2 = i - k * (AH * (TW / 4)), ly = i2 / (TW / 4), g = i2 - ly * (TW / 4);
+            const float4* wp = reinterpret_cast<const float4*>(A + k * (AH * AWP) + ly * AWP + 4 * g);
+            float w[(4 + 2 * R + 3) & ~3];
+#pragma unroll
+            for (int q = 0; q < (4 + 2 * R + 3) / 4; ++q) {
+                float4 v = wp[q];
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+            float o[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                float sacc = w[x] * tp[0];
+#pragma unroll
+                for (int j = 1; j < NT; ++j) sacc = fma_t(w[x + j], tp[j], sacc);
+                o[x] = sacc;
+            }
+            *reinterpret_cast<float4*>(Bm + k * (AH * TW) + ly * TW + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {  // column pass + epilogue
+            const int i = threadIdx.x + it * kMT, g = i / TW, xl = i - g * TW, x = x0 + xl;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float w[4 + 2 * R];
+#pragma unroll
+                for (int q = 0; q < 4 + 2 * R; ++q) w[q] = Bm[k * (AH * TW) + (4 * g + q) * TW + xl];
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy) {
+                    const int yl = 4 * g + yy, y = y0 + yl;
+                    float sacc = w[yy + R] * tp[R];
+#pragma unroll
+                    for (int j = 1; j <= R; ++j) sacc = fma_t(w[yy + R + j] + w[yy + R - j], tp[R + j], sacc);
+                    if (!INT && (y >= a.H || x >= a.W)) continue;
+                    const size_t p = (size_t)y * a.W + x;
+                    if constexpr (MODE == 1) {
+                        a.out[(size_t)k * n + p] = sacc;
+                    } else {
+                        const float c = A[k * (AH * AWP) + (yl + R) * AWP + xl + R];  // the blur's own input at this pixel
+                        if constexpr (MODE == 2) {  // k_unsharp_blend
+                            float high = c - sacc;
+                            high = high < -1.f ? -1.f : (high > 1.f ? 1.f : high);
+                            const float r = clip01f(c + (a.amount * pq[it][yy]) * high);
+                            float v = clip01f((1.0f - a.opacity) * r + a.opacity * a.bar[(size_t)k * n + p]);
+                            if (a.rows) v = clip01f(v * (1.0f + a.scan_gain * (a.rows[p] - 0.5f)));
+                            a.out[(size_t)k * n + p] = v;
+                        } else {  // k_finish
+                            const float t = pq[it][yy];
+                            const float v = (1.0f - t) * c + t * sacc;
+                            if (a.out_f) a.out_f[p * 3 + k] = l2s_f(clip01f(v));
+                            else codes[it][yy] |= quantize_coarse<float, kCoarseNFix>(v, thr, coarse, a.lo_key) << (8 * k);
+                        }
+                    }
+                }
+            }
+            if constexpr (MODE == 3) {
+                if (!a.out_f) {
+#pragma unroll
+                    for (int yy = 0; yy < 4; ++yy) {
+                        const int y = y0 + 4 * g + yy;
+                        if (!INT && (y >= a.H || x >= a.W)) continue;
+                        uint8_t* o = a.out_u8 + ((size_t)y * a.W + x) * 3;
+                        o[0] = (uint8_t)(codes[it][yy] & 0xff); o[1] = (uint8_t)((codes[it][yy] >> 8) & 0xff); o[2] = (uint8_t)(codes[it][yy] >> 16);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        };  // body
+        if (interior) body(std::true_type{}); else body(std::false_type{});
+    }
+}
+
+template <int MODE>
+int launch_mantis_fused(avx_ctx* ctx, const FuseArgs& a, int r, hipStream_t s) {
+    const char* th_env = getenv("AVX_MANTIS_FUSE_TH");  // A/B: tile height 16 | 32
+    const int th = th_env && atoi(th_env) == 32 ? 32 : 16;
+    const long tiles = (long)((a.W + 63) / 64) * ((a.H + th - 1) / th);
+    const int g = (int)(tiles < (long)ctx->num_cus * 8 ? tiles : (long)ctx->num_cus * 8);
+#define AVX_MF(RR, THV)                                                                                                                       \
+    {                                                                                                                                         \
+        const size_t lds = sizeof(float) * 3 * ((size_t)(THV + 2 * RR) * ((64 + 2 * RR + 3) & ~3) + (size_t)(THV + 2 * RR) * 64);              \
+        AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_mantis_fused_blur<RR, MODE, THV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_mantis_fused_blur<RR, MODE, THV>), dim3(g), dim3(kMT), lds, s, a);                                              \
+    }
+#define AVX_MF2(RR) case RR: if (th == 32) AVX_MF(RR, 32) else AVX_MF(RR, 16) break;
+    switch (r) {
+        AVX_MF2(1) AVX_MF2(2) AVX_MF2(3) AVX_MF2(4) AVX_MF2(5)
+        default: return AVX_ERR_UNSUPPORTED;
+    }
+#undef AVX_MF2
+#undef AVX_MF
+    AVX_HIP(ctx, hipGetLastError());
+    return AVX_OK;
+}
+inline bool fuse_radius_ok(int ksize) { return ksize >= 3 && ksize <= 11 && (ksize & 1); }
 
 int grid_for(avx_ctx* ctx, size_t items) {
     const size_t want = (items + kMT - 1) / kMT, cap = (size_t)ctx->num_cus * 16;
@@ -634,16 +882,6 @@ static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_h
     } else {
         hipLaunchKernelGGL(k_barcode, dim3(g), dim3(kMT), 0, s, b);
     }
-    // 7) clear-water look
-    hipLaunchKernelGGL(k_prep_render, dim3(g), dim3(kMT), 0, s, baseline, n, d->red_keep, d->haze, d->haze_keep, make_float3(d->haze_tint[0], d->haze_tint[1], d->haze_tint[2]), P0);
-    float* render = P0;
-    if (d->pre_soft_ksize > 0) { if ((rc = avx_uv_plane_blur_device(ctx, P0, P1, 3, H, W, d->pre_soft_ksize, d->pre_soft_taps_host, s))) return rc; render = P1; }
-    // 8) polarisation gain (the Sobel pair of `broad` is formed inside k_polgain)
-    PolArgs pa{gx, gy, n, d->cos2_global, d->sin2_global, d->orientation_mix, d->pol_linear_strength, d->pol_linear_gamma, d->pol_circular_strength, gain, broad, H, W};
-    hipLaunchKernelGGL(k_polgain, dim3(g), dim3(kMT), 0, s, pa);
-    float* other = render == P0 ? P1 : P0;
-    const int do_unsharp = d->unsharp_ksize > 0 && d->unsharp_amount > 0.f;
-    if (do_unsharp) { if ((rc = avx_uv_plane_blur_device(ctx, render, other, 3, H, W, d->unsharp_ksize, d->unsharp_taps_host, s))) return rc; }
     // 10) scanlines: rows[y] broadcast along x and blurred -- a function of (H, W, rows, taps) only, not of the frame: built once per
     //     workspace and kept (two launches fewer per frame); the gain itself rides in the blend kernel below
     const float* rr = nullptr;
@@ -668,11 +906,70 @@ static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_h
         }
         rr = ws->d_scan;
     }
+    const int do_unsharp = d->unsharp_ksize > 0 && d->unsharp_amount > 0.f;
+    const int do_periph = d->periph_ksize > 0;
+    // 7-12) the finishing stages.  Fused route (round 3): three launches, each a blur with its neighbours as prologue / epilogue (k_mantis_fused_blur); the
+    // seven-launch route below serves the parameter sets the fused kernels are not instantiated for, and AVX_MANTIS_FUSE=0.
+    const char* fuse_env = getenv("AVX_MANTIS_FUSE");  // read per call: tests flip it
+    const bool fused = !(fuse_env && fuse_env[0] == '0') && do_unsharp && fuse_radius_ok(d->unsharp_ksize) && do_periph && fuse_radius_ok(d->periph_ksize) &&
+                       (d->pre_soft_ksize <= 0 || fuse_radius_ok(d->pre_soft_ksize));
+    if (fused) {
+        FuseArgs f{};
+        f.H = H; f.W = W;
+        f.red_keep = d->red_keep; f.haze = d->haze; f.haze_keep = d->haze_keep;
+        for (int c = 0; c < 3; ++c) f.tint[c] = d->haze_tint[c];
+        auto set_taps = [&](int ksize, const double* taps) { for (int i = 0; i < ksize; ++i) f.taps[i] = (float)taps[i]; };
+        const float* render_src = nullptr;  // NULL: MODE 2 reads prep_render(baseline) itself
+        if (d->pre_soft_ksize > 0) {
+            f.lin = baseline; f.in = nullptr; f.out = P1;
+            set_taps(d->pre_soft_ksize, d->pre_soft_taps_host);
+            if ((rc = launch_mantis_fused<1>(ctx, f, d->pre_soft_ksize / 2, s))) return rc;
+            render_src = P1;
+        }
+        f.lin = render_src ? nullptr : baseline; f.in = render_src; f.out = P2;
+        f.bar = bar; f.broad = broad; f.rows = rr;
+        f.cos2g = d->cos2_global; f.sin2g = d->sin2_global; f.mix = d->orientation_mix; f.lin_s = d->pol_linear_strength; f.lin_gamma = d->pol_linear_gamma;
+        f.circ_s = d->pol_circular_strength; f.amount = d->unsharp_amount; f.opacity = d->barcode_opacity; f.scan_gain = d->scan_row_gain;
+        set_taps(d->unsharp_ksize, d->unsharp_taps_host);
+        if ((rc = launch_mantis_fused<2>(ctx, f, d->unsharp_ksize / 2, s))) return rc;
+        f.lin = nullptr; f.in = P2; f.out = nullptr;
+        {   // the periphery weight plane: a function of (H, W, xx, yy, softness, radius) only -- built once per workspace and kept, like the scanline plane
+            uint64_t key = 0xcbf29ce484222325ull;
+            auto mixb = [&](const void* ptr, size_t bytes) { const unsigned char* q = (const unsigned char*)ptr; for (size_t i = 0; i < bytes; ++i) key = (key ^ q[i]) * 0x100000001b3ull; };
+            const int dims[2] = {H, W};
+            const float prm[2] = {d->periph_softness, d->periph_radius};
+            mixb(dims, sizeof(dims)); mixb(prm, sizeof(prm)); mixb(d->xx_host, sizeof(float) * W); mixb(d->yy_host, sizeof(float) * H);
+            key |= 1;
+            if (ws->periph_key != key || ws->periph_cap < n) {
+                if (ws->periph_cap < n) {
+                    if (ws->d_periph) { AVX_HIP(ctx, hipStreamSynchronize(s)); AVX_HIP(ctx, hipFree(ws->d_periph)); }
+                    ws->d_periph = nullptr; ws->periph_cap = 0;
+                    AVX_HIP(ctx, hipMalloc((void**)&ws->d_periph, sizeof(float) * n));
+                    ws->periph_cap = n;
+                }
+                hipLaunchKernelGGL(k_periph_plane, dim3(g), dim3(kMT), 0, s, dxx, dyy, H, W, d->periph_softness, d->periph_radius, ws->d_periph);
+                ws->periph_key = key;
+            }
+            f.tplane = ws->d_periph;
+        }
+        f.thr = ctx->d_enc_thr_f32; f.coarse = ctx->d_coarse_f32; f.lo_key = ctx->coarse_lo_key[0]; f.out_u8 = out_hwc; f.out_f = out_f;
+        set_taps(d->periph_ksize, d->periph_taps_host);
+        if ((rc = launch_mantis_fused<3>(ctx, f, d->periph_ksize / 2, s))) return rc;
+        return AVX_OK;
+    }
+    // 7) clear-water look
+    hipLaunchKernelGGL(k_prep_render, dim3(g), dim3(kMT), 0, s, baseline, n, d->red_keep, d->haze, d->haze_keep, make_float3(d->haze_tint[0], d->haze_tint[1], d->haze_tint[2]), P0);
+    float* render = P0;
+    if (d->pre_soft_ksize > 0) { if ((rc = avx_uv_plane_blur_device(ctx, P0, P1, 3, H, W, d->pre_soft_ksize, d->pre_soft_taps_host, s))) return rc; render = P1; }
+    // 8) polarisation gain (the Sobel pair of `broad` is formed inside k_polgain)
+    PolArgs pa{gx, gy, n, d->cos2_global, d->sin2_global, d->orientation_mix, d->pol_linear_strength, d->pol_linear_gamma, d->pol_circular_strength, gain, broad, H, W};
+    hipLaunchKernelGGL(k_polgain, dim3(g), dim3(kMT), 0, s, pa);
+    float* other = render == P0 ? P1 : P0;
+    if (do_unsharp) { if ((rc = avx_uv_plane_blur_device(ctx, render, other, 3, H, W, d->unsharp_ksize, d->unsharp_taps_host, s))) return rc; }
     // 9) barcode blend (+ the scanline gain)
     hipLaunchKernelGGL(k_unsharp_blend, dim3(grid_for(ctx, 3 * n)), dim3(kMT), 0, s, render, other, gain, bar, n, d->unsharp_amount, do_unsharp, d->barcode_opacity, P2, rr,
                        d->scan_row_gain);
     // 11-12) periphery + encode
-    const int do_periph = d->periph_ksize > 0;
     if (do_periph) { if ((rc = avx_uv_plane_blur_device(ctx, P2, P0, 3, H, W, d->periph_ksize, d->periph_taps_host, s))) return rc; }
     FinishArgs fa{P2, P0, H, W, dxx, dyy, d->periph_softness, d->periph_radius, do_periph, ctx->d_enc_thr_f32, ctx->d_coarse_f32, ctx->coarse_lo_key[0], out_hwc, out_f};
     hipLaunchKernelGGL(k_finish, dim3(g), dim3(kMT), 0, s, fa);

@@ -24,8 +24,18 @@ __device__ __forceinline__ float stack_lerp(float s00, float s01, float s10, flo
     return r0 * b0 + r1 * b1;
 }
 
-// safe_norm of one value (uv_helpers.py:47-53)
-__device__ __forceinline__ float stack_norm(float v, float2 m) { return (m.y - m.x) < 1e-9f ? 0.f : (v - m.x) / (m.y - m.x); }
+// a / b given r = 1.0f / b (the IEEE reciprocal): one multiply and two FMAs instead of the ~11 instructions of a float32 division.  With the correctly rounded
+// reciprocal, q = RN(a r), the exact residual e = a - q b and RN(q + e r) give the correctly rounded quotient (Markstein) whenever q is a faithful rounding of
+// a / b -- all but the rare operands whose first product is 2 ulp off, where the result may differ from a / b in the last place (inside every tolerance of this
+// path: its consumers are a percentile and an argmax over values compared at 1e-4).  Used where one denominator serves many numerators: safe_norm's range of a
+// band (uniform over the frame), the barcode's P95 and per-pixel weight sum.
+__device__ __forceinline__ float div_by_r(float a, float b, float r) {
+    const float q = a * r;
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, r, q);
+}
+// safe_norm of one value (uv_helpers.py:47-53); rinv = 1.0f / (m.y - m.x)
+__device__ __forceinline__ float stack_norm(float v, float2 m, float rinv) { return (m.y - m.x) < 1e-9f ? 0.f : div_by_r(v - m.x, m.y - m.x, rinv); }
 
 // the K values of frame pixel (x, y): resized, and normalised when u.mm is set
 __device__ __forceinline__ void stack_up_pixel(const StackUp& u, int x, int y, float (&v)[kStackKMax]) {
@@ -39,7 +49,7 @@ __device__ __forceinline__ void stack_up_pixel(const StackUp& u, int x, int y, f
     for (int k = 0; k < kStackKMax; ++k)
         if (k < u.K) {
             const float r = stack_lerp(S0[k], S0[o + k], S1[k], S1[o + k], a0, a1, b0, b1, inner);
-            v[k] = u.mm ? stack_norm(r, u.mm[k]) : r;
+            v[k] = u.mm ? stack_norm(r, u.mm[k], 1.0f / (u.mm[k].y - u.mm[k].x)) : r;
         }
 }
 
@@ -96,7 +106,7 @@ __device__ __forceinline__ StackTile stack_tile_load(const StackUp& u, int x0, i
 // value array was copied around them (615 vector instructions per pixel instead of ~120).
 template <int K, bool NORM>
 __device__ __forceinline__ void stack_up_pixel_tile(const StackUp& u, const StackTile& g, const float* lds, int x, int y, const int sx, const float a1, const float2 (&mm)[K],
-                                                    float (&v)[K]) {
+                                                    const float (&rinv)[K], float (&v)[K]) {
     const int sy0 = u.ay.ofs[y], sy1 = sy0 + 1 < u.hs ? sy0 + 1 : sy0;
     const float a0 = 1.f - a1, b1 = u.ay.f[y], b0 = 1.f - b1;
     const bool inner = x < u.ax.dmax;
@@ -127,7 +137,7 @@ __device__ __forceinline__ void stack_up_pixel_tile(const StackUp& u, const Stac
     }
     if (NORM) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = stack_norm(v[k], mm[k]);
+        for (int k = 0; k < K; ++k) v[k] = stack_norm(v[k], mm[k], rinv[k]);
     }
 }
 
@@ -139,6 +149,9 @@ __device__ __forceinline__ void stack_tiles(const StackUp& u, float* lds, size_t
     float2 mm[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) mm[k] = NORM ? u.mm[k] : make_float2(0.f, 1.f);  // wave-uniform: scalar registers
+    float rinv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) rinv[k] = 1.0f / (mm[k].y - mm[k].x);  // inf / NaN for an empty range: stack_norm returns 0 there without using it
     for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
         const int y0 = (tile / tiles_x) * kUpTH, x0 = (tile % tiles_x) * kUpTW;
         const StackTile g = stack_tile_load(u, x0, y0, lds, cap_floats, threadIdx.x, 256);
@@ -152,7 +165,7 @@ __device__ __forceinline__ void stack_tiles(const StackUp& u, float* lds, size_t
                 const int y = y0 + ty + 4 * i;
                 if (y < u.H) {
                     float v[K];
-                    stack_up_pixel_tile<K, NORM>(u, g, lds, x, y, sx, a1, mm, v);
+                    stack_up_pixel_tile<K, NORM>(u, g, lds, x, y, sx, a1, mm, rinv, v);
                     body(x, y, v);
                 }
             }

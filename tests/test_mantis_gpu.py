@@ -93,6 +93,26 @@ def test_mantis_reduced_stack_read_through_its_resize_equals_the_materialised_st
         assert np.array_equal(base0, base1) and np.array_equal(out0, out1), (frame.shape, kw, int(np.abs(out0.astype(int) - out1.astype(int)).max()))
 
 
+def test_mantis_fused_finishing_stages_equal_the_seven_launch_route(monkeypatch):
+    """Round 3: prep_render | blur | polgain | blur | unsharp_blend | blur | finish run as three launches, each blur carrying its neighbours
+    as prologue / epilogue (csrc/mantis.hip::k_mantis_fused_blur).  Same expressions in the same order, so uint8 and float frames must be
+    identical to the unfused route -- border tiles (reflection), frames smaller than a tile, pre-soften off, other radii."""
+    from animal_vision_amd.animals import MantisShrimp
+    from animal_vision_amd.synthetic import noise_frame, structured_frame
+
+    cases = ((structured_frame(3, 270, 484), {}), (noise_frame(4, 133, 201), dict(hsi_scale=0.5, panorama_scale=1.2)), (structured_frame(5, 1080, 1920), {}),
+             (noise_frame(6, 40, 50), {}), (structured_frame(7, 97, 130), dict(pre_soft_sigma=0.0)), (noise_frame(8, 200, 333), dict(unsharp_sigma=1.6, periph_blur_sigma=0.4, pre_soft_sigma=0.6)),
+             (structured_frame(9, 64, 96).astype(np.float32) / 255.0, {}))
+    for frame, kw in cases:
+        m = MantisShrimp(**kw)
+        monkeypatch.setenv("AVX_MANTIS_FUSE", "0")
+        base0, out0 = m.visualize(frame)
+        monkeypatch.delenv("AVX_MANTIS_FUSE")
+        base1, out1 = m.visualize(frame)
+        assert out0.dtype == out1.dtype == frame.dtype
+        assert np.array_equal(base0, base1) and np.array_equal(out0, out1), (frame.shape, kw, float(np.abs(out0.astype(np.float64) - out1.astype(np.float64)).max()))
+
+
 def test_mantis_batch_on_lanes_equals_frame_by_frame(monkeypatch):
     """avx_mantis_u8_batch: the frames of a batch run on up to four internal streams with their own workspaces; every frame must
     come out exactly as from the single-frame entry point, with one lane and with four."""
