@@ -98,9 +98,19 @@ __global__ __launch_bounds__(kMT) void k_uv_front_u8(const uint8_t* __restrict__
 // A pixel with a negative channel (cubic overshoot of the panorama warp) takes the band-by-band route, where
 // the per-wavelength clamp_min(0) of classic_rgb_to_hsi.py:81 is applied before the band-pass sum.
 struct StackArgs { const float* lin; size_t n; const float* M; int K; int B; const float* gains; float denom; const float* wts; float* out; };
+// The band-by-band tables (B x 3 gains, K x B window weights) are staged in LDS once per workgroup: the route's loop is a serial chain of B steps, and with the
+// tables in global memory every step waited out a cache round trip (55 us for hummingbird's 270 x 480 small frame, 4 bands x 81 wavelengths; round 3).
+constexpr int kStackBMax = 160;  // wavelengths the LDS tables hold (the reference's grids: 31, 81, 129); longer grids read global memory
 __global__ __launch_bounds__(kMT) void k_rgbf_to_stack(StackArgs a) {
     __shared__ float M[KMAX * 3];
+    __shared__ float gl[kStackBMax * 3];
+    __shared__ float wl[kStackBMax * KMAX];  // [b][KMAX]
+    const bool tab = a.B <= kStackBMax;
     for (int i = threadIdx.x; i < a.K * 3; i += kMT) M[i] = a.M[i];
+    if (tab) {
+        for (int i = threadIdx.x; i < a.B * 3; i += kMT) gl[i] = a.gains[i];
+        for (int i = threadIdx.x; i < a.B * KMAX; i += kMT) { const int b = i / KMAX, k = i - b * KMAX; wl[i] = k < a.K ? a.wts[(size_t)k * a.B + b] : 0.f; }
+    }
     __syncthreads();
     for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
         const float c0 = s2l(a.lin[3 * p]), c1 = s2l(a.lin[3 * p + 1]), c2 = s2l(a.lin[3 * p + 2]);
@@ -113,12 +123,13 @@ __global__ __launch_bounds__(kMT) void k_rgbf_to_stack(StackArgs a) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
             for (int b = 0; b < a.B; ++b) {
-                const float spec = ((a.gains[3 * b + 2] * c2 + a.gains[3 * b + 1] * c1) + a.gains[3 * b] * c0) / a.denom;
+                const float g0 = tab ? gl[3 * b] : a.gains[3 * b], g1 = tab ? gl[3 * b + 1] : a.gains[3 * b + 1], g2 = tab ? gl[3 * b + 2] : a.gains[3 * b + 2];
+                const float spec = ((g2 * c2 + g1 * c1) + g0 * c0) / a.denom;
                 const float sp = spec > 0.f ? spec : 0.f;
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
                     if (k < a.K) {
-                        const float w = a.wts[(size_t)k * a.B + b];
+                        const float w = tab ? wl[b * KMAX + k] : a.wts[(size_t)k * a.B + b];
                         if (w != 0.f) acc[k] = fma_t(sp, w, acc[k]);
                     }
             }

@@ -489,8 +489,13 @@ struct SelPass { int n_jobs, pass, shift, bits; SelState* st; uint32_t* hist; ui
 // NJ percentiles per launch: the data pass walks the NJ arrays one after the other into NJ LDS histograms, and the
 // last workgroup picks for each in turn -- the per-launch fixed costs (LDS clear / flush, ticket, tail latency)
 // are paid once, which is most of the time of a pass at 1080p.
-__device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int bits, unsigned long long rank0, float gamma, int has_next, double* out,
-                         uint32_t prefix0, uint32_t mask0);
+template <bool AG>
+__device__ void sel_pick_t(uint32_t* hist, SelState* st, int pass, int shift, int bits, unsigned long long rank0, float gamma, int has_next, double* out,
+                           uint32_t prefix0, uint32_t mask0);
+__device__ __forceinline__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int bits, unsigned long long rank0, float gamma, int has_next, double* out,
+                                         uint32_t prefix0 = 0u, uint32_t mask0 = 0u) {
+    sel_pick_t<false>(hist, st, pass, shift, bits, rank0, gamma, has_next, out, prefix0, mask0);
+}
 
 template <int NJ>
 __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
@@ -808,8 +813,15 @@ __device__ __forceinline__ void map_rgb(int mode, float U, float B, float G, con
 // the last workgroup of a radix pass: pick the bin holding the rank, narrow the prefix, on the last pass resolve x[k], x[k+1] and
 // NumPy's float32 lerp (the logic of k_sel_pass's tail, for one job)
 // prefix0 / mask0: key bits every element is known to share before the first pass (0 / 0: none)
-__device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int bits, unsigned long long rank0, float gamma, int has_next, double* out,
-                         uint32_t prefix0 = 0u, uint32_t mask0 = 0u) {
+// AG: the state travels between workgroups INSIDE one launch (k_sel_all): every field is read and written with agent-scope atomics (the L2 slices of the XCDs are not
+// coherent with each other for plain accesses before the kernel ends), and the histogram is left as it is (k_sel_all uses one per pass and clears them at its end).
+__device__ __forceinline__ uint32_t ld_ag(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_ag(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool AG>
+__device__ void sel_pick_t(uint32_t* hist, SelState* st, int pass, int shift, int bits, unsigned long long rank0, float gamma, int has_next, double* out,
+                           uint32_t prefix0, uint32_t mask0) {
     __shared__ unsigned long long csum[kT];
     __shared__ int first_after[kT / 64];
     __shared__ int sel_chunk, sel_bin;
@@ -817,7 +829,7 @@ __device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int 
     __shared__ uint32_t sel_cnt;
     const int nb = 1 << bits, t = threadIdx.x, per = nb / kT;
     const bool last_pass = pass == 2;
-    const uint32_t prefix = pass == 0 ? prefix0 : st->prefix, mask = pass == 0 ? mask0 : st->mask;
+    const uint32_t prefix = pass == 0 ? prefix0 : (AG ? ld_ag(&st->prefix) : st->prefix), mask = pass == 0 ? mask0 : (AG ? ld_ag(&st->mask) : st->mask);
     uint32_t loc[8];
     unsigned long long sum = 0;
 #pragma unroll
@@ -840,7 +852,7 @@ __device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int 
         __syncthreads();
         for (int w = 0; w < wave; ++w) incl += csum[w];
     }
-    const unsigned long long r = pass == 0 ? rank0 : st->rank;
+    const unsigned long long r = pass == 0 ? rank0 : (AG ? ld_ag(&st->rank) : st->rank);
     const unsigned long long excl = incl - sum;
     if (excl <= r && r < incl) sel_chunk = t;
     __syncthreads();
@@ -853,10 +865,17 @@ __device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int 
         }
         if (i == per) i = per - 1;
         const int b = t * per + i;
-        st->prefix = prefix | ((uint32_t)b << shift);
-        st->mask = mask | ((uint32_t)(nb - 1) << shift);
-        st->rank = r - cum;
-        if (pass == 0) st->next_above = 0xffffffffu;
+        if constexpr (AG) {
+            st_ag(&st->prefix, prefix | ((uint32_t)b << shift));
+            st_ag(&st->mask, mask | ((uint32_t)(nb - 1) << shift));
+            st_ag(&st->rank, r - cum);
+            if (pass == 0) st_ag(&st->next_above, 0xffffffffu);
+        } else {
+            st->prefix = prefix | ((uint32_t)b << shift);
+            st->mask = mask | ((uint32_t)(nb - 1) << shift);
+            st->rank = r - cum;
+            if (pass == 0) st->next_above = 0xffffffffu;
+        }
         if (last_pass) { st->key_lo = prefix | (uint32_t)b; st->cnt_in_bin = loc[i]; sel_bin = b; sel_rank = r - cum; sel_cnt = loc[i]; }
     }
     if (last_pass) {
@@ -883,7 +902,8 @@ __device__ void sel_pick(uint32_t* hist, SelState* st, int pass, int shift, int 
             *out = (double)res;
         }
     }
-    for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
+    if constexpr (!AG)
+        for (int i = 0; i < per; ++i) hist[t * per + i] = 0;
     __syncthreads();
 }
 
@@ -1133,11 +1153,138 @@ struct UvScratch {
     Stat3* partials; float4* stats; uint32_t* hist; SelState* sel; uint32_t* ticket; double* pct; float* mat;
 };
 
+// ---- the three radix passes in ONE launch (round 3) ----------------------------------------------------------------------------------------
+// A percentile used to be three dependent launches of ~16-40 us each for a 1080p plane, almost all of it fixed cost (launch, re-reading the plane, the drain before
+// the next pass).  Here the grid stays resident: a workgroup keeps its share of every job in REGISTERS (8 x 16 bytes per thread and job: a whole 1080p plane at one
+// workgroup per CU; what does not fit is re-read), histograms pass p, flushes, takes a ticket; the LAST workgroup picks, then releases the others through a
+// generation counter they poll (agent-scope atomic loads + s_sleep).  The grid is capped at one workgroup per CU (256 threads, 32 KB of LDS at NJ = 4): every
+// workgroup of up to eight such launches is resident at once, so the wait always ends; a wait that outlasts ~1 s gives up (the launch then returns without a result
+// rather than hanging the GPU).  Measured (hummingbird 1080p, phases ablated): 50 us for one plane = visits 14.5 (the run-length LDS atomics), flush 11.6, picks 5.8,
+// the bare ticket / release / poll chain 23 (~ eight dependent agent-scope round trips per pass); the three-launch form took 54.  One global histogram per pass (cleared by the last workgroup at the end: the kernel boundary publishes the zeros).
+struct SelAll { int n_jobs; SelState* st; uint32_t* hist /*[3][kSelMax][2048]*/; uint32_t* ticket; uint32_t* gen; SelJob job[kSelMax]; int shift[3], bits[3]; };
+template <int NJ>
+__global__ __launch_bounds__(kT) void k_sel_all(const SelAll a) {
+    __shared__ uint32_t h[NJ][2048];
+    __shared__ uint32_t wmin[kT / 64];
+    __shared__ int is_last, gave_up;
+    const int t = threadIdx.x;
+    const uint32_t gen0 = ld_ag(a.gen);  // read before this workgroup's first ticket: nobody can have advanced it yet
+    const size_t stride = (size_t)gridDim.x * kT, i0 = (size_t)blockIdx.x * kT + t;
+    auto job_vec = [&](int j, const float4*& xv, size_t& nvec, size_t& head, size_t& tail0) {
+        const SelJob jb = a.job[j];
+        const size_t mis = ((16 - ((uintptr_t)jb.x & 15)) & 15) / 4;
+        head = mis < jb.n ? mis : jb.n;
+        nvec = (jb.n - head) / 4; tail0 = head + nvec * 4;
+        xv = reinterpret_cast<const float4*>(jb.x + head);
+    };
+    float4 keep[NJ][8];  // this thread's first eight vectors of every job: loaded once, visited in all three passes
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j >= a.n_jobs) break;
+        const float4* xv; size_t nvec, head, tail0;
+        job_vec(j, xv, nvec, head, tail0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const size_t idx = i0 + q * stride; keep[j][q] = nvec ? xv[idx < nvec ? idx : nvec - 1] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    if (t == 0) gave_up = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = a.shift[pass], nb = 1 << a.bits[pass];
+        const bool last_pass = pass == 2;
+        for (int i = t; i < NJ * 2048; i += kT) (&h[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j >= a.n_jobs) break;
+            const SelJob jb = a.job[j];
+            SelState* st = a.st + j;
+            const bool find_next = last_pass && jb.has_next;
+            const uint32_t prefix = pass == 0 ? 0u : ld_ag(&st->prefix), mask = pass == 0 ? 0u : ld_ag(&st->mask);
+            const uint32_t above = prefix | ~mask;
+            uint32_t best = 0xffffffffu, run_bin = 0xffffffffu, run_cnt = 0;
+            auto visit = [&](float f) {  // as k_sel_pass: run-length combined LDS atomics
+                const uint32_t k = f2key(f);
+                if ((k & mask) == prefix) {
+                    const uint32_t b = (k >> shift) & (nb - 1);
+                    if (b == run_bin) { ++run_cnt; }
+                    else {
+                        if (run_cnt) atomicAdd(&h[j][run_bin], run_cnt);
+                        run_bin = b; run_cnt = 1;
+                    }
+                } else if (find_next && k > above && k < best) best = k;
+            };
+            const float4* xv; size_t nvec, head, tail0;
+            job_vec(j, xv, nvec, head, tail0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i0 + q * stride < nvec) { visit(keep[j][q].x); visit(keep[j][q].y); visit(keep[j][q].z); visit(keep[j][q].w); }
+            for (size_t i = i0 + 8 * stride; i < nvec; i += 8 * stride) {  // planes beyond 8 vectors per thread: re-read
+                float4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const size_t idx = i + q * stride; v[q] = xv[idx < nvec ? idx : nvec - 1]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i + q * stride < nvec) { visit(v[q].x); visit(v[q].y); visit(v[q].z); visit(v[q].w); }
+            }
+            if (blockIdx.x == 0) {
+                if ((size_t)t < head) visit(jb.x[t]);
+                if (tail0 + t < jb.n && t < 4) visit(jb.x[tail0 + t]);
+            }
+            if (run_cnt) atomicAdd(&h[j][run_bin], run_cnt);
+            if (find_next) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(best, o); best = v < best ? v : best; }
+                __syncthreads();
+                if ((t & 63) == 0) wmin[t >> 6] = best;
+                __syncthreads();
+                if (t == 0) {
+                    for (int w = 1; w < kT / 64; ++w) best = wmin[w] < best ? wmin[w] : best;
+                    if (best != 0xffffffffu) __hip_atomic_fetch_min(&st->next_above, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t* ghist = a.hist + (size_t)pass * kSelMax * 2048;
+        for (int j = 0; j < a.n_jobs; ++j)
+            for (int i = t; i < nb; i += kT)
+                if (h[j][i]) __hip_atomic_fetch_add(&ghist[j * 2048 + i], h[j][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        __syncthreads();
+        if (is_last) {
+            for (int j = 0; j < a.n_jobs; ++j) {
+                const SelJob jb = a.job[j];
+                sel_pick_t<true>(ghist + j * 2048, a.st + j, pass, shift, a.bits[pass], jb.rank0, jb.gamma, jb.has_next, jb.out, 0u, 0u);
+            }
+            if (last_pass)  // leave every histogram of the launch zero for the next one (plain stores: the kernel boundary publishes them)
+                for (int i = t; i < 3 * kSelMax * 2048; i += kT) a.hist[i] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                st_ag(a.ticket, 0u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(a.gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (!last_pass) {
+            if (t == 0) {
+                int spins = 0;
+                while ((int)(ld_ag(a.gen) - (gen0 + (uint32_t)pass + 1u)) < 0) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1 << 20)) { gave_up = 1; break; }
+                }
+            }
+            __syncthreads();
+            if (gave_up) return;
+        }
+    }
+}
+
 static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_ws** out_ws = nullptr) {
     avx_ws* ws = avx_workspace(ctx, stream);
     if (!ws) return AVX_ERR_NOMEM;
     if (out_ws) *out_ws = ws;
-    const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + kSelMax * 2048 * 4 + kSelMax * sizeof(SelState) + 64 + 16 * 8 + 16 * 129 * 4 + 4096;
+    const size_t need = (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3) + 16 * sizeof(float4) + 3 * kSelMax * 2048 * 4 + kSelMax * sizeof(SelState) + 64 + 16 * 8 + 16 * 129 * 4 + 4096;
     if (ws->uv_small == nullptr) {
         AVX_HIP(ctx, hipMalloc(&ws->uv_small, need));
         AVX_HIP(ctx, hipMemsetAsync(ws->uv_small, 0, need, stream));  // histogram and ticket start at zero; k_sel_pass leaves them so
@@ -1145,7 +1292,7 @@ static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_
     char* p = (char*)ws->uv_small;
     s->partials = (Stat3*)p; p += (size_t)ctx->num_cus * 8 * 16 * sizeof(Stat3);
     s->stats = (float4*)p; p += 16 * sizeof(float4);
-    s->hist = (uint32_t*)p; p += kSelMax * 2048 * 4;
+    s->hist = (uint32_t*)p; p += 3 * kSelMax * 2048 * 4;  // one per pass for k_sel_all; the per-pass kernels use the first
     s->sel = (SelState*)p; p += kSelMax * sizeof(SelState) + 8;
     s->ticket = (uint32_t*)p; p += 16;
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
@@ -1179,6 +1326,19 @@ static int run_percentiles(avx_ctx* ctx, const UvScratch& u, const PctReq* req, 
         const size_t cap = (size_t)ctx->num_cus * wg_per_cu;  // measured again in round 2 (hummingbird 1080p: 3.24 / 3.02 / 2.49 / 2.07 GP/s at 1 / 2 / 4 / 8 per CU): every workgroup pays the histogram clear, flush and ticket
         const int g = (int)(want < cap ? (want ? want : 1) : cap);
         const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+        const char* one_env = getenv("AVX_SEL_ONE");  // read per call: tests flip it (0: the three-launch form)
+        if (!(one_env && one_env[0] == '0')) {
+            // one launch for the three passes (k_sel_all): at most one workgroup per CU, so the whole grid is resident and its inner barriers cannot starve
+            SelAll b{};
+            b.n_jobs = nj; b.st = u.sel; b.hist = u.hist; b.ticket = u.ticket; b.gen = u.ticket + 1;
+            for (int j = 0; j < nj; ++j) b.job[j] = a.job[j];
+            for (int p = 0; p < 3; ++p) { b.shift[p] = shifts[p]; b.bits[p] = bits[p]; }
+            const int g1 = (int)(want < (size_t)ctx->num_cus ? (want ? want : 1) : (size_t)ctx->num_cus);
+            if (nj == 1) hipLaunchKernelGGL(k_sel_all<1>, dim3(g1), dim3(kT), 0, s, b);
+            else if (nj == 2) hipLaunchKernelGGL(k_sel_all<2>, dim3(g1), dim3(kT), 0, s, b);
+            else hipLaunchKernelGGL(k_sel_all<4>, dim3(g1), dim3(kT), 0, s, b);
+            continue;
+        }
         for (int p = 0; p < 3; ++p) {
             a.pass = p; a.shift = shifts[p]; a.bits = bits[p];
             if (nj == 1) hipLaunchKernelGGL(k_sel_pass<1>, dim3(g), dim3(kT), 0, s, a);
