@@ -98,45 +98,59 @@ __global__ __launch_bounds__(kMT) void k_uv_front_u8(const uint8_t* __restrict__
 // A pixel with a negative channel (cubic overshoot of the panorama warp) takes the band-by-band route, where
 // the per-wavelength clamp_min(0) of classic_rgb_to_hsi.py:81 is applied before the band-pass sum.
 struct StackArgs { const float* lin; size_t n; const float* M; int K; int B; const float* gains; float denom; const float* wts; float* out; };
-// The band-by-band tables (B x 3 gains, K x B window weights) are staged in LDS once per workgroup: the route's loop is a serial chain of B steps, and with the
-// tables in global memory every step waited out a cache round trip (55 us for hummingbird's 270 x 480 small frame, 4 bands x 81 wavelengths; round 3).
+// Round 3: the band-by-band pixels of a workgroup's 256 are COLLECTED (LDS list) and then worked off densely, one (pixel, window) pair per thread: with the route
+// taken inline a wave paid the B-step serial loop for all 64 lanes as soon as one of its pixels had a negative channel -- on structured frames nearly every wave
+// (hummingbird's 270 x 480 small frame: 53 us; 5 % of the pixels take the route).  The tables (B x 3 gains, K x B window weights) are staged in LDS once per
+// workgroup.  A window's sum still runs over b in order with the same operations, so the values are the inline form's.
 constexpr int kStackBMax = 160;  // wavelengths the LDS tables hold (the reference's grids: 31, 81, 129); longer grids read global memory
 __global__ __launch_bounds__(kMT) void k_rgbf_to_stack(StackArgs a) {
     __shared__ float M[KMAX * 3];
     __shared__ float gl[kStackBMax * 3];
     __shared__ float wl[kStackBMax * KMAX];  // [b][KMAX]
+    __shared__ float lc[kMT][3];             // the collected pixels: linearised channels ...
+    __shared__ unsigned lp[kMT];             // ... and position in the workgroup's batch
+    __shared__ unsigned cnt;
     const bool tab = a.B <= kStackBMax;
     for (int i = threadIdx.x; i < a.K * 3; i += kMT) M[i] = a.M[i];
     if (tab) {
         for (int i = threadIdx.x; i < a.B * 3; i += kMT) gl[i] = a.gains[i];
         for (int i = threadIdx.x; i < a.B * KMAX; i += kMT) { const int b = i / KMAX, k = i - b * KMAX; wl[i] = k < a.K ? a.wts[(size_t)k * a.B + b] : 0.f; }
     }
+    if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    for (size_t p = (size_t)blockIdx.x * kMT + threadIdx.x; p < a.n; p += (size_t)gridDim.x * kMT) {
-        const float c0 = s2l(a.lin[3 * p]), c1 = s2l(a.lin[3 * p + 1]), c2 = s2l(a.lin[3 * p + 2]);
-        if (c0 >= 0.f && c1 >= 0.f && c2 >= 0.f) {
-            for (int k = 0; k < a.K; ++k) a.out[p * a.K + k] = fma_t(c2, M[3 * k + 2], fma_t(c1, M[3 * k + 1], c0 * M[3 * k]));
-        } else {
-            // band by band: the wavelength's value (one division) is shared by the K windows -- computed once per wavelength, not once per
-            // (window, wavelength); each window's sum still runs over b in order, and a zero weight leaves it unchanged either way
-            float acc[KMAX];
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    for (size_t base = (size_t)blockIdx.x * kMT; base < a.n; base += (size_t)gridDim.x * kMT) {
+        const size_t p = base + threadIdx.x;
+        if (p < a.n) {
+            const float c0 = s2l(a.lin[3 * p]), c1 = s2l(a.lin[3 * p + 1]), c2 = s2l(a.lin[3 * p + 2]);
+            if (c0 >= 0.f && c1 >= 0.f && c2 >= 0.f) {
+                for (int k = 0; k < a.K; ++k) a.out[p * a.K + k] = fma_t(c2, M[3 * k + 2], fma_t(c1, M[3 * k + 1], c0 * M[3 * k]));
+            } else {
+                const unsigned i = atomicAdd(&cnt, 1u);
+                lc[i][0] = c0; lc[i][1] = c1; lc[i][2] = c2; lp[i] = threadIdx.x;
+            }
+        }
+        __syncthreads();
+        const unsigned m = cnt;
+        // band by band, one (collected pixel, window) pair per thread: the wavelength's value (three products and one division) then the window's FMA, b in order;
+        // a zero weight leaves the sum unchanged (as the inline form's skip did)
+        for (unsigned it = threadIdx.x; it < m * (unsigned)a.K; it += kMT) {
+            const unsigned i = it / (unsigned)a.K, k = it - i * (unsigned)a.K;
+            const float c0 = lc[i][0], c1 = lc[i][1], c2 = lc[i][2];
+            float acc = 0.f;
+            const float rden = 1.0f / a.denom;  // one denominator for every wavelength: div_by_r (stack_up.h)
+#pragma unroll 4
             for (int b = 0; b < a.B; ++b) {
                 const float g0 = tab ? gl[3 * b] : a.gains[3 * b], g1 = tab ? gl[3 * b + 1] : a.gains[3 * b + 1], g2 = tab ? gl[3 * b + 2] : a.gains[3 * b + 2];
-                const float spec = ((g2 * c2 + g1 * c1) + g0 * c0) / a.denom;
+                const float spec = div_by_r((g2 * c2 + g1 * c1) + g0 * c0, a.denom, rden);
                 const float sp = spec > 0.f ? spec : 0.f;
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k)
-                    if (k < a.K) {
-                        const float w = tab ? wl[b * KMAX + k] : a.wts[(size_t)k * a.B + b];
-                        if (w != 0.f) acc[k] = fma_t(sp, w, acc[k]);
-                    }
+                const float w = tab ? wl[b * KMAX + k] : a.wts[(size_t)k * a.B + b];
+                if (w != 0.f) acc = fma_t(sp, w, acc);
             }
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < a.K) a.out[p * a.K + k] = acc[k];
+            a.out[(base + lp[i]) * a.K + k] = acc;
         }
+        __syncthreads();
+        if (threadIdx.x == 0) cnt = 0;
+        __syncthreads();
     }
 }
 
