@@ -273,6 +273,7 @@ _SIGS = {
     "avx_mst_ffn_fused": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_mst_conv3x3_lds_spectral": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _fp, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp]),
     "avx_mst_ffn_fused_mx": (_i, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "avx_mst_gelu_prescale": (ctypes.c_float, []),
     "avx_mst_dw_gemm_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "avx_dwconv3x3_nhwc_add": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "avx_dwconv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

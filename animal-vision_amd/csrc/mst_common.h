@@ -117,6 +117,75 @@ __device__ __forceinline__ void gelu_multi(float2_t (&x)[NP]) {
 #endif
 }
 
+// ---- prescaled form (round 3): six packed + four full-rate instructions per pair instead of ten packed-rate ones -----------------------------------------------------------------
+// The two v_med3_f32 of gelu_poly2 exist to clamp x; float32 instructions clamp their RESULT to [0, 1] for free (the `clamp` bit), so the
+// polynomial is arranged for that to be the only clamp needed: the operator in front of the GELU delivers x' = x / A (its weights are scaled by 1 / A on the
+// host -- A = 4, a power of two: exact in float16), and
+//     t   = clamp01(x' x')                 v_mul_f32 ... clamp         (= (xc / A)^2)
+//     r   = R^(t)                          Horner, R^(t) = A R(A^2 t)  (the same minimax fit, coefficients rescaled)
+//     Phi = clamp01(x' r + 1/2)            v_fma_f32 ... clamp         (|x| > A: R^(1) = 1/2, so the sum leaves [0, 1] and the clamp pins Phi to 0 / 1)
+//     out = x' Phi                         = gelu(x) / A: the operator behind takes its weights times A (depthwise conv -> the second GELU sees x2 / A again; the
+//                                            last 1x1 conv / second depthwise conv restores the scale)
+// Inside |x| <= A this is gelu_poly2's value; outside it is x or 0 exactly.  Degree 5 at A = 4: |error| <= 1.1e-3 relative (x > 0) / absolute (x < 0); degree 6:
+// 2.4e-4 (tools/experiments/gelu_fit.py; -DAVX_GELU_PRE_DEG).  -DAVX_GELU_PRE=0 builds the kernels with gelu_poly2 and unscaled weights (avx_mst_gelu_prescale()
+// tells the host which).
+#ifndef AVX_GELU_PRE
+#define AVX_GELU_PRE 1
+#endif
+#ifndef AVX_GELU_PRE_DEG
+#define AVX_GELU_PRE_DEG 5
+#endif
+#if AVX_GELU_PRE_DEG == 5
+#define AVX_GELU_PRE_COEFFS {0x1.960306p+0f, -0x1.fc1ff8p+1f, 0x1.ee409cp+2f, -0x1.262110p+3f, 0x1.7b5900p+2f, -0x1.932106p+0f}
+#elif AVX_GELU_PRE_DEG == 6
+#define AVX_GELU_PRE_COEFFS {0x1.97e942p+0f, -0x1.0a57bcp+2f, 0x1.249574p+3f, -0x1.b85e3cp+3f, 0x1.a4e7c2p+3f, -0x1.c69c8ep+2f, 0x1.a2f00ap+0f}
+#else
+#error "AVX_GELU_PRE_DEG must be 5 or 6"
+#endif
+constexpr float kGeluPrescale = AVX_GELU_PRE ? 4.0f : 1.0f;
+// Written as fmed3(v, 0, 1) of the product / FMA: the compiler folds that into the instruction's clamp bit (v_mul_f32 / v_fma_f32 ... clamp) and keeps its own
+// hazard bookkeeping -- as inline assembly the instructions sat directly behind the packed FMAs whose results they read, without the wait states the compiler
+// inserts between such pairs on gfx950, and read stale registers (measured: wrong values in 60 % of the outputs).
+__device__ __forceinline__ float2_t pk_sq_clamp(float2_t a) {
+    return float2_t{__builtin_amdgcn_fmed3f(a.x * a.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(a.y * a.y, 0.0f, 1.0f)};
+}
+__device__ __forceinline__ float2_t pk_fma_half_clamp(float2_t a, float2_t b) {  // clamp01(a b + 1/2)
+    return float2_t{__builtin_amdgcn_fmed3f(__builtin_fmaf(a.x, b.x, 0.5f), 0.0f, 1.0f), __builtin_amdgcn_fmed3f(__builtin_fmaf(a.y, b.y, 0.5f), 0.0f, 1.0f)};
+}
+// NP pairs step-major (as gelu_multi); x holds x / A on entry, gelu(x) / A on return
+template <int NP>
+__device__ __forceinline__ void gelu_pre_multi(float2_t (&x)[NP]) {
+    constexpr int D = AVX_GELU_PRE_DEG;
+    constexpr float R[D + 1] = AVX_GELU_PRE_COEFFS;
+    auto c2 = [](float v) { return float2_t{v, v}; };
+    float2_t t[NP], r[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) t[i] = pk_sq_clamp(x[i]);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = __builtin_elementwise_fma(t[i], c2(R[D]), c2(R[D - 1]));
+#pragma unroll
+    for (int k = D - 2; k >= 0; --k) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            r[i] = __builtin_elementwise_fma(r[i], t[i], c2(R[k]));
+            if (NP > 1) asm volatile("" : "+v"(r[i]));  // keeps the step-major order through the scheduler
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = pk_fma_half_clamp(x[i], r[i]);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = x[i] * r[i];
+}
+// the GELU of the matrix-pipe kernels (k_mst_ffn_fused<DWM>, k_mst_attn_tail_mx): prescaled operands when built so
+template <int NP>
+__device__ __forceinline__ void gelu_mx(float2_t (&x)[NP]) {
+#if AVX_GELU_PRE
+    gelu_pre_multi<NP>(x);
+#else
+    gelu_multi<NP>(x);
+#endif
+}
+
 __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
 #ifdef AVX_GELU_SIGMOID
     return gelu_sig2(x);

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                             float2_t gq[GP1];
 #pragma unroll
                             for (int v = 0; v < GP1; ++v) gq[v] = float2_t{d[2 * (v0 + v)], d[2 * (v0 + v) + 1]};
-                            gelu_multi<GP1>(gq);
+                            if constexpr (DWM) gelu_mx<GP1>(gq); else gelu_multi<GP1>(gq);
 #pragma unroll
                             for (int v = 0; v < GP1; ++v) pk[v0 + v] = pack_f16(gq[v].x, gq[v].y);
                         }
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                 auto finish = [&](int u, float4_t a) {
                     const int o2 = u / (TS / 2), pr = u % (TS / 2);
                     float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
-                    if constexpr (C == 64 || (C == 32 && AVX_FFN32_GM2)) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
+                    if constexpr (C == 64 || (C == 32 && AVX_FFN32_GM2)) gelu_mx<2>(gp);
+                    else { float2_t g0[1] = {gp[0]}, g1[1] = {gp[1]}; gelu_mx<1>(g0); gelu_mx<1>(g1); gp[0] = g0[0]; gp[1] = g1[0]; }
                     *reinterpret_cast<uint2*>(wbase + (size_t)(2 * pr) * RPITCH + 16 * NW * o2) = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
                 };
 #ifndef AVX_FFN_PIPE_ALL
@@ -876,7 +877,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_attn_tail_mx(const __half
             };
             auto finish = [&](int u, float4_t a) {
                 float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
-                if constexpr (C >= 64) gelu_multi<2>(gp); else { gp[0] = gelu_fast2(gp[0]); gp[1] = gelu_fast2(gp[1]); }
+                if constexpr (C >= 64) gelu_mx<2>(gp);
+                else { float2_t g0[1] = {gp[0]}, g1[1] = {gp[1]}; gelu_mx<1>(g0); gelu_mx<1>(g1); gp[0] = g0[0]; gp[1] = g1[0]; }
                 uint2 ov = uint2{pack_f16(gp[0].x, gp[0].y), pack_f16(gp[1].x, gp[1].y)};
                 if (!mid_inside) {
                     const int yy = t.y0 - 1 + 2 * (rpo + u) + (q >> 1), xx = t.x0 - 1 + n16;
@@ -1490,6 +1492,10 @@ __global__ __launch_bounds__(256) void k_mst_conv_in_u8_mfma(const uint8_t* __re
 
 static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid, const void* dwpack,
                             const void* w2pack, void* out, int B, int H, int W, int C, void* stream);
+
+// What the matrix-pipe kernels expect of their weights (csrc/mst_common.h, prescaled GELU): avx_mst_ffn_fused_mx takes W1 / s, the depthwise weights as they are
+// and W2 * s; avx_mst_attn_tail_mx takes pos_emb's first depthwise weights / s and the second * s.  s = 4 (1 when built with -DAVX_GELU_PRE=0).
+extern "C" float avx_mst_gelu_prescale(void) { return kGeluPrescale; }
 
 extern "C" int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* taps_9xhid,
                                  const void* w2pack, void* out, int B, int H, int W, int C, void* stream) {

@@ -183,6 +183,7 @@ class _AvxOps:
         self._qkv16 = os.environ.get("AVX_MST_NO_QKV16", "") == ""  # A/B: the Gram pass on K = 16 MFMAs
         self._convgram = os.environ.get("AVX_MST_NO_CONVGRAM", "") == ""  # A/B: the embedding conv carries the first block's Gram pass as its epilogue
         self._ffn = os.environ.get("AVX_MST_NO_FFN_FUSED", "") == ""  # A/B: the whole FeedForward in one kernel, hidden tile in LDS
+        self._gelu_pre = None
         self._dwmx = os.environ.get("AVX_MST_NO_DW_MFMA", "") == ""  # A/B: depthwise 3x3 convs on the matrix pipe (round 3)
         self._specfuse = os.environ.get("AVX_MST_NO_SPEC_FUSE", "") == ""  # A/B: the spectral integration as conv_out's epilogue (the cube is never written)
         self.FFN_FUSED_C = tuple(int(v) for v in os.environ.get("AVX_MST_FFN_FUSED_C", "32,64,128").split(",") if v)
@@ -221,6 +222,13 @@ class _AvxOps:
         for i in range(b):
             ctx._check(lib.avx_mst_gram(ctx._h, qkv[i].data_ptr(), self._dt(qkv), n, c, heads, g[i].data_ptr(), nq[i].data_ptr(), nk[i].data_ptr(), st))
         return g[:, :, :d, :d], nq, nk
+
+    def gelu_prescale(self) -> float:
+        """s of include/avx.h::avx_mst_gelu_prescale: the matrix-pipe kernels' GELU takes x / s and returns gelu(x) / s."""
+        if self._gelu_pre is None:
+            from .. import _lib
+            self._gelu_pre = float(_lib.lib.avx_mst_gelu_prescale())
+        return self._gelu_pre
 
     def fused_ok(self, x: torch.Tensor) -> bool:
         """The matrix-core kernels take float16 rows of 32, 64 or 128 channels."""
@@ -720,8 +728,9 @@ class MSTPlusPlus(torch.nn.Module):
                 out = torch.empty_like(xc)
                 if tailx and _AVX._dwmx:  # both depthwise convs and the projection on the matrix pipe
                     wv16 = self._prep(p + ".wv.frag16h", lambda: pack_fragments16(wqkv[:, 2 * c :].contiguous(), halfrow=True))
-                    d1 = self._prep(k1 + ".dwmx", lambda: pack_dw_mfma(self._w(k1, (0,))))
-                    d2 = self._prep(k2 + ".dwmx", lambda: pack_dw_mfma(self._w(k2, (0,))))
+                    gs = _AVX.gelu_prescale()  # the GELU between the two convs works on x / gs (csrc/mst_common.h): first conv / gs, second * gs
+                    d1 = self._prep(k1 + f".dwmx/{gs}", lambda: pack_dw_mfma((self._w(k1, (0,)).float() / gs).to(x.dtype)))
+                    d2 = self._prep(k2 + f".dwmx*{gs}", lambda: pack_dw_mfma((self._w(k2, (0,)).float() * gs).to(x.dtype)))
                     for i in range(b):
                         _AVX.attn_tail_mx(xc[i], wv16, _AVX.attn_pack_mx(gram[i], nq[i], nk[i], resc, wpt), d1, d2, bias32, out[i])
                     return out
@@ -790,11 +799,14 @@ class MSTPlusPlus(torch.nn.Module):
         b32 = self._prep(p + ".b32", lambda: self._w(p + ".norm.bias", (0,)).float().contiguous())
         w2 = self._prep(p + ".w2", lambda: self._w(p + ".fn.net.4.weight", (0, 1)).reshape(c, 4 * c).t().contiguous())
         if _AVX.fused_ok(x) and _AVX._ffn and c in _AVX.FFN_FUSED_C:  # the whole FeedForward + residual in one kernel: the hidden tensor stays in LDS
-            w1q = self._prep(p + ".w1.frag16", lambda: pack_fragments16(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous()))
-            w2q = self._prep(p + ".w2.frag16", lambda: pack_fragments16(w2))
             key = p + ".fn.net.2.weight"
             if _AVX._dwmx:
-                return _AVX.ffn_fused(x, g32, b32, w1q, None, w2q, dwpack=self._prep(key + ".dwmx", lambda: pack_dw_mfma(self._w(key, (0,)))))
+                gs = _AVX.gelu_prescale()  # both GELUs work on x / gs (csrc/mst_common.h): W1 / gs, the depthwise conv as it is (linear: x2 / gs again), W2 * gs
+                w1s = self._prep(p + f".w1.frag16/{gs}", lambda: pack_fragments16((self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().float() / gs).to(x.dtype).contiguous()))
+                w2s = self._prep(p + f".w2.frag16*{gs}", lambda: pack_fragments16((w2.float() * gs).to(x.dtype).contiguous()))
+                return _AVX.ffn_fused(x, g32, b32, w1s, None, w2s, dwpack=self._prep(key + ".dwmx", lambda: pack_dw_mfma(self._w(key, (0,)))))
+            w1q = self._prep(p + ".w1.frag16", lambda: pack_fragments16(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous()))
+            w2q = self._prep(p + ".w2.frag16", lambda: pack_fragments16(w2))
             t9 = self._prep(key + ".t9h", lambda: self._w(key, (0,)).reshape(4 * c, 9).t().contiguous())  # [9][4c], tap-major, the model's own float16 values
             return _AVX.ffn_fused(x, g32, b32, w1q, t9, w2q)
         if _AVX.fused_ok(x):  # LayerNorm -> 1x1 conv -> GELU on the matrix cores, the hidden tensor is written once

@@ -428,6 +428,11 @@ int avx_mst_ffn_fused(avx_ctx* ctx, const void* x, const float* gamma, const flo
  * (ml/mst_plus_plus.py::pack_dw_mfma).  Same result up to the summation order of the nine taps (float32 accumulation in both). */
 int avx_mst_ffn_fused_mx(avx_ctx* ctx, const void* x, const float* gamma, const float* beta, float eps, const void* w1pack, const void* dwpack,
                          const void* w2pack, void* out, int B, int H, int W, int C, void* stream);
+/* The matrix-pipe kernels evaluate GELU on PRESCALED operands (csrc/mst_common.h: x / s enters, gelu(x) / s leaves; two packed instructions fewer per pair).
+ * s = avx_mst_gelu_prescale() (4: a power of two, exact in float16; 1 when the library was built without the prescaled form), and the caller scales the
+ * weights around each GELU accordingly: avx_mst_ffn_fused_mx takes W1 / s in w1pack, the depthwise weights unscaled and W2 * s in w2pack;
+ * avx_mst_attn_tail_mx takes pos_emb's first depthwise weights / s in dw1pack and the second * s in dw2pack. */
+float avx_mst_gelu_prescale(void);
 
 /* out = [add +] a @ W [+ a2 @ W2] for (rows x C) float16 tensors and C x C weights in fragment order (out may alias
  * add; a2 / W2 and add may be NULL): MS_MSA's `proj(attn @ v)` collapsed to one matrix per frame (:132-135)
