@@ -157,6 +157,15 @@ def pack_dw_mfma(w: torch.Tensor) -> torch.Tensor:
     return out.contiguous()
 
 
+def fold_layernorm(w1_kn: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, scale: float) -> torch.Tensor:
+    """(K = c input channels, N) weight of the 1x1 conv behind a LayerNorm -> float32 (K, N) weight for avx_mst_ffn_fused_mx, whose LayerNorm only centres and
+    scales (include/avx.h): row k times gamma[k], row 31 (the first 32-wide group's padding channel; the kernel feeds it a 1) = beta @ W, everything / scale."""
+    w = w1_kn.float()
+    out = w * gamma.float()[:, None]
+    out[31, :] = beta.float() @ w
+    return (out / scale).contiguous()
+
+
 def pack_down4x4(w: torch.Tensor) -> torch.Tensor:
     """(Cout, Cin, 4, 4) float16 stride-2 conv weight -> [16 taps][Cout/32][Cin/16][64][8] fragments (tap = 4 ky + kx), the A operands
     of csrc/mst_fused.hip::k_mst_down4x4_dma."""
@@ -802,7 +811,7 @@ class MSTPlusPlus(torch.nn.Module):
             key = p + ".fn.net.2.weight"
             if _AVX._dwmx:
                 gs = _AVX.gelu_prescale()  # both GELUs work on x / gs (csrc/mst_common.h): W1 / gs, the depthwise conv as it is (linear: x2 / gs again), W2 * gs
-                w1s = self._prep(p + f".w1.frag16/{gs}", lambda: pack_fragments16((self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().float() / gs).to(x.dtype).contiguous()))
+                w1s = self._prep(p + f".w1.frag16.ln/{gs}", lambda: pack_fragments16(fold_layernorm(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t(), g32, b32, gs).to(x.dtype)))
                 w2s = self._prep(p + f".w2.frag16*{gs}", lambda: pack_fragments16((w2.float() * gs).to(x.dtype).contiguous()))
                 return _AVX.ffn_fused(x, g32, b32, w1s, None, w2s, dwpack=self._prep(key + ".dwmx", lambda: pack_dw_mfma(self._w(key, (0,)))))
             w1q = self._prep(p + ".w1.frag16", lambda: pack_fragments16(self._w(p + ".fn.net.0.weight", (0, 1)).reshape(4 * c, c).t().contiguous()))

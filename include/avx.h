@@ -430,7 +430,9 @@ int avx_mst_ffn_fused_mx(avx_ctx* ctx, const void* x, const float* gamma, const 
                          const void* w2pack, void* out, int B, int H, int W, int C, void* stream);
 /* The matrix-pipe kernels evaluate GELU on PRESCALED operands (csrc/mst_common.h: x / s enters, gelu(x) / s leaves; two packed instructions fewer per pair).
  * s = avx_mst_gelu_prescale() (4: a power of two, exact in float16; 1 when the library was built without the prescaled form), and the caller scales the
- * weights around each GELU accordingly: avx_mst_ffn_fused_mx takes W1 / s in w1pack, the depthwise weights unscaled and W2 * s in w2pack;
+ * weights around each GELU accordingly: avx_mst_ffn_fused_mx takes W1 / s in w1pack, the depthwise weights unscaled and W2 * s in w2pack -- and, since its
+ * LayerNorm only centres and scales (round 3), LayerNorm's gamma and beta FOLDED into w1pack as well: row k of W1 (input channel k) times gamma[k], and row 31
+ * (the first group's padding channel, whose operand the kernel sets to 1) = W1^T beta; its gamma / beta arguments are ignored;
  * avx_mst_attn_tail_mx takes pos_emb's first depthwise weights / s in dw1pack and the second * s in dw2pack. */
 float avx_mst_gelu_prescale(void);
 
