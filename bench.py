@@ -71,9 +71,11 @@ MFMA_FP16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, same guide
 MSTPP_FLOP_PER_PX = 703.4e3  # 2 x 351.7 kMAC/px (23.05 GMAC at 256x256)
 # The vector unit's side of one MST++ forward pass, per full-resolution pixel: what the network's arithmetic needs at the very least
 # once the GEMM-shaped work AND the depthwise convs (16,848 MACs / px) are on the matrix pipe.  Counted in wave64 issue slots per lane ("lane-instructions"):
-#   2,808 GELUs (15 blocks: 2 x 4C hidden + C pos_emb channels each, at the block's resolution) x 5 (ten packed float32 operations per PAIR, degree 5)
-#   + 1,404 float16 conversions of their results (one v_cvt_pk_f16_f32 per pair) + 312 LayerNorm elements x 5 (sum, centre, square, scale + shift, half a conversion)
-VALU_MIN_LANE_INSTR_PER_PX = 2808 * 5 + 1404 + 312 * 5
+#   2,808 GELUs (15 blocks: 2 x 4C hidden + C pos_emb channels each, at the block's resolution) x 4 (the prescaled form of round 3, csrc/mst_common.h: six packed
+#   float32 operations + four full-rate ones -- half a slot each -- per PAIR, degree 5; ten packed ones = 5 per element before)
+#   + 1,404 float16 conversions of their results (one v_cvt_pk_f16_f32 per pair) + 312 LayerNorm elements x 3.5 (half a dot2 for the sum, centre, square, half a packed
+#   scale, half a conversion; gamma / beta live in the first GEMM's weights since round 3: 5 before)
+VALU_MIN_LANE_INSTR_PER_PX = 2808 * 4 + 1404 + 312 * 3.5
 VALU_PEAK_LANE_INSTR_PER_S = 1024 * 16 * 2.4e9  # 1,024 SIMDs x 16 lanes per clock (a wave64 instruction holds its SIMD for 4 cycles) x 2.4 GHz
 
 
@@ -441,7 +443,7 @@ class Workload:
                                             "note": "bytes crossing THIS build's launch boundaries (falls whenever two kernels are fused): not SURVEY 8(d)'s quantity, kept for continuity with round 2"},
                     "valu": {"bound": "valu", "achieved": round(vi / 1e12, 3), "peak": round(VALU_PEAK_LANE_INSTR_PER_S / 1e12, 3), "unit": "T lane-instructions/s",
                              "frac": round(vi / VALU_PEAK_LANE_INSTR_PER_S, 4), "min_lane_instr_per_px": VALU_MIN_LANE_INSTR_PER_PX,
-                             "note": "minimal vector work of the network per pixel (2,808 GELUs x 5 + conversions + LayerNorm; the 16,848 depthwise MACs run on the matrix pipe) "
+                             "note": "minimal vector work of the network per pixel (2,808 GELUs x 4 + conversions + LayerNorm; the 16,848 depthwise MACs run on the matrix pipe) "
                                      "x pixels / step time against 1,024 SIMDs x 16 lanes x 2.4 GHz; measured: see `valu_measured` (PMC SQ_INSTS_VALU, profiles/)"}}
             dom = self.dominant_kernel()
             if dom:
