@@ -44,6 +44,24 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// "Am I the last workgroup to arrive?" for grids of hundreds to thousands of workgroups.  One counter serialises every arrival at one address (agent-scope atomics
+// are performed at the memory side: ~10-25 ns each back to back, i.e. 10-25 us for 1,024 workgroups -- most of the duration of the small reduction kernels that end
+// with it); here a workgroup arrives at counter 1 + (block % kTicketFan) and only the one that completes its group goes on to counter 0: <= nblocks / 32 + 32 arrivals
+// deep.  Called by ONE thread of each workgroup after its own stores have completed (s_waitcnt vmcnt(0)); tk: 1 + kTicketFan words, zero at rest and left zero.
+constexpr unsigned kTicketFan = 32;
+// reuse: the counters are used again INSIDE the same launch (k_sel_all): a group's reset is then waited for before its finisher moves on (between launches the kernel
+// boundary orders it).
+__device__ __forceinline__ bool ticket_is_last(uint32_t* tk, unsigned block, unsigned nblocks, bool reuse = false) {
+    const unsigned fan = nblocks < kTicketFan ? nblocks : kTicketFan, grp = block % kTicketFan;
+    const unsigned gsize = (nblocks - grp + kTicketFan - 1) / kTicketFan;  // blocks b < nblocks with b % kTicketFan == grp
+    if (__hip_atomic_fetch_add(&tk[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gsize - 1) return false;
+    __hip_atomic_store(&tk[1 + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (reuse) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__hip_atomic_fetch_add(&tk[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fan - 1) return false;
+    __hip_atomic_store(&tk[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // count of thresholds <= v (thr ascending, 255 real entries + 1 huge pad)
 template <typename T>
 __device__ __forceinline__ uint32_t quantize(T v, const T* __restrict__ thr) {

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
     }
     if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+        is_last = avxk::ticket_is_last(a.ticket, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (!is_last) return;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kET) void k_ew(const EwArgs a) {
             if (lane == 0) a.scalars_out[a.acc_slot[k]] = kind == AVX_EW_ACC_MEAN ? (double)((float)vs / (float)a.n) : (double)(float)vs;
         }
     }
-    if (tid == 0) *a.ticket = 0;
+
 }
 
 }  // namespace

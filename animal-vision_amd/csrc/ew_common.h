@@ -54,7 +54,7 @@ __device__ __forceinline__ void ew_reduce_tail(const EwArgs& a, const float (&ac
     }
     if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+        is_last = avxk::ticket_is_last(a.ticket, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (!is_last) return;
@@ -87,7 +87,6 @@ __device__ __forceinline__ void ew_reduce_tail(const EwArgs& a, const float (&ac
             if (lane == 0) a.scalars_out[a.acc_slot[k]] = kind == AVX_EW_ACC_MEAN ? (double)((float)vs / (float)a.n) : (double)(float)vs;
         }
     }
-    if (tid == 0) *a.ticket = 0;
 }
 
 // program-specific kernels: keyed by two 64-bit FNV-1a hashes of the program's structure bytes (ew_structure_hash in ew.hip)

@@ -603,14 +603,15 @@ __global__ __launch_bounds__(kT) void k_sel_pass(const SelPass a_in) {
     // the ticket is taken.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+    // one word per frame in the batched form (blockIdx.y = frame); the single-array form owns the whole ticket block and arrives through the two-level ticket
+    if (t == 0) is_last = gridDim.y > 1 ? atomicAdd(a.ticket, 1u) == gridDim.x - 1 : avxk::ticket_is_last(a.ticket, blockIdx.x, gridDim.x);
     __syncthreads();
     if (!is_last) return;
     for (int j = 0; j < a.n_jobs; ++j) {
         const SelJob jb = a.job[j];
         sel_pick(a.hist + j * 2048, a.st + j, a.pass, a.shift, a.bits, jb.rank0, jb.gamma, jb.has_next, jb.out, 0u, 0u);
     }
-    if (t == 0) *a.ticket = 0;
+    if (t == 0 && gridDim.y > 1) *a.ticket = 0;
 }
 
 // ---- opponent prep / maps / encode ------------------------------------------------------------------
@@ -947,11 +948,10 @@ __global__ __launch_bounds__(kT) void k_sel_pass_up(const SelUpArgs a) {
         if (h[i]) atomicAdd(&a.hist[i], h[i]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) is_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+    if (t == 0) is_last = avxk::ticket_is_last(a.ticket, blockIdx.x, gridDim.x);  // two-level: up to 1,024 workgroups arrive here
     __syncthreads();
     if (!is_last) return;
     sel_pick(a.hist, a.st, a.pass, a.shift, a.bits, a.rank0, a.gamma, a.has_next, a.out, a.prefix0, a.mask0);
-    if (t == 0) *a.ticket = 0;
 }
 
 // SRC: 0 uint8 frames (decode table + K x 3 matrix), 1 raw catch planes.  R: blur radius 0 | 1.  STAGE: 0 one radix-select pass
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(kT) void k_sel_all(const SelAll a) {
                 if (h[j][i]) __hip_atomic_fetch_add(&ghist[j * 2048 + i], h[j][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t == 0) is_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (t == 0) is_last = avxk::ticket_is_last(a.ticket, blockIdx.x, gridDim.x, true);
         __syncthreads();
         if (is_last) {
             for (int j = 0; j < a.n_jobs; ++j) {
@@ -1262,8 +1262,7 @@ __global__ __launch_bounds__(kT) void k_sel_all(const SelAll a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0) {
-                st_ag(a.ticket, 0u);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ticket's own resets (ticket_is_last) and the state have landed before anyone is released
                 __hip_atomic_fetch_add(a.gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (!last_pass) {
@@ -1294,7 +1293,7 @@ static int uv_small_scratch(avx_ctx* ctx, hipStream_t stream, UvScratch* s, avx_
     s->stats = (float4*)p; p += 16 * sizeof(float4);
     s->hist = (uint32_t*)p; p += 3 * kSelMax * 2048 * 4;  // one per pass for k_sel_all; the per-pass kernels use the first
     s->sel = (SelState*)p; p += kSelMax * sizeof(SelState) + 8;
-    s->ticket = (uint32_t*)p; p += 16;
+    s->ticket = (uint32_t*)p; p += 256;  // ticket_is_last's 1 + 32 counters; word 48: k_sel_all's generation counter
     p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     s->pct = (double*)p; p += 16 * 8;
     s->mat = (float*)p;
@@ -1330,7 +1329,7 @@ static int run_percentiles(avx_ctx* ctx, const UvScratch& u, const PctReq* req, 
         if (!(one_env && one_env[0] == '0')) {
             // one launch for the three passes (k_sel_all): at most one workgroup per CU, so the whole grid is resident and its inner barriers cannot starve
             SelAll b{};
-            b.n_jobs = nj; b.st = u.sel; b.hist = u.hist; b.ticket = u.ticket; b.gen = u.ticket + 1;
+            b.n_jobs = nj; b.st = u.sel; b.hist = u.hist; b.ticket = u.ticket; b.gen = u.ticket + 48;
             for (int j = 0; j < nj; ++j) b.job[j] = a.job[j];
             for (int p = 0; p < 3; ++p) { b.shift[p] = shifts[p]; b.bits[p] = bits[p]; }
             const int g1 = (int)(want < (size_t)ctx->num_cus ? (want ? want : 1) : (size_t)ctx->num_cus);
