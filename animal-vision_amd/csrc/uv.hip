@@ -1158,8 +1158,8 @@ struct UvScratch {
 // the next pass).  Here the grid stays resident: a workgroup keeps its share of every job in REGISTERS (8 x 16 bytes per thread and job: a whole 1080p plane at one
 // workgroup per CU; what does not fit is re-read), histograms pass p, flushes, takes a ticket; the LAST workgroup picks, then releases the others through a
 // generation counter they poll (agent-scope atomic loads + s_sleep).  The grid is capped at one workgroup per CU (256 threads, 32 KB of LDS at NJ = 4): every
-// workgroup of up to eight such launches is resident at once, so the wait always ends; a wait that outlasts ~1 s gives up (the launch then returns without a result
-// rather than hanging the GPU).  Measured (hummingbird 1080p, phases ablated): 50 us for one plane = visits 14.5 (the run-length LDS atomics), flush 11.6, picks 5.8,
+// workgroup of ONE such launch is resident at once; launches from several streams can starve each other (each gets part of its grid and waits for the rest), which is
+// why this form is opt-in (run_percentiles); a wait that outlasts ~0.3 s gives up (the launch then returns without a result rather than hanging the GPU).  Measured (hummingbird 1080p, phases ablated): 50 us for one plane = visits 14.5 (the run-length LDS atomics), flush 11.6, picks 5.8,
 // the bare ticket / release / poll chain 23 (~ eight dependent agent-scope round trips per pass); the three-launch form took 54.  One global histogram per pass (cleared by the last workgroup at the end: the kernel boundary publishes the zeros).
 struct SelAll { int n_jobs; SelState* st; uint32_t* hist /*[3][kSelMax][2048]*/; uint32_t* ticket; uint32_t* gen; SelJob job[kSelMax]; int shift[3], bits[3]; };
 template <int NJ>
@@ -1325,9 +1325,12 @@ static int run_percentiles(avx_ctx* ctx, const UvScratch& u, const PctReq* req, 
         const size_t cap = (size_t)ctx->num_cus * wg_per_cu;  // measured again in round 2 (hummingbird 1080p: 3.24 / 3.02 / 2.49 / 2.07 GP/s at 1 / 2 / 4 / 8 per CU): every workgroup pays the histogram clear, flush and ticket
         const int g = (int)(want < cap ? (want ? want : 1) : cap);
         const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-        const char* one_env = getenv("AVX_SEL_ONE");  // read per call: tests flip it (0: the three-launch form)
-        if (!(one_env && one_env[0] == '0')) {
-            // one launch for the three passes (k_sel_all): at most one workgroup per CU, so the whole grid is resident and its inner barriers cannot starve
+        // The one-launch form (k_sel_all) is OPT-IN (AVX_SEL_ONE=1; read per call: tests flip it).  Its inner barriers need the whole grid resident, and that holds for ONE
+        // instance only: at 128+ registers per lane a CU takes two of its workgroups, so when several streams run selects at once (the four frame lanes of bench.py's
+        // UV legs did) the dispatcher can give each launch HALF of its workgroups and all of them wait for the other halves until the time-out fires (measured: the
+        // default bench's hummingbird leg at 326 ms per step, its selects giving up).  With one stream it is 14 us per hummingbird frame faster than three launches.
+        const char* one_env = getenv("AVX_SEL_ONE");
+        if (one_env && one_env[0] == '1') {
             SelAll b{};
             b.n_jobs = nj; b.st = u.sel; b.hist = u.hist; b.ticket = u.ticket; b.gen = u.ticket + 48;
             for (int j = 0; j < nj; ++j) b.job[j] = a.job[j];

@@ -38,8 +38,8 @@ def test_percentile_matches_numpy(uv, n, q):
 
 
 def test_percentile_one_launch_equals_numpy_and_the_three_launch_form(uv, monkeypatch):
-    """Round 3: the three radix passes run in one launch (csrc/uv.hip::k_sel_all: register-resident share of the plane, ticket + generation
-    counter between the passes).  Planes smaller than a grid, a 1080p plane (exactly the register share), a 4K plane (the re-read loop),
+    """Round 3: the three radix passes can run in one launch (csrc/uv.hip::k_sel_all: register-resident share of the plane, ticket + generation
+    counter between the passes; opt-in, AVX_SEL_ONE=1: several such launches on different streams can starve each other).  Planes smaller than a grid, a 1080p plane (exactly the register share), a 4K plane (the re-read loop),
     unaligned starts; each against np.percentile and against the three-launch form (AVX_SEL_ONE=0), repeated (the histograms and the
     ticket must be left clean)."""
     rng = np.random.default_rng(77)
@@ -48,10 +48,10 @@ def test_percentile_one_launch_equals_numpy_and_the_three_launch_form(uv, monkey
         for off in (0, 1):
             for q in (95.0, 50.0, 99.9):
                 want = float(np.percentile(x[off:off + n], q))
+                assert uv.percentile(x[off:off + n], q) == want, (n, off, q, "three launches (the default)")
+                monkeypatch.setenv("AVX_SEL_ONE", "1")
                 for rep in range(2):
                     assert uv.percentile(x[off:off + n], q) == want, (n, off, q, rep)
-                monkeypatch.setenv("AVX_SEL_ONE", "0")
-                assert uv.percentile(x[off:off + n], q) == want, (n, off, q, "three launches")
                 monkeypatch.delenv("AVX_SEL_ONE")
 
 
