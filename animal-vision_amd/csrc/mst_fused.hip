@@ -41,8 +41,12 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 constexpr int kFT = 512;              // 8 waves
 constexpr int TS = 16;                // output tile side
 constexpr int HS = TS + 2;            // halo tile side
-constexpr int NHALO = HS * HS;        // 324
-constexpr int NGRP = (NHALO + 31) / 32;  // 11 pixel groups of 32
+#ifndef AVX_FFN_TH
+#define AVX_FFN_TH 16
+#endif
+constexpr int kFfnTH = AVX_FFN_TH;     // rows of a FeedForward tile.  -DAVX_FFN_TH=14 (the 18 x 16 halo region is then exactly nine 32-pixel groups instead of ten and four pixels: 6.5 % fewer LayerNorm / first-GEMM / GELU slots per output pixel) measured 1.8 % SLOWER at 4K: 15 % more tiles, each with its barriers, prologue and epilogue (profiles/r03/ab_ffn_tile_16x14.txt)
+static_assert(kFfnTH == 14 || kFfnTH == 16, "FeedForward tile rows");
+constexpr int kFfnNGRP = (HS * (kFfnTH + 2) + 31) / 32;
 // Hidden channels are processed in passes of HPASS (128 or 64).  Per pixel the hidden tile takes HPASS * 2 + 16 bytes (68 or 36
 // dwords: 16-byte reads of 16 consecutive pixels are conflict-free) and a halo ROW is padded to a multiple of 256 bytes, so the
 // two output rows of a wave hit disjoint banks.  HPASS = 64 halves the tile: two workgroups fit a CU (4 waves per SIMD), and
@@ -95,8 +99,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                                                           float eps, const uint4* __restrict__ w1pack /*[4C/32][C/16][64]*/, const __half* __restrict__ taps /*[9][4C]*/,
                                                           const uint4* __restrict__ w2pack /*[C/32][4C/16][64]*/, __half* __restrict__ out /*[B][H][W][C], != x*/, int B,
                                                           int H, int W, const uint4* __restrict__ dwpack /*[4C/8][3][64], DWM only*/, unsigned long long* __restrict__ stamps /*STAMP: [blocks][8 waves][8 segments] cycles*/) {
+    // tile = TS (16) columns x FTH rows (16; 14 is the measured-and-rejected alternative, see kFfnTH)
+    constexpr int FTH = kFfnTH, HSY = FTH + 2, NHALO = HS * HSY, NGRP = (NHALO + 31) / 32;
     constexpr int HID = 4 * C, NPASS = HID / HPASS, KS1 = C / 16, KS2 = HPASS / 16, NT = C / 32, YPITCH = C * 2 + 16, LNV = C / 16;
-    constexpr int HPITCH = HPASS * 2 + 16, RPITCH = (HS * HPITCH + 255) / 256 * 256, NCT = HPASS / 32;  // channel tiles of 32 per pass
+    constexpr int HPITCH = HPASS * 2 + 16, RPITCH = (HS * HPITCH + 255) / 256 * 256 /* a halo ROW: HS pixels */, NCT = HPASS / 32;  // channel tiles of 32 per pass
     static_assert(C == 32 || C == 64 || C == 128, "31-, 62- or 124-channel blocks (stored 32 / 64 / 128 wide)");
     constexpr int NTHR = 64 * NW, NGW = (NGRP + NW - 1) / NW;  // threads; halo pixel groups per wave
     constexpr int NTW = NT / (NW / 8), NOCTW = HPASS / (8 * NW);  // 32-channel output tiles per wave (phase 2b / epilogue); octets per wave and pass (phase 2a)
@@ -104,8 +110,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
     constexpr bool PREFETCH = C <= 64;  // the next tile's raw rows wait in registers during phase 2 (C = 128: 64 registers that the accumulators need)
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* yt = smem;                                       // [NGRP * 32][YPITCH]  LayerNorm'd rows, float16
-    unsigned char* ht = yt + (size_t)NGRP * 32 * YPITCH;             // [HS rows][RPITCH]: [HS px][HPITCH]  hidden map of the halo region, float16
-    __half* tapl = reinterpret_cast<__half*>(ht + (size_t)HS * RPITCH);  // [9][HID] (not with DWM: no table, no space)
+    unsigned char* ht = yt + (size_t)NGRP * 32 * YPITCH;             // [HSY rows][RPITCH]: [HS px][HPITCH]  hidden map of the halo region, float16
+    __half* tapl = reinterpret_cast<__half*>(ht + (size_t)HSY * RPITCH);  // [9][HID] (not with DWM: no table, no space)
     float* gl = reinterpret_cast<float*>(tapl + (DWM ? 0 : 9 * HID));  // [C] gamma, [C] beta
     constexpr bool W2LDS = NW == 16;  // 128 registers per lane: the second GEMM's fragments of a pass wait in LDS (16 KB), not in 32 registers through phase 2a
     uint4* w2l = reinterpret_cast<uint4*>(gl + 2 * C);               // W2LDS: [NT][KS2][64] this pass's W2 fragments
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
     if constexpr (!DWM)
         for (int i = tid; i < 9 * HID; i += NTHR) tapl[i] = taps[i];
     for (int i = tid; i < C; i += NTHR) { gl[i] = gamma[i]; gl[C + i] = beta[i]; }
-    const int tx = (W + TS - 1) / TS, ty = (H + TS - 1) / TS;
+    const int tx = (W + TS - 1) / TS, ty = (H + FTH - 1) / FTH;
     const long total = (long)B * ty * tx;
-    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * TS, t / ((long)tx * ty)}; };  // (TileWalk measured 2 % slower in THIS kernel: the divisions run on the scalar unit beside a saturated vector unit)
+    auto tile_of = [&](long t) { return Tile{(int)(t % tx) * TS, (int)((t / tx) % ty) * FTH, t / ((long)tx * ty)}; };  // (TileWalk measured 2 % slower in THIS kernel: the divisions run on the scalar unit beside a saturated vector unit)
     const float cnt = (float)(NT * 31);
 
     // ---- phase 0, split: fetch the raw rows of this wave's halo pixel groups (wave w: groups w and w + 8) ----
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
         f_rel[gi] = (unsigned)(((qq / HS) * W + qq % HS) * C + h * (C / 2)) * 2u;
     }
     auto fetch = [&](const Tile& t) {
-        if (t.y0 >= 1 && t.y0 + HS - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W) {  // all but the frame's border tiles: no clamping, no 64-bit lane arithmetic
+        if (t.y0 >= 1 && t.y0 + HSY - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W) {  // all but the frame's border tiles: no clamping, no 64-bit lane arithmetic
             const char* origin = reinterpret_cast<const char*>(x + ((t.b * H + t.y0 - 1) * (size_t)W + t.x0 - 1) * C);
 #pragma unroll
             for (int gi = 0; gi < NGW; ++gi) {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
     layernorm();
     for (;;) {
         const long next = tile + gridDim.x;
-        const bool halo_inside = t.y0 >= 1 && t.y0 + HS - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W;  // scalar
+        const bool halo_inside = t.y0 >= 1 && t.y0 + HSY - 1 <= H && t.x0 >= 1 && t.x0 + HS - 1 <= W;  // scalar
         float16_t D[NTW];
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
@@ -356,15 +362,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                 //   unit u's three MFMAs | the reads of unit u + 1 (into the operand registers the MFMAs have just consumed) | GELU + store of unit u - 1
                 // so an LDS round trip and the matrix pipe's latency both pass under the previous unit's GELU.  sched_barrier pins that order (left alone, the
                 // scheduler hoists unit u + 1's first MFMA up against its reads and the wave waits out the LDS latency once per unit).
-                constexpr int NU = NOCT * (TS / 2);
+                constexpr int NU = NOCT * (FTH / 2);
                 uint4 bq[3];
                 auto rd = [&](int u) {
-                    const int o2 = u / (TS / 2), pr = u % (TS / 2);
+                    const int o2 = u / (FTH / 2), pr = u % (FTH / 2);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) bq[i] = *reinterpret_cast<const uint4*>(rbase + (size_t)(2 * pr) * RPITCH + (size_t)i * HPITCH + 16 * NW * o2);
                 };
                 auto finish = [&](int u, float4_t a) {
-                    const int o2 = u / (TS / 2), pr = u % (TS / 2);
+                    const int o2 = u / (FTH / 2), pr = u % (FTH / 2);
                     float2_t gp[2] = {float2_t{a[0], a[1]}, float2_t{a[2], a[3]}};
                     if constexpr (C == 64 || (C == 32 && AVX_FFN32_GM2)) gelu_mx<2>(gp);
                     else { float2_t g0[1] = {gp[0]}, g1[1] = {gp[1]}; gelu_mx<1>(g0); gelu_mx<1>(g1); gp[0] = g0[0]; gp[1] = g1[0]; }
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                     float4_t prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
-                        const int o2 = u / (TS / 2);
+                        const int o2 = u / (FTH / 2);
                         float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o2][i], __builtin_bit_cast(half8_t, bq[i]), acc, 0, 0, 0);
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                 } else {
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
-                        const int o2 = u / (TS / 2);
+                        const int o2 = u / (FTH / 2);
                         rd(u);
                         float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -408,6 +414,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                 // ---- phase 2b: second GEMM, this wave's 32 output pixels (rows 2 wave, 2 wave + 1), B fragments from the map ----
                 const int r = 2 * w8 + (p >> 4), c = p & 15;
                 const unsigned char* zb = ht + (size_t)r * RPITCH + (size_t)c * HPITCH + 16 * h;
+                if (2 * w8 < FTH) {  // wave-uniform (FTH = 14: the eighth row pair does not exist)
 #pragma unroll
                 for (int s = 0; s < KS2; ++s) {
                     const half8_t bf = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(zb + 32 * s));
@@ -417,9 +424,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
                         else D[n] = mfma16(w2f[n * KS2 + s], bf, D[n]);
                     }
                 }
+                }
             } else
             // ---- phase 2: depthwise 3x3 + GELU + W2, this wave's 32 output pixels (rows 2 wave, 2 wave + 1) ----
-            {
+            if (2 * wave < FTH) {  // wave-uniform (FTH = 14: the eighth row pair does not exist)
                 const int r = 2 * wave + (p >> 4), c = p & 15;
                 const unsigned char* hbase = ht + (size_t)r * RPITCH + (size_t)c * HPITCH + 16 * h;  // top-left tap of this pixel, this lane's channel octet
                 const unsigned char* tbase = reinterpret_cast<const unsigned char*>(tapl) + (size_t)(pass * HPASS + 8 * h) * 2;
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_mst_ffn_fused(const __half* _
         // ---- epilogue: + x (the block's residual, :184), float16, 32 contiguous bytes per lane and output tile ----
         {
             const int yo = t.y0 + 2 * w8 + (p >> 4), xo = t.x0 + (p & 15);
-            if (yo < H && xo < W) {
+            if (2 * w8 < FTH && yo < H && xo < W) {
                 const size_t off = ((t.b * H + yo) * (size_t)W + xo) * C + 16 * h + 32 * n0;
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
@@ -1561,13 +1569,13 @@ static int ffn_fused_launch(avx_ctx* ctx, const void* x, const float* gamma, con
     AVX_REQUIRE(ctx, x != out, "avx_mst_ffn_fused: neighbouring tiles read each other's halo: the output cannot be the input");
     AVX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = avx_pick_stream(ctx, stream);
-    const long total = (long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+    const long total = (long)B * ((H + kFfnTH - 1) / kFfnTH) * ((W + TS - 1) / TS);
     const char* hp = getenv("AVX_MST_FFN_HPASS");  // A/B: 128 = one 8-wave workgroup per CU, 64 (C = 32 only) = two
     const bool small = C == 32 && !(hp && atoi(hp) == 128);
     const int hpass = (small || C == 128) ? 64 : 128, hpitch = hpass * 2 + 16, rpitch = (HS * hpitch + 255) / 256 * 256;
     const long cap = (long)ctx->num_cus * (small ? 2 : 1);
     const bool nw16 = C == 64 && dwpack && !(getenv("AVX_MST_FFN_NW") && atoi(getenv("AVX_MST_FFN_NW")) == 8);  // AVX_MST_FFN_NW=8: A/B, the round-2 split
-    const size_t lds = (size_t)NGRP * 32 * (C * 2 + 16) + (size_t)HS * rpitch + (dwpack ? 0 : (size_t)9 * 4 * C * 2) + sizeof(float) * 2 * C + (nw16 ? (size_t)(C / 32) * (hpass / 16) * 1024 : 0);
+    const size_t lds = (size_t)kFfnNGRP * 32 * (C * 2 + 16) + (size_t)(kFfnTH + 2) * rpitch + (dwpack ? 0 : (size_t)9 * 4 * C * 2) + sizeof(float) * 2 * C + (nw16 ? (size_t)(C / 32) * (hpass / 16) * 1024 : 0);
     const dim3 grid((unsigned)(total < cap ? total : cap));
 #define AVX_FFN1(CV, HP, MW, DW, NWV)                                                                                                            \
     {                                                                                                                                            \
