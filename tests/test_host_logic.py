@@ -155,3 +155,53 @@ def test_honeybee_constructor_surface():
     assert bee.onnx_path.endswith("mst_plus_plus.onnx")
     with pytest.raises(AssertionError):
         bee.visualize(np.zeros((4, 4), np.uint8))
+
+
+def test_gelu_tables_of_the_matrix_pipe_kernels_hold_their_stated_error():
+    """csrc/mst_common.h: the coefficient tables of the clamped odd polynomial (gelu_poly2: degree 7 / 6 / 5, x clamped to +-A) and of its
+    prescaled form (gelu_pre_multi: x / 4 enters, t = clamp01(x'^2), Phi = clamp01(x' R^(t) + 1/2), x' Phi = gelu(x) / 4 leaves), evaluated here
+    in float32 NumPy step for step, against the exact erf GELU (nn.GELU() of MST_Plus_Plus.py:48-50) over [-9, 9]: max(|error| for x < 0,
+    |error| / gelu for x > 0.02) must stay within what the header states -- a transcription slip in a table shows here, not in a tolerance test."""
+    import math
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "animal-vision_amd", "csrc", "mst_common.h")).read()
+
+    def table(macro, deg_macro, deg):
+        m = re.search(r"#(?:el)?if %s == %d\n(?:#define AVX_GELU_A ([0-9.]+)f\n)?#define %s \{([^}]*)\}" % (deg_macro, deg, macro), src)
+        assert m, (macro, deg)
+        return [np.float32(float.fromhex(v.strip().rstrip("f"))) for v in m.group(2).split(",")], (float(m.group(1)) if m.group(1) else None)
+
+    xs = np.linspace(-9.0, 9.0, 360001)
+    ref = xs * 0.5 * (1.0 + np.vectorize(math.erf)(xs / math.sqrt(2.0)))
+
+    def check(got, bound, what):
+        err = np.abs(got.astype(np.float64) - ref)
+        pos = xs > 0.02
+        worst = max(float(err[~pos].max()), float((err[pos] / ref[pos]).max()))
+        assert worst <= bound, (what, worst, bound)
+
+    # the clamped form: Phi(x) - 1/2 = xc R(xc^2)
+    for deg, bound in ((7, 1.4e-4), (6, 2.5e-4), (5, 7.0e-4)):
+        R, A = table("AVX_GELU_COEFFS", "AVX_GELU_DEG", deg)
+        x32 = xs.astype(np.float32)
+        xc = np.clip(x32, -np.float32(A), np.float32(A))
+        t = (xc * xc).astype(np.float32)
+        r = np.full_like(t, R[-1])
+        for k in range(deg - 1, -1, -1):
+            r = (r * t + R[k]).astype(np.float32)
+        check((x32 * (xc * r + np.float32(0.5)).astype(np.float32)).astype(np.float32), bound, ("clamped", deg))
+    # the prescaled form (A = 4)
+    for deg, bound in ((5, 1.15e-3), (6, 2.5e-4)):
+        R, _ = table("AVX_GELU_PRE_COEFFS", "AVX_GELU_PRE_DEG", deg)
+        assert abs(float(sum(np.float64(v) for v in R)) - 0.5) < 1e-6  # R^(1) = 1/2: beyond |x| = A the clamp pins Phi to 0 / 1
+        xp = (xs / 4.0).astype(np.float32)
+        t = np.clip((xp * xp).astype(np.float32), 0, 1)
+        r = np.full_like(t, R[-1])
+        for k in range(deg - 1, -1, -1):
+            r = (r * t + R[k]).astype(np.float32)
+        phi = np.clip((xp * r + np.float32(0.5)).astype(np.float32), 0, 1)
+        check((xp * phi).astype(np.float32).astype(np.float64) * 4.0, bound, ("prescaled", deg))
+        big = np.abs(xs) > 4.0
+        assert np.array_equal((xp * phi)[big] * 4, np.where(xs[big] > 0, xp[big] * 4, 0.0 * xp[big]))  # exactly x or 0 outside the clamp
