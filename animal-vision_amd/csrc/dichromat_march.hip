@@ -23,6 +23,13 @@ using namespace avxk;
 
 namespace {
 
+// -DAVX_MARCH_DMA=1: the producer wave stages the raw rows by LDS-direct loads (global_load_lds_dword into a third raw buffer, counted vmcnt) instead of through
+// registers + ds_write (VERDICT r02's lever 6a).  Built and measured in round 3, bit-exact in all 183 dichromat tests and SLOWER on every species (same-box A/B,
+// profiles/r03/ab_march_lds_dma.txt: cat 161.0 -> 152.9, dog 128.8 -> 121.7, wolf 195.8 -> 184.6, squirrel 261.9 -> 257.5 GP/s): 4-byte LDS-direct loads cost the
+// producer more than the register staging they replace.  Off by default.
+#ifndef AVX_MARCH_DMA
+#define AVX_MARCH_DMA 0
+#endif
 // Workgroup = NG column groups x 3 channels (NG a multiple of 64 keeps the channel wave-uniform).
 
 struct MarchGeom {
@@ -85,8 +92,11 @@ struct MarchCfg {
     static constexpr size_t A_bytes = (size_t)SY * 3 * PA * sizeof(T) + 64;
     static constexpr size_t raw_bytes = (size_t)SY * RAWP;
     static constexpr size_t out_bytes = (size_t)SY * OUTP;
+    // SPEC: the raw rows have THREE buffers (iteration mod 3): the producer's LDS-direct loads of iteration t + 3 are issued two intervals before
+    // their rows are decoded, as the register-staged loads were (loaded in one interval, written in the next)
+    static constexpr int kRawBufs = (AVX_MARCH_DMA && SPEC) ? 3 : 2;
     static constexpr size_t off_raw = off_A + 2 * A_bytes;
-    static constexpr size_t off_out = off_raw + 2 * raw_bytes;
+    static constexpr size_t off_out = off_raw + kRawBufs * raw_bytes;
     static constexpr size_t lds_bytes = ((off_out + 2 * out_bytes + 15) / 16) * 16;
     static_assert(3 * R <= RAW_LEAD, "raw lead-in too small for this radius");
     static_assert(lds_bytes <= 160 * 1024, "does not fit LDS");
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
     T* ktab = reinterpret_cast<T*>(smem_raw + C::off_ktab);
     // double-buffered by iteration parity: A [SY/2][3][PA] of {row 2k, row 2k+1}; RAW [SY][RAWP]; OUT [SY][OUTP]
     auto A_of = [&](int t) { return reinterpret_cast<P*>(smem_raw + C::off_A + (size_t)(t & 1) * C::A_bytes); };
-    auto RAW_of = [&](int t) { return smem_raw + C::off_raw + (size_t)(t & 1) * C::raw_bytes; };
+    auto RAW_of = [&](int t) { return smem_raw + C::off_raw + (size_t)(C::kRawBufs == 3 ? (unsigned)t % 3u : (unsigned)t & 1u) * C::raw_bytes; };
     auto OUT_of = [&](int t) { return smem_raw + C::off_out + (size_t)(t & 1) * C::out_bytes; };
     // AVX_ABLATE (phase skipping, tuning only) exists in the diagnostic instantiation alone: as run-time tests these uniform
     // branches split the loop into small blocks and kept the compiler from overlapping the quantiser's LDS lookups across rows
@@ -229,6 +239,36 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
             const int dc = d < last ? d : last;
             rv[n] = *reinterpret_cast<const uint32_t*>(fin_base + (size_t)(aoff + (uint32_t)dc * 4u));
         }
+    };
+    // The same rows by LDS-direct loads (global_load_lds_dword: lane l's dword lands at M0 + 4 l): no staging registers, no write_raw.  Used by the producer
+    // wave once the "byte > 1" detector has nothing left to find (it needs the bytes in registers): the loads go straight into RAW_of(t).  hipcc does not count
+    // them: the producer waits for them itself (dma_wait) -- it issues no other vector-memory operation in the steady state (the compute waves store).
+    constexpr bool kDma = AVX_MARCH_DMA && SPEC && NLD <= 32;
+    auto dma_raw = [&](int t) {
+        const unsigned raw_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)RAW_of(t);
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int u = swave + n * NSTAGE;            // uniform
+            const int s = u / NSEG, seg = u - s * NSEG; // uniform
+            if (s < SY) {
+                uint32_t shift;
+                const uint32_t aoff = row_off(t, s, shift);
+                const int last = ((int)shift + row_bytes - 1) >> 2;
+                const int d = seg * 64 + lane;
+                const int dc = d < last ? d : last;
+                const uint8_t* g = fin_base + (size_t)(aoff + (uint32_t)dc * 4u);
+                const unsigned dst = raw_lds + (unsigned)(s * C::RAWP + C::RAW_LEAD + seg * 256);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // "m0 is reserved": nothing of the compiler's lives in M0 across this statement
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(g) : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        }
+    };
+    // every LDS-direct load but the NLD most recent ones (all == true: every one) has landed
+    auto dma_wait = [&](bool all) {
+        if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");
     };
     bool flag_done = false;  // wave-uniform: this wave has already reported a byte > 1 for the frame -- nothing left to detect
     auto write_raw = [&](int t, const uint32_t (&rv)[NLD]) {
@@ -566,15 +606,24 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
         if (n_iter > 2) issue_raw_loads(2, rv);
     }
     __syncthreads();
+    bool have_regs = stager && n_iter > 2;  // the prologue's issue_raw_loads(2)
+    bool dma_used = false;
 #pragma unroll 1
     for (int t = 0; t < n_iter; ++t) {
         stamp(-1);
         // raw staging first: its s_waitcnt vmcnt covers only the loads issued one interval ago (vmcnt counts
         // stores too, in order: behind store_out it would also wait for those stores to retire)
-        if (stager && t + 2 < n_iter) {
-            write_raw(t + 2, rv);
+        bool dma_issued = false;
+        if (stager) {
+            if (have_regs) {  // the rows of t + 2, loaded in the previous interval
+                write_raw(t + 2, rv);
+                have_regs = false;
+            }
             stamp(1);
-            if (t + 3 < n_iter) issue_raw_loads(t + 3, rv);
+            if (t + 3 < n_iter) {
+                if (kDma && producer && (DARK || flag_done)) { dma_raw(t + 3); dma_issued = true; dma_used = true; }
+                else { issue_raw_loads(t + 3, rv); have_regs = true; }
+            }
         }
         stamp(2);
         if (t + 1 < n_iter) decode(t + 1);
@@ -583,6 +632,7 @@ __global__ __launch_bounds__(3 * NG + (SPEC ? 64 : 0), MINW) void dichromat_marc
         stamp(4);
         if (t > 0 && !(ablate & 32)) store_out(t - 1);
         stamp(0);
+        if (kDma && dma_used) dma_wait(!dma_issued);  // the rows decode(t + 2) will read (issued in the previous interval) are in LDS
         __syncthreads();
         stamp(5);
     }
