@@ -12,7 +12,10 @@
  *   - an avx_ctx is bound to ONE device and is single-threaded (one caller at a time), matching the
  *     reference's one-frame-in-flight loop (main.py:60-72);
  *   - `stream` is a hipStream_t passed as void*, with HIP's own meaning: NULL is the null (default) stream,
- *     a torch.cuda.Stream.cuda_stream value is accepted as is; every launch is asynchronous on it;
+ *     a torch.cuda.Stream.cuda_stream value is accepted as is; every launch is asynchronous on it, with ONE exception:
+ *     the first avx_dichromat_u8 call for a (kernel configuration, batch, frame size) that is not in the seeded table
+ *     times its candidate launch geometries on the caller's frames (~40 ms, blocking; the results are the same for every
+ *     candidate) and remembers the winner in the ctx -- AVX_MARCH_CHUNKS / AVX_MARCH_NG pin a geometry and skip it;
  *   - frame/plane pointers are DEVICE pointers unless the parameter name ends in `_host`;
  *     the caller owns them; ctx owns only its scratch and its constant tables;
  *   - images are C-contiguous HWC (H x W x 3), batches are N such frames back to back.
