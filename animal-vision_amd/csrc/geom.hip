@@ -24,19 +24,36 @@ struct AxisLin { int* ofs; float* f; int dmax; };
 struct AxisCub { int* idx; float* a; };                 // [d][4]
 struct AxisArea { int* start; int* cnt; float* alpha; int maxcnt; };  // alpha [d][maxcnt]
 
+// One thread per DESTINATION PIXEL (all C channels: the weights and the four source addresses are shared; 16-byte loads / stores when C is a multiple of 4 and the
+// pointers allow).  Round 2's form was one thread per output element with three 64-bit divisions each (i % C, (i / C) % Wd, i / (C Wd): ~300 vector instructions
+// around a 9-operation lerp): 28 us for the 1080p x 4-band stack of the UV species, 1.2 TB/s written.  Same statement per element (stack_lerp): identical values.
 __global__ __launch_bounds__(kGT) void k_resize_linear_f32(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Hd, int Wd,
                                                            AxisLin ax, AxisLin ay) {
-    const size_t total = (size_t)Hd * Wd * C;
-    for (size_t i = (size_t)blockIdx.x * kGT + threadIdx.x; i < total; i += (size_t)gridDim.x * kGT) {
-        const int c = (int)(i % C);
-        const int x = (int)((i / C) % Wd), y = (int)(i / ((size_t)C * Wd));
+    const unsigned npx = (unsigned)Hd * (unsigned)Wd;  // the host checks Hd * Wd < 2^31
+    const bool vec = (C & 3) == 0 && ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0);
+    for (unsigned p = blockIdx.x * kGT + threadIdx.x; p < npx; p += gridDim.x * kGT) {
+        const unsigned y = p / (unsigned)Wd, x = p - y * (unsigned)Wd;
         const int sx = ax.ofs[x], sy0 = ay.ofs[y], sy1 = sy0 + 1 < H ? sy0 + 1 : sy0;
         const float a1 = ax.f[x], a0 = 1.f - a1, b1 = ay.f[y], b0 = 1.f - b1;
-        const float* S0 = src + ((size_t)sy0 * W + sx) * C + c;
-        const float* S1 = src + ((size_t)sy1 * W + sx) * C + c;
-        const bool inner = x < ax.dmax;
+        const float* S0 = src + ((size_t)sy0 * W + sx) * C;
+        const float* S1 = src + ((size_t)sy1 * W + sx) * C;
+        const bool inner = (int)x < ax.dmax;
         const int o = inner ? C : 0;
-        dst[i] = stack_lerp(S0[0], S0[o], S1[0], S1[o], a0, a1, b0, b1, inner);  // stack_up.h: the one statement of this arithmetic
+        float* D = dst + (size_t)p * C;
+        if (vec) {
+            for (int c = 0; c < C; c += 4) {
+                const float4 p00 = *reinterpret_cast<const float4*>(S0 + c), p01 = *reinterpret_cast<const float4*>(S0 + o + c);
+                const float4 p10 = *reinterpret_cast<const float4*>(S1 + c), p11 = *reinterpret_cast<const float4*>(S1 + o + c);
+                float4 r;
+                r.x = stack_lerp(p00.x, p01.x, p10.x, p11.x, a0, a1, b0, b1, inner);  // stack_up.h: the one statement of this arithmetic
+                r.y = stack_lerp(p00.y, p01.y, p10.y, p11.y, a0, a1, b0, b1, inner);
+                r.z = stack_lerp(p00.z, p01.z, p10.z, p11.z, a0, a1, b0, b1, inner);
+                r.w = stack_lerp(p00.w, p01.w, p10.w, p11.w, a0, a1, b0, b1, inner);
+                *reinterpret_cast<float4*>(D + c) = r;
+            }
+        } else {
+            for (int c = 0; c < C; ++c) D[c] = stack_lerp(S0[c], S0[o + c], S1[c], S1[o + c], a0, a1, b0, b1, inner);
+        }
     }
 }
 
@@ -477,7 +494,10 @@ int avx_resize_hwc(avx_ctx* ctx, const void* src, int dtype, int H, int W, int C
     if (interp == 1) {
         AxisLin ax{}, ay{};
         if ((rc = tc.lin(W, Wd, &ax)) || (rc = tc.lin(H, Hd, &ay))) return rc;
-        if (dtype == 0) hipLaunchKernelGGL(k_resize_linear_f32, dim3(g), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);
+        if (dtype == 0) {
+            AVX_REQUIRE(ctx, (size_t)Hd * Wd < ((size_t)1 << 31), "avx_resize_hwc: destination larger than 2^31 pixels");
+            hipLaunchKernelGGL(k_resize_linear_f32, dim3(grid_for(ctx, (size_t)Hd * Wd)), dim3(kGT), 0, s, (const float*)src, H, W, C, (float*)dst, Hd, Wd, ax, ay);  // one thread per destination pixel
+        }
         else hipLaunchKernelGGL(k_resize_linear_u8, dim3(g), dim3(kGT), 0, s, (const uint8_t*)src, H, W, C, (uint8_t*)dst, Hd, Wd, ax, ay);
     } else if (interp == 2) {
         AxisCub ax{}, ay{};
