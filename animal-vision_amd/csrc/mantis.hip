@@ -69,11 +69,11 @@ __global__ __launch_bounds__(kMT) void k_uv_front_u8(const uint8_t* __restrict__
     for (int i = threadIdx.x; i < 256; i += kMT) { lut[i] = lut_g[i]; thr[i] = thr_g[i]; }
     for (int i = threadIdx.x; i < kCoarseTableBytes; i += kMT) coarse[i] = coarse_g[i];
     __syncthreads();
-    const size_t total = (size_t)H * W;
-    for (size_t i = (size_t)blockIdx.x * kMT + threadIdx.x; i < total; i += (size_t)gridDim.x * kMT) {
+    const unsigned total = (unsigned)H * (unsigned)W;  // 32-bit pixel index (frames < 2^32 / 12 pixels: the host checks): the 64-bit form paid two 64-bit divisions per pixel
+    for (unsigned i = blockIdx.x * kMT + threadIdx.x; i < total; i += gridDim.x * kMT) {
         float v[3];
         if (idx) {
-            const int x = (int)(i % W), y = (int)(i / W);
+            const unsigned y = i / (unsigned)W, x = i - y * (unsigned)W;
             const int* ix = idx + 4 * x;
             const float* a = ca + 4 * x;
             const uint8_t* S = in + (size_t)y * W * 3;
@@ -83,12 +83,12 @@ __global__ __launch_bounds__(kMT) void k_uv_front_u8(const uint8_t* __restrict__
             for (int c = 0; c < 3; ++c) v[c] = lut[S[i0 + c]] * a0 + lut[S[i1 + c]] * a1 + lut[S[i2 + c]] * a2 + lut[S[i3 + c]] * a3;
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = lut[in[i * 3 + c]];
+            for (int c = 0; c < 3; ++c) v[c] = lut[in[(size_t)i * 3 + c]];
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            lin_out[i * 3 + c] = v[c];
-            if (base_out) base_out[i * 3 + c] = (uint8_t)quantize_coarse<float, kCoarseNFix>(v[c], thr, coarse, lo_key);
+            lin_out[(size_t)i * 3 + c] = v[c];
+            if (base_out) base_out[(size_t)i * 3 + c] = (uint8_t)quantize_coarse<float, kCoarseNFix>(v[c], thr, coarse, lo_key);
         }
     }
 }
@@ -619,7 +619,7 @@ int grid_for(avx_ctx* ctx, size_t items) {
 static int uv_front(avx_ctx* ctx, const uint8_t* in_hwc, int H, int W, int newW, float* tmp, float* lin_out, uint8_t* base_out, hipStream_t s) {
     const size_t n = (size_t)H * W;
     int rc;
-    if (!getenv("AVX_UV_FRONT_SPLIT")) {  // one pass (k_uv_front_u8); AVX_UV_FRONT_SPLIT=1: decode, warp and encode as separate launches
+    if (!getenv("AVX_UV_FRONT_SPLIT") && n < ((size_t)1 << 31)) {  // one pass (k_uv_front_u8, 32-bit pixel indices); AVX_UV_FRONT_SPLIT=1: decode, warp and encode as separate launches
         const int* idx = nullptr;
         const float* ca = nullptr;
         if (newW > W) {
