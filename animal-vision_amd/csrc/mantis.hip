@@ -22,7 +22,7 @@ int avx_geom_panorama_cubic(avx_ctx* ctx, const float* src, int H, int W, int ne
 int avx_geom_cache_trim(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int limit);
 int avx_geom_linear_tables(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int H, int W, int Hd, int Wd, avx_lin_tab* ax, avx_lin_tab* ay);
 int avx_geom_cubic_x_tables(avx_ctx* ctx, avx_ws* ws, hipStream_t s, int W, int newW, int start, const int** idx, const float** a);
-int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, double* out_dev, hipStream_t s);
+int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, double* out_dev, hipStream_t s, float* cand_buf);
 
 namespace {
 
@@ -881,7 +881,7 @@ static int mantis_frame(avx_ctx* ctx, const uint8_t* in_hwc, uint8_t* out_base_h
         AVX_STACK_K_SWITCH(K, hipLaunchKernelGGL(k_up_minmax<KT>, dim3(gu), dim3(kMT), tile_lds, s, up, cap_floats, part))
         hipLaunchKernelGGL(k_stack_minmax_final, dim3(1), dim3(1024), 0, s, part, gu, K, mm);
         up.mm = mm;
-        if ((rc = avx_uv_percentile_up_device(ctx, up, 95.0, pct, s))) return rc;
+        if ((rc = avx_uv_percentile_up_device(ctx, up, 95.0, pct, s, stack /*the materialised route's buffer: free here, H * W * K floats for the second pass's candidates*/))) return rc;
         b.S = nullptr; b.up = up;
     } else {
         if (hs != H || wsm != W) {

@@ -142,8 +142,11 @@ __device__ __forceinline__ void stack_up_pixel_tile(const StackUp& u, const Stac
 }
 
 // for (tile of this workgroup) { load; sync; for (pixel of this thread in the tile) body(x, y, v); sync; }  -- 256 threads, u.K == K
-template <int K, bool NORM, typename F>
-__device__ __forceinline__ void stack_tiles(const StackUp& u, float* lds, size_t cap_floats, F&& body) {
+struct StackNoHook { __device__ __forceinline__ bool operator()() const { return false; } };
+// after: called by every thread once per sweep of a tile, behind the barrier that follows the sweep's body calls (a per-tile epilogue: the candidate copy-out of the
+// radix pass); returning true (the same value in every thread) makes the tile's body calls run once more (that pass's dense tiles: second sweep writes directly)
+template <int K, bool NORM, typename F, typename A = StackNoHook>
+__device__ __forceinline__ void stack_tiles(const StackUp& u, float* lds, size_t cap_floats, F&& body, A&& after = A()) {
     const int tiles_x = (u.W + kUpTW - 1) / kUpTW, tiles_y = (u.H + kUpTH - 1) / kUpTH;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     float2 mm[K];
@@ -159,18 +162,22 @@ __device__ __forceinline__ void stack_tiles(const StackUp& u, float* lds, size_t
         const int sx = u.ax.ofs[xc];
         const float a1 = u.ax.f[xc];
         __syncthreads();
-        if (x < u.W) {
+        bool again;
+        do {
+            if (x < u.W) {
 #pragma unroll
-            for (int i = 0; i < kUpTH / 4; ++i) {
-                const int y = y0 + ty + 4 * i;
-                if (y < u.H) {
-                    float v[K];
-                    stack_up_pixel_tile<K, NORM>(u, g, lds, x, y, sx, a1, mm, rinv, v);
-                    body(x, y, v);
+                for (int i = 0; i < kUpTH / 4; ++i) {
+                    const int y = y0 + ty + 4 * i;
+                    if (y < u.H) {
+                        float v[K];
+                        stack_up_pixel_tile<K, NORM>(u, g, lds, x, y, sx, a1, mm, rinv, v);
+                        body(x, y, v);
+                    }
                 }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            again = after();
+        } while (again);
     }
 }
 

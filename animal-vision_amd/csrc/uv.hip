@@ -910,27 +910,63 @@ __device__ void sel_pick_t(uint32_t* hist, SelState* st, int pass, int shift, in
 
 // One radix pass over the values of a band stack that only exists at reduced size (stack_up.h): every thread recomputes the K
 // resized + normalised values of its pixels and histograms them; flush, ticket and pick as in k_sel_pass (one job).
-struct SelUpArgs { StackUp u; size_t cap_floats; uint32_t prefix0, mask0; int pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket; unsigned long long rank0; float gamma; int has_next; double* out; };
+// cand / cand_cnt (round 3): the SECOND pass also copies every value of the bin the first pass selected into cand[] (count in *cand_cnt) and tracks the smallest key
+// above that bin, so the THIRD pass scans those candidates (k_sel_cand) instead of recomputing the whole stack a third time.
+struct SelUpArgs { StackUp u; size_t cap_floats; uint32_t prefix0, mask0; int pass, shift, bits; SelState* st; uint32_t* hist; uint32_t* ticket; unsigned long long rank0; float gamma; int has_next; double* out;
+                   float* cand; uint32_t* cand_cnt; };
+constexpr uint32_t kSelStage = 3072;  // staged candidates per tile (12 KB of LDS); denser tiles take a second sweep
 template <int K>
 __global__ __launch_bounds__(kT) void k_sel_pass_up(const SelUpArgs a) {
     __shared__ uint32_t h[2048];
     __shared__ uint32_t wmin[kT / 64];
     __shared__ int is_last;
+    __shared__ uint32_t scnt, sbase;
+    __shared__ int redo;  // collect: 1 during the second sweep of a tile whose candidates outgrew the staging area (values are then written straight to cand[])
     const int nb = 1 << a.bits, t = threadIdx.x;
-    const bool last_pass = a.pass == 2, find_next = last_pass && a.has_next;
+    const bool last_pass = a.pass == 2, collect = a.pass == 1 && a.cand != nullptr;
+    const bool find_next = (last_pass || collect) && a.has_next;  // collect: the smallest key above the first pass's bin (the successor when the candidates hold none)
     for (int i = t; i < 2048; i += kT) h[i] = 0;
+    if (t == 0) { scnt = 0; redo = 0; }
     const uint32_t prefix = a.pass == 0 ? a.prefix0 : a.st->prefix, mask = a.pass == 0 ? a.mask0 : a.st->mask;
     const uint32_t above = prefix | ~mask;
     uint32_t best = 0xffffffffu;
     __syncthreads();
     extern __shared__ float tile_lds[];
+    float* stage = tile_lds + a.cap_floats;  // collect: this tile's candidates, up to kSelStage of them
     stack_tiles<K, true>(a.u, tile_lds, a.cap_floats, [&](int, int, float (&v)[K]) {
+        const bool second = collect && redo;  // uniform
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t key = f2key(v[k]);
-            if ((key & mask) == prefix) atomicAdd(&h[(key >> a.shift) & (nb - 1)], 1u);
-            else if (find_next && key > above && key < best) best = key;
+            if ((key & mask) == prefix) {
+                if (!second) atomicAdd(&h[(key >> a.shift) & (nb - 1)], 1u);
+                if (collect) {
+                    const uint32_t idx = atomicAdd(&scnt, 1u);
+                    if (second) a.cand[(size_t)sbase + idx] = v[k];
+                    else if (idx < kSelStage) stage[idx] = v[k];
+                }
+            } else if (find_next && key > above && key < best) best = key;
         }
+    }, [&]() -> bool {
+        if (!collect) return false;  // uniform
+        const uint32_t m = scnt;
+        const bool was_second = redo != 0, dense = !was_second && m > kSelStage;
+        __syncthreads();  // everyone has read scnt / redo
+        if (was_second) {
+            if (t == 0) { scnt = 0; redo = 0; }
+            __syncthreads();
+            return false;
+        }
+        if (t == 0) {
+            if (m) sbase = atomicAdd(a.cand_cnt, m);  // one reservation per tile
+            scnt = 0;
+            redo = dense ? 1 : 0;
+        }
+        __syncthreads();
+        if (dense) return true;  // too many for the staging area (a flat region: every value in the bin): the tile is swept again and writes straight to cand[sbase + ...]
+        for (uint32_t i = t; i < m; i += kT) a.cand[(size_t)sbase + i] = stage[i];
+        __syncthreads();  // the staging area is free again
+        return false;
     });
     if (find_next) {
 #pragma unroll
@@ -952,6 +988,47 @@ __global__ __launch_bounds__(kT) void k_sel_pass_up(const SelUpArgs a) {
     __syncthreads();
     if (!is_last) return;
     sel_pick(a.hist, a.st, a.pass, a.shift, a.bits, a.rank0, a.gamma, a.has_next, a.out, a.prefix0, a.mask0);
+    if (a.pass == 0 && a.cand_cnt && t == 0) *a.cand_cnt = 0;  // the next launch collects from zero (the kernel boundary publishes it)
+}
+
+// The third radix pass over the candidates the second one collected (k_sel_pass_up): *cand_cnt values, all inside the first pass's bin.  Same histogram, successor
+// search, flush, ticket and pick as the full pass; the successor found among keys above that bin is already in st->next_above.
+__global__ __launch_bounds__(kT) void k_sel_cand(const SelUpArgs a) {
+    __shared__ uint32_t h[2048];
+    __shared__ uint32_t wmin[kT / 64];
+    __shared__ int is_last;
+    const int nb = 1 << a.bits, t = threadIdx.x;
+    const bool find_next = a.has_next != 0;
+    for (int i = t; i < 2048; i += kT) h[i] = 0;
+    const uint32_t prefix = a.st->prefix, mask = a.st->mask, above = prefix | ~mask;
+    const size_t n = *a.cand_cnt;
+    uint32_t best = 0xffffffffu;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * kT + t; i < n; i += (size_t)gridDim.x * kT) {
+        const uint32_t key = f2key(a.cand[i]);
+        if ((key & mask) == prefix) atomicAdd(&h[(key >> a.shift) & (nb - 1)], 1u);
+        else if (find_next && key > above && key < best) best = key;
+    }
+    if (find_next) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(best, o); best = w < best ? w : best; }
+        __syncthreads();
+        if ((t & 63) == 0) wmin[t >> 6] = best;
+        __syncthreads();
+        if (t == 0) {
+            for (int w = 1; w < kT / 64; ++w) best = wmin[w] < best ? wmin[w] : best;
+            if (best != 0xffffffffu) atomicMin(&a.st->next_above, best);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < nb; i += kT)
+        if (h[i]) atomicAdd(&a.hist[i], h[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) is_last = avxk::ticket_is_last(a.ticket, blockIdx.x, gridDim.x);
+    __syncthreads();
+    if (!is_last) return;
+    sel_pick(a.hist, a.st, 2, a.shift, a.bits, a.rank0, a.gamma, a.has_next, a.out, a.prefix0, a.mask0);
 }
 
 // SRC: 0 uint8 frames (decode table + K x 3 matrix), 1 raw catch planes.  R: blur radius 0 | 1.  STAGE: 0 one radix-select pass
@@ -1365,7 +1442,7 @@ int avx_uv_percentile_device(avx_ctx* ctx, const float* x, size_t n, double q, d
 }
 
 // np.percentile(q) over the H x W x K values of a reduced-size band stack read through its resize (+ safe_norm): stack_up.h
-int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, double* out_dev, hipStream_t s) {
+int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, double* out_dev, hipStream_t s, float* cand_buf /*H * W * K floats, or NULL: three full passes*/) {
     UvScratch u;
     int rc = uv_small_scratch(ctx, s, &u);
     if (rc) return rc;
@@ -1380,8 +1457,13 @@ int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, doubl
     const size_t tiles = (size_t)((up.W + kUpTW - 1) / kUpTW) * ((up.H + kUpTH - 1) / kUpTH), cap = (size_t)ctx->num_cus * 4;
     const int g = (int)(tiles < cap ? (tiles ? tiles : 1) : cap);
     a.cap_floats = stack_tile_floats(up.hs, up.ws, up.H, up.W, up.K);
-    const size_t lds = a.cap_floats * sizeof(float);
-    AVX_REQUIRE(ctx, lds <= 96 * 1024, "percentile through a resized stack: the tile's source rectangle does not fit LDS (%zu bytes)", lds);
+    const size_t lds_tile = a.cap_floats * sizeof(float);
+    AVX_REQUIRE(ctx, lds_tile <= 96 * 1024, "percentile through a resized stack: the tile's source rectangle does not fit LDS (%zu bytes)", lds_tile);
+    // candidates: the second pass stages a tile's matching values in LDS (kSelStage floats behind the source rectangle) and copies them out once per tile
+    const size_t lds_stage = (size_t)kSelStage * sizeof(float);
+    const char* cand_env = getenv("AVX_MANTIS_CAND");  // read per call: tests flip it (0: three full passes)
+    const bool use_cand = cand_buf && !(cand_env && cand_env[0] == '0') && lds_tile + lds_stage <= 120 * 1024;
+    const size_t lds = lds_tile + (use_cand ? lds_stage : 0);
     AVX_REQUIRE(ctx, stack_k_tiled(up.K) && up.mm, "percentile through a resized stack: K=%d is not instantiated / no min-max table", up.K);
     AVX_STACK_K_SWITCH(up.K, AVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sel_pass_up<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)))
     // safe_norm's values lie in [0, 1]: every key starts with the bits 10 (positive, exponent < 128), so the three digits are taken from
@@ -1389,9 +1471,16 @@ int avx_uv_percentile_up_device(avx_ctx* ctx, const StackUp& up, double q, doubl
     // collide a quarter as often (the plain 11/11/10 split put an eighth of a uniform [0, 1] sample into ONE bin)
     a.prefix0 = 0x80000000u; a.mask0 = 0xc0000000u;
     const int shifts[3] = {19, 8, 0}, bits[3] = {11, 11, 8};
+    if (use_cand) { a.cand = cand_buf; a.cand_cnt = u.ticket + 56; }  // word 56 of the ticket block: zero at rest (uv_small_scratch), re-zeroed by the first pass
     for (int p = 0; p < 3; ++p) {
         a.pass = p; a.shift = shifts[p]; a.bits = bits[p];
-        AVX_STACK_K_SWITCH(up.K, hipLaunchKernelGGL(k_sel_pass_up<KT>, dim3(g), dim3(kT), lds, s, a))
+        if (p == 2 && use_cand) {  // the candidates of the first pass's bin instead of the whole stack
+            const int gc = (int)((size_t)ctx->num_cus < (size_t)g ? (size_t)ctx->num_cus : (size_t)g);
+            hipLaunchKernelGGL(k_sel_cand, dim3(gc), dim3(kT), 0, s, a);
+            break;
+        }
+        const size_t lds_p = (p == 1 && use_cand) ? lds : lds_tile;  // only the collecting pass carries the staging area
+        AVX_STACK_K_SWITCH(up.K, hipLaunchKernelGGL(k_sel_pass_up<KT>, dim3(g), dim3(kT), lds_p, s, a))
     }
     AVX_HIP(ctx, hipGetLastError());
     return AVX_OK;

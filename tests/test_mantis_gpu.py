@@ -113,6 +113,26 @@ def test_mantis_fused_finishing_stages_equal_the_seven_launch_route(monkeypatch)
         assert np.array_equal(base0, base1) and np.array_equal(out0, out1), (frame.shape, kw, float(np.abs(out0.astype(np.float64) - out1.astype(np.float64)).max()))
 
 
+def test_mantis_percentile_candidates_equal_three_full_passes(monkeypatch):
+    """Round 3: the second radix pass of the P95 over the (virtual) band stack copies the values of the first pass's bin out, the third pass
+    scans those candidates only (csrc/uv.hip::k_sel_cand).  Exact by construction: the frames must equal the three-full-pass route
+    (AVX_MANTIS_CAND=0), also where nearly every value shares a bin (flat frames: the candidate list is the whole stack)."""
+    from animal_vision_amd.animals import MantisShrimp
+    from animal_vision_amd.synthetic import noise_frame, structured_frame
+
+    flat = np.full((120, 200, 3), 97, np.uint8)
+    flat[40:80, 50:150] = (180, 60, 20)
+    for frame, kw in ((structured_frame(3, 270, 484), {}), (noise_frame(4, 133, 201), dict(hsi_scale=0.5, panorama_scale=1.2)), (structured_frame(5, 1080, 1920), {}), (flat, {}),
+                      (noise_frame(6, 720, 1280), {})):
+        m = MantisShrimp(**kw)
+        monkeypatch.setenv("AVX_MANTIS_CAND", "0")
+        base0, out0 = m.visualize(frame)
+        monkeypatch.delenv("AVX_MANTIS_CAND")
+        base1, out1 = m.visualize(frame)
+        base2, out2 = m.visualize(frame)  # again: the candidate counter must have been left clean
+        assert np.array_equal(base0, base1) and np.array_equal(out0, out1) and np.array_equal(out0, out2), (frame.shape, kw)
+
+
 def test_mantis_batch_on_lanes_equals_frame_by_frame(monkeypatch):
     """avx_mantis_u8_batch: the frames of a batch run on up to four internal streams with their own workspaces; every frame must
     come out exactly as from the single-frame entry point, with one lane and with four."""
