@@ -205,3 +205,26 @@ def test_gelu_tables_of_the_matrix_pipe_kernels_hold_their_stated_error():
         check((xp * phi).astype(np.float32).astype(np.float64) * 4.0, bound, ("prescaled", deg))
         big = np.abs(xs) > 4.0
         assert np.array_equal((xp * phi)[big] * 4, np.where(xs[big] > 0, xp[big] * 4, 0.0 * xp[big]))  # exactly x or 0 outside the clamp
+
+
+def test_fold_layernorm_is_the_affine_layernorm_followed_by_the_conv():
+    """ml/mst_plus_plus.py::fold_layernorm (the weight contract of avx_mst_ffn_fused_mx, include/avx.h): with gamma scaling W1's rows and W1^T beta in
+    row 31 (the padding channel, whose operand the kernel sets to 1), (normalised row with a 1 in slot 31) @ W' * s == (gamma * normalised + beta) @ W1,
+    for one and for several 32-wide channel groups."""
+    import torch
+
+    from animal_vision_amd.ml.mst_plus_plus import fold_layernorm, pad_channels
+
+    g = torch.Generator().manual_seed(5)
+    for c in (32, 64, 128):
+        real = c // 32 * 31
+        w1 = pad_channels(torch.randn(real, 4 * real, generator=g, dtype=torch.float64), (0, 1))     # (c, 4c): K = input channels
+        gam = pad_channels(torch.randn(real, generator=g, dtype=torch.float64), (0,))
+        bet = pad_channels(torch.randn(real, generator=g, dtype=torch.float64), (0,))
+        yn = pad_channels(torch.randn(7, real, generator=g, dtype=torch.float64), (1,))               # normalised rows, padding channels 0
+        want = (yn * gam + bet) @ w1
+        for s in (1.0, 4.0):
+            wf = fold_layernorm(w1, gam, bet, s).double()
+            op = yn.clone()
+            op[:, 31] = 1.0                                                                            # what the kernel writes into the bias slot
+            torch.testing.assert_close(op @ wf * s, want, rtol=2e-5, atol=2e-5)  # the fold itself runs in float32
